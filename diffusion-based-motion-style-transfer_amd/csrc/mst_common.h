@@ -1,0 +1,132 @@
+// Shared device helpers for the gfx950 denoising kernels (wave64, MFMA 32x32x16 f16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// model constants (utils/model_util.py:160-167 hard-codes heads/ff; latent_dim default 512)
+#define MST_D 512
+#define MST_H 4
+#define MST_HD 128
+#define MST_FF 1024
+
+// schedule table rows (include/mst_engine.h enum mst_table)
+#define TAB_SQRT_AC 0
+#define TAB_SQRT_1M_AC 1
+#define TAB_COEF1 2
+#define TAB_COEF2 3
+#define TAB_LOGVAR 4
+#define TAB_SQRT_RECIP_AC 5
+#define TAB_SQRT_RECIPM1_AC 6
+#define TAB_AC 7
+#define TAB_AC_PREV 8
+#define NTAB 9
+
+__device__ __forceinline__ f32x16 mfma_f16(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// C/D fragment of the 32x32 MFMA: lane holds column (lane & 31); register r holds
+// row (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+__device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ uint2 pack4_f16(float a, float b, float c, float d) {
+    f16x4 v = {(f16)a, (f16)b, (f16)c, (f16)d};
+    return __builtin_bit_cast(uint2, v);
+}
+
+// LDS image of a [rows][64] f16 K-slab (128-B rows): 16-B chunk c of row `row` lives at
+// chunk c ^ ((row >> 1) & 7).  With two rows per 256-B bank row this makes the ds_read_b128
+// fragment reads of a 32-row tile conflict-free (lane groups {0-3,12-15,20-27} ... see DESIGN.md).
+__device__ __forceinline__ int slab_off(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
+
+// exact-erf GELU (nn.TransformerEncoderLayer activation="gelu", mdm_forstyledataset.py:539-543)
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+// ------------------------------------------------------------------------------------------
+// Philox4x32-10 + Box-Muller: counter-based normals for the in-kernel noise mode.
+// Element (clip, f, t) of step `step` = component (f & 3) of the 4 normals generated from
+// counter (t, f >> 2, clip, step) under key (seed_lo, seed_hi).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ void philox_normal4(uint32_t t, uint32_t fq, uint32_t clip, uint32_t step,
+                                               uint64_t seed, float (&n)[4]) {
+    uint32_t r[4];
+    philox4x32_10(t, fq, clip, step, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    // u in (0, 1]: never log(0)
+    float u0 = ((float)(r[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);
+    float u1 = (float)(r[1] >> 8) * (1.0f / 16777216.0f);
+    float u2 = ((float)(r[2] >> 8) + 1.0f) * (1.0f / 16777216.0f);
+    float u3 = (float)(r[3] >> 8) * (1.0f / 16777216.0f);
+    float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
+    float sa, ca, sb, cb;
+    sincosf(6.283185307179586f * u1, &sa, &ca);
+    sincosf(6.283185307179586f * u3, &sb, &cb);
+    n[0] = ra * ca; n[1] = ra * sa; n[2] = rb * cb; n[3] = rb * sb;
+}
+
+// ------------------------------------------------------------------------------------------
+// The per-element diffusion update shared by the fused output-projection epilogue and the
+// stand-alone kernel.  Restates gaussian_diffusion.py:341-349 (inpainting blend), :404-412
+// (x0-hat -> posterior mean), :569-585 / inpainting_gaussian_diffusion.py:51-63 (ancestral step)
+// and inpainting_gaussian_diffusion.py:157-177 (DDIM step) in the reference's operation order.
+// ------------------------------------------------------------------------------------------
+struct StepCoef {   // per-clip scalars gathered from the float32 tables at index t
+    float c1, c2, sigma_ddpm;      // posterior_mean_coef1/2, nonzero * exp(0.5 * logvar)
+    float srac, srm1ac;            // sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod
+    float sq_abp, dir, sigma_ddim; // sqrt(abar_prev), sqrt(1 - abar_prev - sigma^2), nonzero * sigma
+};
+
+__device__ __forceinline__ StepCoef step_coef(const float* __restrict__ tab, int nsteps, int t, float eta) {
+    StepCoef c;
+    float nz = t != 0 ? 1.0f : 0.0f;
+    c.c1 = tab[TAB_COEF1 * nsteps + t];
+    c.c2 = tab[TAB_COEF2 * nsteps + t];
+    c.sigma_ddpm = nz * expf(0.5f * tab[TAB_LOGVAR * nsteps + t]);
+    c.srac = tab[TAB_SQRT_RECIP_AC * nsteps + t];
+    c.srm1ac = tab[TAB_SQRT_RECIPM1_AC * nsteps + t];
+    float ab = tab[TAB_AC * nsteps + t], abp = tab[TAB_AC_PREV * nsteps + t];
+    float sigma = eta * sqrtf((1.0f - abp) / (1.0f - ab)) * sqrtf(1.0f - ab / abp);
+    c.sq_abp = sqrtf(abp);
+    c.dir = sqrtf(1.0f - abp - sigma * sigma);
+    c.sigma_ddim = nz * sigma;
+    return c;
+}
+
+// returns the next sample; x0-hat (after blend / clip) is written to *pred.
+template <int SAMPLER>
+__device__ __forceinline__ float step_update(const StepCoef& c, float model_out, float x, float noise,
+                                             bool has_blend, float mask, float motion, bool mask_noise,
+                                             bool clip, float* pred) {
+    float out = model_out;
+    if (has_blend) out = out * (1.0f - mask) + motion * mask;
+    if (clip) out = fminf(fmaxf(out, -1.0f), 1.0f);
+    *pred = out;
+    if (mask_noise) noise = noise * (1.0f - mask);
+    if (SAMPLER == 0) {
+        float mean = c.c1 * out + c.c2 * x;
+        return mean + c.sigma_ddpm * noise;
+    } else {
+        float eps = (c.srac * x - out) / c.srm1ac;
+        float mean_pred = out * c.sq_abp + c.dir * eps;
+        return mean_pred + c.sigma_ddim * noise;
+    }
+}

@@ -1,0 +1,125 @@
+// Bandwidth-bound and latency-bound helpers: weight conversion, the conditioning-token path (K1/K2),
+// the stand-alone q_sample / step kernels (K10/K11 for callers that bring their own model) and the
+// Philox normal fill.
+#pragma once
+#include "mst_common.h"
+
+namespace mst {
+
+// float32 [N][K] -> f16 [Npad][Kpad], zero padded
+__global__ void k_convert_pad(const float* __restrict__ src, int N, int K, f16* __restrict__ dst, int Npad, int Kpad) {
+    size_t total = (size_t)Npad * Kpad;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int n = (int)(i / Kpad), k = (int)(i - (size_t)n * Kpad);
+        dst[i] = (n < N && k < K) ? (f16)src[(size_t)n * K + k] : (f16)0.0f;
+    }
+}
+
+__global__ void k_copy_pad_f32(const float* __restrict__ src, int n, float* __restrict__ dst, int npad) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < npad) dst[i] = i < n ? src[i] : 0.f;
+}
+
+// K1/K2: y[row][n] = act(sum_k in[row][k] * rowscale[row] * W[n][k] + b[n]) in float32.
+// One wave per output element group: lanes stride K (coalesced W rows), shuffle reduce.
+// gather != null: input row = table[gather[row]] (timestep embedding: pe[t]).
+// act: 0 none, 1 SiLU.   rows_zero_from: rows >= that index use a zero input (uncond half).
+__global__ __launch_bounds__(256) void k_rowwise_linear(const float* __restrict__ in, int ldin,
+                                                        const long long* __restrict__ gather,
+                                                        const float* __restrict__ rowscale, int rows_zero_from,
+                                                        const float* __restrict__ W, const float* __restrict__ b,
+                                                        int K, int N, int act, float* __restrict__ out, int in_row_mod) {
+    const int row = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int src_row = in_row_mod > 0 ? row % in_row_mod : row;
+    const float* x = in + (size_t)(gather ? gather[src_row] : src_row) * ldin;
+    float rs = 1.0f;
+    if (rowscale) rs = rowscale[src_row];
+    if (row >= rows_zero_from) rs = 0.0f;
+    for (int n = blockIdx.y * 4 + wave; n < N; n += gridDim.y * 4) {
+        const float* w = W + (size_t)n * K;
+        float s = 0.f;
+        for (int k = lane; k < K; k += 64) s += (x[k] * rs) * w[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) {
+            float v = s + b[n];
+            if (act == 1) v = v / (1.0f + __expf(-v));
+            out[(size_t)row * N + n] = v;
+        }
+    }
+}
+
+// token 0 of every clip: h[clip*S][:] = temb[row] + textproj[clip] + pe[0]  (mdm :609-621)
+// uniform_row >= 0: every clip uses that temb row (sampling loop: one t per step);
+// uniform_row < 0: clip uses temb row (clip % temb_mod) (per-clip t; the CFG halves share rows).
+__global__ void k_cond_token(const float* __restrict__ temb, int uniform_row, int temb_mod,
+                             const float* __restrict__ textproj, const float* __restrict__ pe, int S, int rows,
+                             float* __restrict__ h32, f16* __restrict__ h16) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * MST_D) return;
+    int clip = i / MST_D, f = i - clip * MST_D;
+    int tr = uniform_row >= 0 ? uniform_row : clip % temb_mod;
+    float v = temb[(size_t)tr * MST_D + f] + textproj[(size_t)clip * MST_D + f];
+    v += pe[f];
+    size_t o = (size_t)clip * S * MST_D + f;
+    h32[o] = v;
+    h16[o] = (f16)v;
+}
+
+// K11 stand-alone: x_t = sqrt(abar_t) x0 + sqrt(1-abar_t) (noise * (1 - mask))
+__global__ void k_q_sample(const float* __restrict__ tab, int nsteps, const float* __restrict__ x0,
+                           const float* __restrict__ noise, const float* __restrict__ mask,
+                           const long long* __restrict__ t, long long per_clip, float* __restrict__ out) {
+    const int clip = blockIdx.y;
+    const int tt = (int)t[clip];
+    const float a = tab[TAB_SQRT_AC * nsteps + tt], b = tab[TAB_SQRT_1M_AC * nsteps + tt];
+    const size_t base = (size_t)clip * per_clip;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per_clip; i += (long long)gridDim.x * blockDim.x) {
+        float n = noise[base + i];
+        if (mask) n = n * (1.0f - mask[base + i]);
+        out[base + i] = a * x0[base + i] + b * n;
+    }
+}
+
+// K10 / K10' stand-alone (model output produced elsewhere)
+template <int SAMPLER>
+__global__ void k_step_epilogue(const float* __restrict__ tab, int nsteps, float eta,
+                                const float* __restrict__ model_out, const float* __restrict__ x,
+                                const float* __restrict__ noise, const float* __restrict__ mask,
+                                const float* __restrict__ motion, const long long* __restrict__ t,
+                                long long per_clip, int mask_noise, int clip_denoised,
+                                float* __restrict__ sample, float* __restrict__ xstart) {
+    const int clip = blockIdx.y;
+    const StepCoef sc = step_coef(tab, nsteps, (int)t[clip], eta);
+    const bool blend = mask != nullptr && motion != nullptr;
+    const size_t base = (size_t)clip * per_clip;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per_clip; i += (long long)gridDim.x * blockDim.x) {
+        size_t idx = base + i;
+        float m = mask ? mask[idx] : 0.f;
+        float mot = blend ? motion[idx] : 0.f;
+        float pred;
+        float nx = step_update<SAMPLER>(sc, model_out[idx], x[idx], noise ? noise[idx] : 0.f, blend, m, mot,
+                                        mask_noise && mask, clip_denoised, &pred);
+        if (sample) sample[idx] = nx;
+        if (xstart) xstart[idx] = pred;
+    }
+}
+
+// same counter mapping as the fused epilogue: element (clip, f, t) <- component f & 3
+__global__ void k_philox_normal(float* __restrict__ out, int F, int T, unsigned long long seed, unsigned step) {
+    const int clip = blockIdx.y;
+    const int FQ = (F + 3) >> 2;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < FQ * T; i += gridDim.x * blockDim.x) {
+        int fq = i / T, t = i - fq * T;
+        float n[4];
+        philox_normal4((unsigned)t, (unsigned)fq, (unsigned)clip, step, seed, n);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            int f = fq * 4 + j;
+            if (f < F) out[((size_t)clip * F + f) * T + t] = n[j];
+        }
+    }
+}
+
+}  // namespace mst

@@ -1,0 +1,625 @@
+// libmst_engine.so -- host side: engine state, launch sequence, C ABI (include/mst_engine.h).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mst_engine.h"
+#include "mst_attn.h"
+#include "mst_common.h"
+#include "mst_elem.h"
+#include "mst_gemm.h"
+
+using namespace mst;
+
+// ------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+static int fail(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+#define HIPCHECK(x)                                                                              \
+    do {                                                                                         \
+        hipError_t _e = (x);                                                                     \
+        if (_e != hipSuccess) return fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+#define CHECK(x)                 \
+    do {                         \
+        int _r = (x);            \
+        if (_r) return _r;       \
+    } while (0)
+
+extern "C" const char* mst_last_error(void) { return g_err; }
+extern "C" int mst_version(void) { return 1; }
+
+// ------------------------------------------------------------------------------------------ state
+struct mst_schedule {
+    int n = 0, device = 0;
+    float* tab = nullptr;          // [NTAB][n] float32
+    long long* tmap = nullptr;     // [n] int64 original-process timesteps
+};
+
+struct LayerW {
+    f16 *w_in = nullptr, *w_out = nullptr, *w1 = nullptr, *w2 = nullptr;
+    float *b_in = nullptr, *b_out = nullptr, *b1 = nullptr, *b2 = nullptr;
+    float *g1 = nullptr, *be1 = nullptr, *g2 = nullptr, *be2 = nullptr;
+};
+
+enum Family { FAM_COND = 0, FAM_EMBED_IN, FAM_QKV, FAM_ATTN, FAM_OUTPROJ_LN, FAM_FFN1, FAM_FFN2_LN, FAM_EMBED_OUT, FAM_COUNT };
+static const char* kFamilyNames[FAM_COUNT] = {"cond_token", "embed_in", "qkv_gemm", "attention", "outproj_ln_gemm",
+                                              "ffn1_gelu_gemm", "ffn2_ln_gemm", "embed_out_step"};
+
+struct ProfPoint { int fam; hipEvent_t a, b; };
+
+struct mst_engine {
+    mst_config cfg;
+    int S_max = 0, M_pad = 0, kin_pad = 0, nt_out = 0, fout_pad = 0;
+    LayerW L[16];
+    f16 *w_pose_in = nullptr, *w_pose_out = nullptr;
+    float *b_pose_in = nullptr, *b_pose_out = nullptr;
+    float *w_t0 = nullptr, *b_t0 = nullptr, *w_t2 = nullptr, *b_t2 = nullptr, *w_text = nullptr, *b_text = nullptr;
+    float* pe = nullptr;
+    // workspace
+    float* hs = nullptr;
+    f16 *hx = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr;
+    float *temb_hid = nullptr, *temb = nullptr, *textproj = nullptr;
+    int temb_cap = 0;
+    std::vector<std::string> loaded;
+    int text_batch = 0, text_cfg = 0;
+    int dbg_layer = -1, dbg_stage = -1;   // stop the trunk after (layer, stage); -1 = run everything
+    // profiling
+    int prof_on = 0, prof_now = 0, prof_period = 16;
+    std::vector<ProfPoint> prof_pts;
+    size_t prof_used = 0;
+    double prof_ms[FAM_COUNT] = {0};
+    int prof_n[FAM_COUNT] = {0};
+};
+
+template <class T>
+static int dmalloc(T** p, size_t count) {
+    HIPCHECK(hipMalloc((void**)p, count * sizeof(T)));
+    HIPCHECK(hipMemset(*p, 0, count * sizeof(T)));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ schedule
+extern "C" int mst_schedule_create(int32_t num_steps, const float* tables_host, const int32_t* timestep_map_host,
+                                   int32_t device, mst_schedule** out) {
+    if (!out || !tables_host || !timestep_map_host || num_steps <= 0) return fail("mst_schedule_create: bad arguments");
+    HIPCHECK(hipSetDevice(device));
+    mst_schedule* s = new mst_schedule();
+    s->n = num_steps;
+    s->device = device;
+    HIPCHECK(hipMalloc((void**)&s->tab, sizeof(float) * NTAB * num_steps));
+    HIPCHECK(hipMalloc((void**)&s->tmap, sizeof(long long) * num_steps));
+    HIPCHECK(hipMemcpy(s->tab, tables_host, sizeof(float) * NTAB * num_steps, hipMemcpyHostToDevice));
+    std::vector<long long> tm(num_steps);
+    for (int i = 0; i < num_steps; i++) tm[i] = timestep_map_host[i];
+    HIPCHECK(hipMemcpy(s->tmap, tm.data(), sizeof(long long) * num_steps, hipMemcpyHostToDevice));
+    *out = s;
+    return 0;
+}
+
+extern "C" void mst_schedule_destroy(mst_schedule* s) {
+    if (!s) return;
+    (void)hipFree(s->tab);
+    (void)hipFree(s->tmap);
+    delete s;
+}
+
+// ------------------------------------------------------------------------------------------ engine
+extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
+    if (!c || !out) return fail("mst_engine_create: null argument");
+    if (c->latent_dim != MST_D || c->num_heads != MST_H || c->ff_size != MST_FF)
+        return fail("mst_engine_create: kernels are built for latent_dim 512 / 4 heads / ff 1024 (got %d/%d/%d)",
+                    c->latent_dim, c->num_heads, c->ff_size);
+    if (c->num_layers < 1 || c->num_layers > 16) return fail("mst_engine_create: num_layers must be 1..16");
+    if (c->feats < 1 || c->feats > 384) return fail("mst_engine_create: feats must be 1..384 (got %d)", c->feats);
+    if (c->max_frames < 1 || c->max_frames > 223) return fail("mst_engine_create: max_frames must be 1..223 (got %d)", c->max_frames);
+    if (c->max_rows < 1) return fail("mst_engine_create: max_rows must be >= 1");
+    if (c->clip_dim < 1 || c->pe_len < c->max_frames + 1) return fail("mst_engine_create: bad clip_dim / pe_len");
+    HIPCHECK(hipSetDevice(c->device));
+    mst_engine* e = new mst_engine();
+    e->cfg = *c;
+    e->S_max = c->max_frames + 1;
+    size_t M = (size_t)c->max_rows * e->S_max;
+    e->M_pad = (int)(((M + 127) / 128) * 128);
+    e->kin_pad = ((c->feats + 63) / 64) * 64;
+    e->nt_out = (c->feats + 127) / 128;
+    e->fout_pad = e->nt_out * 128;
+    for (int l = 0; l < c->num_layers; l++) {
+        LayerW& w = e->L[l];
+        CHECK(dmalloc(&w.w_in, (size_t)3 * MST_D * MST_D));
+        CHECK(dmalloc(&w.w_out, (size_t)MST_D * MST_D));
+        CHECK(dmalloc(&w.w1, (size_t)MST_FF * MST_D));
+        CHECK(dmalloc(&w.w2, (size_t)MST_D * MST_FF));
+        CHECK(dmalloc(&w.b_in, 3 * MST_D));
+        CHECK(dmalloc(&w.b_out, MST_D));
+        CHECK(dmalloc(&w.b1, MST_FF));
+        CHECK(dmalloc(&w.b2, MST_D));
+        CHECK(dmalloc(&w.g1, MST_D));
+        CHECK(dmalloc(&w.be1, MST_D));
+        CHECK(dmalloc(&w.g2, MST_D));
+        CHECK(dmalloc(&w.be2, MST_D));
+    }
+    CHECK(dmalloc(&e->w_pose_in, (size_t)MST_D * e->kin_pad));
+    CHECK(dmalloc(&e->b_pose_in, MST_D));
+    CHECK(dmalloc(&e->w_pose_out, (size_t)e->fout_pad * MST_D));
+    CHECK(dmalloc(&e->b_pose_out, e->fout_pad));
+    CHECK(dmalloc(&e->w_t0, (size_t)MST_D * MST_D));
+    CHECK(dmalloc(&e->b_t0, MST_D));
+    CHECK(dmalloc(&e->w_t2, (size_t)MST_D * MST_D));
+    CHECK(dmalloc(&e->b_t2, MST_D));
+    CHECK(dmalloc(&e->w_text, (size_t)MST_D * c->clip_dim));
+    CHECK(dmalloc(&e->b_text, MST_D));
+    CHECK(dmalloc(&e->pe, (size_t)c->pe_len * MST_D));
+    CHECK(dmalloc(&e->hs, (size_t)e->M_pad * MST_D));
+    CHECK(dmalloc(&e->hx, (size_t)e->M_pad * MST_D));
+    CHECK(dmalloc(&e->qkv, (size_t)e->M_pad * 3 * MST_D));
+    CHECK(dmalloc(&e->att, (size_t)e->M_pad * MST_D));
+    CHECK(dmalloc(&e->hid, (size_t)e->M_pad * MST_FF));
+    e->temb_cap = c->max_rows > 1024 ? c->max_rows : 1024;
+    CHECK(dmalloc(&e->temb_hid, (size_t)e->temb_cap * MST_D));
+    CHECK(dmalloc(&e->temb, (size_t)e->temb_cap * MST_D));
+    CHECK(dmalloc(&e->textproj, (size_t)c->max_rows * MST_D));
+    *out = e;
+    return 0;
+}
+
+extern "C" void mst_engine_destroy(mst_engine* e) {
+    if (!e) return;
+    for (int l = 0; l < e->cfg.num_layers; l++) {
+        LayerW& w = e->L[l];
+        void* p[] = {w.w_in, w.w_out, w.w1, w.w2, w.b_in, w.b_out, w.b1, w.b2, w.g1, w.be1, w.g2, w.be2};
+        for (void* q : p) (void)hipFree(q);
+    }
+    void* p[] = {e->w_pose_in, e->b_pose_in, e->w_pose_out, e->b_pose_out, e->w_t0, e->b_t0, e->w_t2, e->b_t2,
+                 e->w_text, e->b_text, e->pe, e->hs, e->hx, e->qkv, e->att, e->hid, e->temb_hid, e->temb, e->textproj};
+    for (void* q : p) (void)hipFree(q);
+    for (auto& pp : e->prof_pts) {
+        (void)hipEventDestroy(pp.a);
+        (void)hipEventDestroy(pp.b);
+    }
+    delete e;
+}
+
+// ------------------------------------------------------------------------------------------ weights
+static int put_matrix(const float* src, int N, int K, f16* dst, int Npad, int Kpad, hipStream_t st) {
+    hipLaunchKernelGGL(k_convert_pad, dim3(1024), dim3(256), 0, st, src, N, K, dst, Npad, Kpad);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+static int put_vector(const float* src, int n, float* dst, int npad, hipStream_t st) {
+    hipLaunchKernelGGL(k_copy_pad_f32, dim3((npad + 255) / 256), dim3(256), 0, st, src, n, dst, npad);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+static bool shape_is(const int64_t* s, int nd, int64_t a, int64_t b = -1) {
+    if (b < 0) return nd == 1 && s[0] == a;
+    return nd == 2 && s[0] == a && s[1] == b;
+}
+
+extern "C" int mst_load_weight(mst_engine* e, const char* name, const float* src, const int64_t* shape, int32_t ndim,
+                               void* stream) {
+    if (!e || !name || !src || !shape) return fail("mst_load_weight: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHECK(hipSetDevice(e->cfg.device));
+    const int F = e->cfg.feats, C = e->cfg.clip_dim;
+    std::string n(name);
+    int rc = -1;
+    int layer = -1;
+    char rest[128] = "";
+    if (sscanf(name, "seqTransEncoder.layers.%d.%127s", &layer, rest) == 2) {
+        if (layer < 0 || layer >= e->cfg.num_layers) return fail("mst_load_weight: layer %d out of range", layer);
+        LayerW& w = e->L[layer];
+        std::string r(rest);
+#define MAT(key, N_, K_, dst) if (r == key) { if (!shape_is(shape, ndim, N_, K_)) return fail("mst_load_weight: %s: bad shape", name); rc = put_matrix(src, N_, K_, dst, N_, K_, st); }
+#define VEC(key, N_, dst) if (r == key) { if (!shape_is(shape, ndim, N_)) return fail("mst_load_weight: %s: bad shape", name); rc = put_vector(src, N_, dst, N_, st); }
+        MAT("self_attn.in_proj_weight", 3 * MST_D, MST_D, w.w_in)
+        VEC("self_attn.in_proj_bias", 3 * MST_D, w.b_in)
+        MAT("self_attn.out_proj.weight", MST_D, MST_D, w.w_out)
+        VEC("self_attn.out_proj.bias", MST_D, w.b_out)
+        MAT("linear1.weight", MST_FF, MST_D, w.w1)
+        VEC("linear1.bias", MST_FF, w.b1)
+        MAT("linear2.weight", MST_D, MST_FF, w.w2)
+        VEC("linear2.bias", MST_D, w.b2)
+        VEC("norm1.weight", MST_D, w.g1)
+        VEC("norm1.bias", MST_D, w.be1)
+        VEC("norm2.weight", MST_D, w.g2)
+        VEC("norm2.bias", MST_D, w.be2)
+#undef MAT
+#undef VEC
+    } else if (n == "input_process.poseEmbedding.weight") {
+        if (!shape_is(shape, ndim, MST_D, F)) return fail("mst_load_weight: %s: bad shape", name);
+        rc = put_matrix(src, MST_D, F, e->w_pose_in, MST_D, e->kin_pad, st);
+    } else if (n == "input_process.poseEmbedding.bias") {
+        if (!shape_is(shape, ndim, MST_D)) return fail("mst_load_weight: %s: bad shape", name);
+        rc = put_vector(src, MST_D, e->b_pose_in, MST_D, st);
+    } else if (n == "output_process.poseFinal.weight") {
+        if (!shape_is(shape, ndim, F, MST_D)) return fail("mst_load_weight: %s: bad shape", name);
+        rc = put_matrix(src, F, MST_D, e->w_pose_out, e->fout_pad, MST_D, st);
+    } else if (n == "output_process.poseFinal.bias") {
+        if (!shape_is(shape, ndim, F)) return fail("mst_load_weight: %s: bad shape", name);
+        rc = put_vector(src, F, e->b_pose_out, e->fout_pad, st);
+    } else if (n == "embed_timestep.time_embed.0.weight" || n == "embed_timestep.time_embed.2.weight") {
+        if (!shape_is(shape, ndim, MST_D, MST_D)) return fail("mst_load_weight: %s: bad shape", name);
+        rc = put_vector(src, MST_D * MST_D, n[26] == '0' ? e->w_t0 : e->w_t2, MST_D * MST_D, st);
+    } else if (n == "embed_timestep.time_embed.0.bias" || n == "embed_timestep.time_embed.2.bias") {
+        if (!shape_is(shape, ndim, MST_D)) return fail("mst_load_weight: %s: bad shape", name);
+        rc = put_vector(src, MST_D, n[26] == '0' ? e->b_t0 : e->b_t2, MST_D, st);
+    } else if (n == "embed_text.weight") {
+        if (!shape_is(shape, ndim, MST_D, C)) return fail("mst_load_weight: %s: bad shape", name);
+        rc = put_vector(src, MST_D * C, e->w_text, MST_D * C, st);
+    } else if (n == "embed_text.bias") {
+        if (!shape_is(shape, ndim, MST_D)) return fail("mst_load_weight: %s: bad shape", name);
+        rc = put_vector(src, MST_D, e->b_text, MST_D, st);
+    } else if (n == "sequence_pos_encoder.pe") {
+        int64_t rows = ndim == 3 ? shape[0] : (ndim == 2 ? shape[0] : -1);
+        int64_t cols = ndim == 3 ? shape[1] * shape[2] : (ndim == 2 ? shape[1] : -1);
+        if (cols != MST_D || rows < e->cfg.pe_len) return fail("mst_load_weight: %s: bad shape", name);
+        rc = put_vector(src, e->cfg.pe_len * MST_D, e->pe, e->cfg.pe_len * MST_D, st);
+    }
+    if (rc == -1) return fail("mst_load_weight: unknown tensor name '%s'", name);
+    if (rc) return rc;
+    bool seen = false;
+    for (auto& s : e->loaded) seen |= (s == n);
+    if (!seen) e->loaded.push_back(n);
+    return 0;
+}
+
+extern "C" int mst_weights_complete(const mst_engine* e) {
+    if (!e) return fail("mst_weights_complete: null engine");
+    size_t want = (size_t)e->cfg.num_layers * 12 + 11;
+    if (e->loaded.size() != want) return fail("mst_weights_complete: %zu of %zu tensors loaded", e->loaded.size(), want);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ profiling
+extern "C" int mst_profile_enable(mst_engine* e, int32_t on) {
+    if (!e) return fail("mst_profile_enable: null engine");
+    e->prof_on = on > 0 ? 1 : 0;          // on = N > 0: instrument every N-th step of a loop
+    e->prof_period = on > 0 ? on : 16;
+    if (e->prof_on && e->prof_pts.empty()) {
+        e->prof_pts.resize(8192);
+        for (auto& p : e->prof_pts) {
+            HIPCHECK(hipEventCreate(&p.a));
+            HIPCHECK(hipEventCreate(&p.b));
+        }
+    }
+    e->prof_used = 0;
+    for (int i = 0; i < FAM_COUNT; i++) { e->prof_ms[i] = 0; e->prof_n[i] = 0; }
+    return 0;
+}
+
+extern "C" int mst_profile_read(mst_engine* e, const char** names, float* total_ms, int32_t* launches, int32_t cap) {
+    if (!e) return -1;
+    // caller has synchronised the stream
+    for (size_t i = 0; i < e->prof_used; i++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e->prof_pts[i].a, e->prof_pts[i].b) == hipSuccess) {
+            e->prof_ms[e->prof_pts[i].fam] += ms;
+            e->prof_n[e->prof_pts[i].fam] += 1;
+        }
+    }
+    e->prof_used = 0;
+    int n = FAM_COUNT < cap ? FAM_COUNT : cap;
+    for (int i = 0; i < n; i++) {
+        names[i] = kFamilyNames[i];
+        total_ms[i] = (float)e->prof_ms[i];
+        launches[i] = e->prof_n[i];
+    }
+    return n;
+}
+
+struct ProfScope {
+    mst_engine* e; hipStream_t st; ProfPoint* p = nullptr;
+    ProfScope(mst_engine* e_, int fam, hipStream_t st_) : e(e_), st(st_) {
+        if (e->prof_on && e->prof_now && e->prof_used < e->prof_pts.size()) {
+            p = &e->prof_pts[e->prof_used++];
+            p->fam = fam;
+            (void)hipEventRecord(p->a, st);
+        }
+    }
+    ~ProfScope() { if (p) (void)hipEventRecord(p->b, st); }
+};
+
+// ------------------------------------------------------------------------------------------ launches
+template <int BT, int NT, int NX, class XL, class EPI>
+static int launch_gemm(dim3 grid, const XL& xl, const f16* W, int ldw, int K, const EPI& epi, hipStream_t st) {
+    using TL = Tile<BT, NT, NX>;
+    auto kern = k_gemm<BT, NT, NX, XL, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TL::SMEM));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(512), TL::SMEM, st, xl, W, ldw, K, epi);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+template <int NKT>
+static int launch_attn_n(const f16* qkv, f16* out, int S, int rows, hipStream_t st) {
+    auto kern = k_attention<NKT>;
+    static bool attr_set = false;
+    const int smem = NKT * 32 * 256 * 2;
+    if (!attr_set) {
+        HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(rows * MST_H), dim3(512), smem, st, qkv, out, S);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+static int launch_attn(const f16* qkv, f16* out, int S, int rows, hipStream_t st) {
+    switch ((S + 31) / 32) {
+        case 1: return launch_attn_n<1>(qkv, out, S, rows, st);
+        case 2: return launch_attn_n<2>(qkv, out, S, rows, st);
+        case 3: return launch_attn_n<3>(qkv, out, S, rows, st);
+        case 4: return launch_attn_n<4>(qkv, out, S, rows, st);
+        case 5: return launch_attn_n<5>(qkv, out, S, rows, st);
+        case 6: return launch_attn_n<6>(qkv, out, S, rows, st);
+        case 7: return launch_attn_n<7>(qkv, out, S, rows, st);
+    }
+    return fail("attention: S=%d unsupported", S);
+}
+
+static int rowwise_linear(const float* in, int ldin, const long long* gather, const float* rowscale, int rows_zero_from,
+                          const float* W, const float* b, int K, int N, int act, float* out, int in_row_mod, int rows,
+                          hipStream_t st) {
+    hipLaunchKernelGGL(k_rowwise_linear, dim3(rows, 16), dim3(256), 0, st, in, ldin, gather, rowscale, rows_zero_from, W, b,
+                       K, N, act, out, in_row_mod);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+// timestep embedding rows: temb[j] = W2 silu(W0 pe[tidx[j]] + b0) + b2   (mdm :415-422)
+static int timestep_rows(mst_engine* e, const long long* tidx_dev, int rows, hipStream_t st) {
+    if (rows > e->temb_cap) return fail("timestep_rows: %d rows exceed capacity %d", rows, e->temb_cap);
+    CHECK(rowwise_linear(e->pe, MST_D, tidx_dev, nullptr, rows, e->w_t0, e->b_t0, MST_D, MST_D, 1, e->temb_hid, 0, rows, st));
+    CHECK(rowwise_linear(e->temb_hid, MST_D, nullptr, nullptr, rows, e->w_t2, e->b_t2, MST_D, MST_D, 0, e->temb, 0, rows, st));
+    return 0;
+}
+
+extern "C" int mst_set_text(mst_engine* e, const float* text_emb, const float* keep, int32_t batch, int32_t cfg, void* stream) {
+    if (!e || !text_emb) return fail("mst_set_text: null argument");
+    int rows = cfg ? 2 * batch : batch;
+    if (batch < 1 || rows > e->cfg.max_rows) return fail("mst_set_text: %d rows exceed max_rows %d", rows, e->cfg.max_rows);
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHECK(hipSetDevice(e->cfg.device));
+    CHECK(rowwise_linear(text_emb, e->cfg.clip_dim, nullptr, keep, cfg ? batch : rows, e->w_text, e->b_text, e->cfg.clip_dim,
+                         MST_D, 0, e->textproj, batch, rows, st));
+    e->text_batch = batch;
+    e->text_cfg = cfg ? 1 : 0;
+    return 0;
+}
+
+// K3 .. K8: token stream through the encoder stack.  rows = clips through the transformer.
+static int run_trunk(mst_engine* e, const float* x, int clips_x, int rows, int T, int temb_uniform_row, int temb_mod,
+                     hipStream_t st) {
+    const int S = T + 1, M = rows * S;
+    {
+        ProfScope ps(e, FAM_COND, st);
+        hipLaunchKernelGGL(k_cond_token, dim3((rows * MST_D + 255) / 256), dim3(256), 0, st, e->temb, temb_uniform_row,
+                           temb_mod, e->textproj, e->pe, S, rows, e->hs, e->hx);
+        HIPCHECK(hipGetLastError());
+    }
+    {
+        // the doubled CFG batch feeds the same x to both halves: frames of clip r come from x[r % clips_x]
+        ProfScope ps(e, FAM_EMBED_IN, st);
+        for (int half = 0; half * clips_x < rows; half++) {
+            XInput xl{x, e->cfg.feats, T, clips_x * T};
+            size_t off = (size_t)half * clips_x * S * MST_D;
+            EpiEmbedIn epi{e->b_pose_in, e->pe, e->hs + off, e->hx + off, T, S, clips_x * T};
+            CHECK((launch_gemm<64, 4, 1>(dim3((clips_x * T + 63) / 64, 1), xl, e->w_pose_in, e->kin_pad, e->kin_pad, epi, st)));
+        }
+    }
+    if (e->dbg_stage == 0) return 0;
+#define DBG_STOP(stage) if (e->dbg_layer == l && e->dbg_stage == stage) return 0;
+    for (int l = 0; l < e->cfg.num_layers; l++) {
+        const LayerW& w = e->L[l];
+        {
+            ProfScope ps(e, FAM_QKV, st);
+            XRows xl{e->hx, MST_D};
+            EpiBiasF16 epi{w.b_in, e->qkv, 3 * MST_D, M, 0};
+            CHECK((launch_gemm<128, 4, 1>(dim3((M + 127) / 128, 3 * MST_D / 256), xl, w.w_in, MST_D, MST_D, epi, st)));
+        }
+        DBG_STOP(1)
+        {
+            ProfScope ps(e, FAM_ATTN, st);
+            CHECK(launch_attn(e->qkv, e->att, S, rows, st));
+        }
+        DBG_STOP(2)
+        {
+            ProfScope ps(e, FAM_OUTPROJ_LN, st);
+            XRows xl{e->att, MST_D};
+            EpiResidLN epi{w.b_out, e->hs, w.g1, w.be1, e->hs, e->hx, M};
+            CHECK((launch_gemm<64, 4, 1>(dim3((M + 63) / 64, 1), xl, w.w_out, MST_D, MST_D, epi, st)));
+        }
+        DBG_STOP(3)
+        {
+            ProfScope ps(e, FAM_FFN1, st);
+            XRows xl{e->hx, MST_D};
+            EpiBiasF16 epi{w.b1, e->hid, MST_FF, M, 1};
+            CHECK((launch_gemm<128, 4, 1>(dim3((M + 127) / 128, MST_FF / 256), xl, w.w1, MST_D, MST_D, epi, st)));
+        }
+        DBG_STOP(4)
+        {
+            ProfScope ps(e, FAM_FFN2_LN, st);
+            XRows xl{e->hid, MST_FF};
+            EpiResidLN epi{w.b2, e->hs, w.g2, w.be2, e->hs, e->hx, M};
+            CHECK((launch_gemm<64, 4, 1>(dim3((M + 63) / 64, 1), xl, w.w2, MST_FF, MST_FF, epi, st)));
+        }
+        DBG_STOP(5)
+    }
+#undef DBG_STOP
+    return 0;
+}
+
+template <int MODE, int NT, int NX>
+static int launch_out(mst_engine* e, int batch, int T, float* out, const StepArgs& sa, hipStream_t st) {
+    const int S = T + 1;
+    XFrames xl{e->hx, MST_D, T, S, batch * T, batch * S, 64};
+    EpiEmbedOut<MODE> epi{e->b_pose_out, e->cfg.feats, T, batch * T, out, sa};
+    return launch_gemm<64, NT, NX>(dim3((batch * T + 63) / 64, 1), xl, e->w_pose_out, MST_D, MST_D, epi, st);
+}
+template <int MODE, int NT>
+static int launch_out_nx(mst_engine* e, int cfg, int batch, int T, float* out, const StepArgs& sa, hipStream_t st) {
+    return cfg ? launch_out<MODE, NT, 2>(e, batch, T, out, sa, st) : launch_out<MODE, NT, 1>(e, batch, T, out, sa, st);
+}
+template <int MODE>
+static int launch_out_nt(mst_engine* e, int cfg, int batch, int T, float* out, const StepArgs& sa, hipStream_t st) {
+    ProfScope ps(e, FAM_EMBED_OUT, st);
+    switch (e->nt_out) {
+        case 1: return launch_out_nx<MODE, 1>(e, cfg, batch, T, out, sa, st);
+        case 2: return launch_out_nx<MODE, 2>(e, cfg, batch, T, out, sa, st);
+        case 3: return launch_out_nx<MODE, 3>(e, cfg, batch, T, out, sa, st);
+    }
+    return fail("output projection: feats %d unsupported", e->cfg.feats);
+}
+
+static int check_ready(mst_engine* e, int batch, int frames, int cfg) {
+    if (!e) return fail("null engine");
+    CHECK(mst_weights_complete(e));
+    if (frames < 1 || frames > e->cfg.max_frames) return fail("frames %d outside 1..%d", frames, e->cfg.max_frames);
+    int rows = cfg ? 2 * batch : batch;
+    if (batch < 1 || rows > e->cfg.max_rows) return fail("batch %d (rows %d) exceeds max_rows %d", batch, rows, e->cfg.max_rows);
+    if (e->text_batch != batch || e->text_cfg != (cfg ? 1 : 0))
+        return fail("mst_set_text was not called for batch %d cfg %d (have %d/%d)", batch, cfg, e->text_batch, e->text_cfg);
+    return 0;
+}
+
+extern "C" int mst_forward(mst_engine* e, const float* x, const int64_t* t, const float* scale, int32_t batch, int32_t frames,
+                           int32_t cfg, float* out, void* stream) {
+    CHECK(check_ready(e, batch, frames, cfg));
+    if (!x || !t || !out || (cfg && !scale)) return fail("mst_forward: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHECK(hipSetDevice(e->cfg.device));
+    e->prof_now = e->prof_on;
+    CHECK(timestep_rows(e, (const long long*)t, batch, st));
+    const int rows = cfg ? 2 * batch : batch;
+    CHECK(run_trunk(e, x, batch, rows, frames, -1, batch, st));
+    StepArgs sa{};
+    sa.scale = scale;
+    return launch_out_nt<0>(e, cfg, batch, frames, out, sa, st);
+}
+
+extern "C" int mst_sample_loop(mst_engine* e, const mst_schedule* s, const mst_loop_args* a, void* stream) {
+    if (!s || !a) return fail("mst_sample_loop: null argument");
+    CHECK(check_ready(e, a->batch, a->frames, a->cfg));
+    if (a->t_start >= s->n || a->t_end < 0 || a->t_start < a->t_end)
+        return fail("mst_sample_loop: bad index range %d..%d for %d steps", a->t_start, a->t_end, s->n);
+    if (!a->x_dev || (a->cfg && !a->scale_dev)) return fail("mst_sample_loop: null x / scale");
+    if (a->noise_mode == MST_NOISE_BUFFER && !a->noise_dev) return fail("mst_sample_loop: noise buffer missing");
+    if (a->sampler != MST_SAMPLER_DDPM && a->sampler != MST_SAMPLER_DDIM) return fail("mst_sample_loop: bad sampler");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHECK(hipSetDevice(e->cfg.device));
+    const int nrun = a->t_start - a->t_end + 1;
+    const int rows = a->cfg ? 2 * a->batch : a->batch;
+    const size_t clip_elems = (size_t)a->batch * e->cfg.feats * a->frames;
+    // K1 hoisted: the timestep MLP for every index this loop visits (row j <-> index t_end + j)
+    e->prof_now = 0;
+    CHECK(timestep_rows(e, s->tmap + a->t_end, nrun, st));
+    for (int j = 0; j < nrun; j++) {
+        const int ti = a->t_start - j;
+        e->prof_now = e->prof_on && (j % e->prof_period == 0);
+        CHECK(run_trunk(e, a->x_dev, a->batch, rows, a->frames, ti - a->t_end, 0, st));
+        StepArgs sa{};
+        sa.tab = s->tab;
+        sa.nsteps = s->n;
+        sa.t = ti;
+        sa.eta = a->eta;
+        sa.mask = a->inpainting_mask_dev;
+        sa.motion = a->inpainted_motion_dev;
+        sa.noise = a->noise_mode == MST_NOISE_BUFFER ? a->noise_dev + (size_t)j * clip_elems : nullptr;
+        sa.scale = a->scale_dev;
+        sa.x = a->x_dev;
+        sa.sample = a->x_dev;
+        sa.xstart = a->xstart_dump_dev ? a->xstart_dump_dev + (size_t)j * clip_elems : nullptr;
+        sa.seed = a->seed;
+        sa.step = (unsigned)j;
+        sa.mask_noise = a->mask_noise;
+        sa.clip = a->clip_denoised;
+        sa.philox = a->noise_mode == MST_NOISE_PHILOX;
+        if (a->sampler == MST_SAMPLER_DDPM) CHECK(launch_out_nt<1>(e, a->cfg, a->batch, a->frames, nullptr, sa, st));
+        else CHECK(launch_out_nt<2>(e, a->cfg, a->batch, a->frames, nullptr, sa, st));
+    }
+    e->prof_now = 0;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ elementwise ABI
+extern "C" int mst_q_sample(const mst_schedule* s, const float* x0, const float* noise, const float* mask, const int64_t* t,
+                            int32_t batch, int64_t per_clip, float* out, void* stream) {
+    if (!s || !x0 || !noise || !t || !out || batch < 1 || per_clip < 1) return fail("mst_q_sample: bad arguments");
+    HIPCHECK(hipSetDevice(s->device));
+    int gx = (int)((per_clip + 255) / 256);
+    if (gx > 2048) gx = 2048;
+    hipLaunchKernelGGL(k_q_sample, dim3(gx, batch), dim3(256), 0, (hipStream_t)stream, s->tab, s->n, x0, noise, mask,
+                       (const long long*)t, (long long)per_clip, out);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mst_step_epilogue(const mst_schedule* s, const float* model_out, const float* x, const float* noise,
+                                 const float* mask, const float* motion, const int64_t* t, int32_t batch, int64_t per_clip,
+                                 int32_t sampler, float eta, int32_t mask_noise, int32_t clip_denoised, float* sample,
+                                 float* xstart, void* stream) {
+    if (!s || !model_out || !x || !t || batch < 1 || per_clip < 1) return fail("mst_step_epilogue: bad arguments");
+    HIPCHECK(hipSetDevice(s->device));
+    int gx = (int)((per_clip + 255) / 256);
+    if (gx > 2048) gx = 2048;
+    if (sampler == MST_SAMPLER_DDPM)
+        hipLaunchKernelGGL(k_step_epilogue<0>, dim3(gx, batch), dim3(256), 0, (hipStream_t)stream, s->tab, s->n, eta, model_out, x,
+                           noise, mask, motion, (const long long*)t, (long long)per_clip, mask_noise, clip_denoised, sample, xstart);
+    else if (sampler == MST_SAMPLER_DDIM)
+        hipLaunchKernelGGL(k_step_epilogue<1>, dim3(gx, batch), dim3(256), 0, (hipStream_t)stream, s->tab, s->n, eta, model_out, x,
+                           noise, mask, motion, (const long long*)t, (long long)per_clip, mask_noise, clip_denoised, sample, xstart);
+    else
+        return fail("mst_step_epilogue: bad sampler %d", sampler);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mst_philox_normal(float* out, int32_t batch, int32_t feats, int32_t frames, uint64_t seed, uint32_t step,
+                                 void* stream) {
+    if (!out || batch < 1 || feats < 1 || frames < 1) return fail("mst_philox_normal: bad arguments");
+    int n = ((feats + 3) / 4) * frames;
+    hipLaunchKernelGGL(k_philox_normal, dim3((n + 255) / 256, batch), dim3(256), 0, (hipStream_t)stream, out, feats, frames,
+                       (unsigned long long)seed, (unsigned)step);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ debug ABI
+extern "C" int mst_debug_stop_after(mst_engine* e, int32_t layer, int32_t stage) {
+    if (!e) return fail("mst_debug_stop_after: null engine");
+    e->dbg_layer = layer;
+    e->dbg_stage = stage;
+    return 0;
+}
+
+extern "C" int mst_debug_copy(mst_engine* e, const char* which, void* dst_dev, uint64_t nbytes, void* stream) {
+    if (!e || !which || !dst_dev) return fail("mst_debug_copy: null argument");
+    std::string w(which);
+    const void* src = nullptr;
+    size_t cap = 0;
+    if (w == "hs") { src = e->hs; cap = (size_t)e->M_pad * MST_D * 4; }
+    else if (w == "hx") { src = e->hx; cap = (size_t)e->M_pad * MST_D * 2; }
+    else if (w == "qkv") { src = e->qkv; cap = (size_t)e->M_pad * 3 * MST_D * 2; }
+    else if (w == "att") { src = e->att; cap = (size_t)e->M_pad * MST_D * 2; }
+    else if (w == "hid") { src = e->hid; cap = (size_t)e->M_pad * MST_FF * 2; }
+    else if (w == "temb") { src = e->temb; cap = (size_t)e->temb_cap * MST_D * 4; }
+    else if (w == "textproj") { src = e->textproj; cap = (size_t)e->cfg.max_rows * MST_D * 4; }
+    else return fail("mst_debug_copy: unknown buffer '%s'", which);
+    if (nbytes > cap) return fail("mst_debug_copy: %llu bytes requested, buffer holds %zu", (unsigned long long)nbytes, cap);
+    HIPCHECK(hipMemcpyAsync(dst_dev, src, nbytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}

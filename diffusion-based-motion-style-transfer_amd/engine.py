@@ -1,0 +1,227 @@
+"""Python handles on the native engine: `Schedule` (one diffusion process' tables on the device) and
+`DenoiserEngine` (one MDM-shaped denoiser: weights + workspace + the fused sampling loop).
+
+Everything here is plumbing -- tensor validation, pointer passing, stream selection; the arithmetic
+is in csrc/.  Reference counterparts are cited in include/mst_engine.h."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+SAMPLER_DDPM, SAMPLER_DDIM = 0, 1
+NOISE_BUFFER, NOISE_PHILOX = 0, 1
+
+# order of enum mst_table; names are the reference's attribute names (gaussian_diffusion.py:183-219)
+TABLE_ORDER = ("sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "posterior_mean_coef1",
+               "posterior_mean_coef2", "_log_variance", "sqrt_recip_alphas_cumprod",
+               "sqrt_recipm1_alphas_cumprod", "alphas_cumprod", "alphas_cumprod_prev")
+
+# engine tensor name -> where StyleDiffusion / MDM keep it (model/mdm_forstyledataset.py)
+PRIOR_TENSORS = (
+    "input_process.poseEmbedding.weight", "input_process.poseEmbedding.bias",
+    "output_process.poseFinal.weight", "output_process.poseFinal.bias",
+    "embed_timestep.time_embed.0.weight", "embed_timestep.time_embed.0.bias",
+    "embed_timestep.time_embed.2.weight", "embed_timestep.time_embed.2.bias",
+    "embed_text.weight", "embed_text.bias", "sequence_pos_encoder.pe")
+LAYER_TENSORS = (
+    "self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_attn.out_proj.weight",
+    "self_attn.out_proj.bias", "linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias",
+    "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias")
+
+
+def _f32c(t, device, what):
+    if not isinstance(t, torch.Tensor):
+        t = torch.as_tensor(np.asarray(t))
+    t = t.to(device=device, dtype=torch.float32)
+    if not t.is_contiguous():
+        t = t.contiguous()
+    if t.device.type != "cuda":
+        raise RuntimeError(f"{what}: the engine needs a GPU tensor")
+    return t
+
+
+class Schedule:
+    """Device copy of one diffusion process (enum mst_table order), built from the float64 numpy
+    tables of a GaussianDiffusion-like object or an `oracle.schedule`-style dict."""
+
+    def __init__(self, tables, timestep_map, device, log_variance=None):
+        get = (lambda k: tables[k]) if isinstance(tables, dict) else (lambda k: getattr(tables, k))
+        if log_variance is None:
+            log_variance = get("posterior_log_variance_clipped")      # FIXED_SMALL
+        rows = []
+        for name in TABLE_ORDER:
+            a = log_variance if name == "_log_variance" else get(name)
+            rows.append(np.asarray(a, dtype=np.float64).astype(np.float32))  # == `.float()` of :1615
+        tab = np.ascontiguousarray(np.stack(rows))
+        tmap = np.ascontiguousarray(np.asarray(timestep_map, dtype=np.int32))
+        self.num_steps = tab.shape[1]
+        assert tmap.shape == (self.num_steps,)
+        self.device = torch.device(device)
+        h = C.c_void_p()
+        N.check(N.lib().mst_schedule_create(self.num_steps, tab.ctypes.data_as(C.c_void_p),
+                                            tmap.ctypes.data_as(C.c_void_p), self.device.index or 0, C.byref(h)))
+        self.handle = h
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            N.lib().mst_schedule_destroy(h)
+            self.handle = None
+
+    # stand-alone elementwise kernels (any model callable) -------------------------------------
+    def q_sample(self, x_start, t, noise, mask=None):
+        dev = x_start.device
+        x_start = _f32c(x_start, dev, "x_start")
+        noise = _f32c(noise, dev, "noise")
+        mask = None if mask is None else _f32c(mask, dev, "mask")
+        t = t.to(device=dev, dtype=torch.int64).contiguous()
+        out = torch.empty_like(x_start)
+        B = x_start.shape[0]
+        N.check(N.lib().mst_q_sample(self.handle, N.ptr(x_start), N.ptr(noise), N.ptr(mask), N.ptr(t), B,
+                                     x_start.numel() // B, N.ptr(out), N.stream_ptr(dev)))
+        return out
+
+    def step(self, model_output, x, t, noise, sampler=SAMPLER_DDPM, eta=0.0, mask=None, motion=None,
+             mask_noise=False, clip_denoised=False):
+        """(sample, pred_xstart) of one p_sample / ddim_sample step given the model output."""
+        dev = x.device
+        mo = _f32c(model_output, dev, "model_output")
+        x = _f32c(x, dev, "x")
+        noise = None if noise is None else _f32c(noise, dev, "noise")
+        mask = None if mask is None else _f32c(mask, dev, "mask")
+        motion = None if motion is None else _f32c(motion, dev, "motion")
+        t = t.to(device=dev, dtype=torch.int64).contiguous()
+        sample, xstart = torch.empty_like(x), torch.empty_like(x)
+        B = x.shape[0]
+        N.check(N.lib().mst_step_epilogue(self.handle, N.ptr(mo), N.ptr(x), N.ptr(noise), N.ptr(mask), N.ptr(motion),
+                                          N.ptr(t), B, x.numel() // B, int(sampler), float(eta), int(bool(mask_noise)),
+                                          int(bool(clip_denoised)), N.ptr(sample), N.ptr(xstart), N.stream_ptr(dev)))
+        return sample, xstart
+
+
+class DenoiserEngine:
+    def __init__(self, feats, max_frames, max_rows, num_layers=8, device="cuda:0", latent_dim=512, num_heads=4,
+                 ff_size=1024, clip_dim=512, pe_len=5000):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("DenoiserEngine needs a GPU device; the HIP kernels are the only implementation")
+        self.cfg = N.MstConfig(feats, max_frames, max_rows, latent_dim, num_heads, ff_size, num_layers, clip_dim,
+                               pe_len, self.device.index or 0)
+        self.feats, self.max_frames, self.max_rows, self.num_layers = feats, max_frames, max_rows, num_layers
+        h = C.c_void_p()
+        N.check(N.lib().mst_engine_create(C.byref(self.cfg), C.byref(h)))
+        self.handle = h
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            N.lib().mst_engine_destroy(h)
+            self.handle = None
+
+    # ------------------------------------------------------------------------------ weights
+    def load_tensor(self, name, tensor):
+        t = _f32c(tensor, self.device, name)
+        shape = (C.c_int64 * t.dim())(*t.shape)
+        N.check(N.lib().mst_load_weight(self.handle, name.encode(), N.ptr(t), shape, t.dim(), N.stream_ptr(self.device)))
+
+    def load_state_dict(self, sd, layer_prefix="seqTransEncoder.layers.", prior_prefix="motion_enc.mdm_model.",
+                        pe=None):
+        """Load from a reference-layout state dict: encoder layers under `layer_prefix`, the frozen
+        prior's projections under `prior_prefix` (StyleDiffusion: 'seqTransEncoder.layers.' +
+        'motion_enc.mdm_model.'; the prior itself: 'motion_enc.mdm_model.seqTransEncoder.layers.')."""
+        for i in range(self.num_layers):
+            for k in LAYER_TENSORS:
+                self.load_tensor(f"seqTransEncoder.layers.{i}.{k}", sd[f"{layer_prefix}{i}.{k}"])
+        for k in PRIOR_TENSORS:
+            if k == "sequence_pos_encoder.pe" and pe is not None:
+                self.load_tensor(k, pe)
+            else:
+                self.load_tensor(k, sd[prior_prefix + k])
+        torch.cuda.current_stream(self.device).synchronize()   # sources may be temporaries
+        N.check(N.lib().mst_weights_complete(self.handle))
+
+    # ------------------------------------------------------------------------------ conditioning
+    def set_text(self, text_emb, keep=None, cfg=False):
+        te = _f32c(text_emb, self.device, "text_emb")
+        kp = None if keep is None else _f32c(keep, self.device, "keep")
+        N.check(N.lib().mst_set_text(self.handle, N.ptr(te), N.ptr(kp), te.shape[0], int(bool(cfg)),
+                                     N.stream_ptr(self.device)))
+        self._text_keepalive = (te, kp)
+
+    # ------------------------------------------------------------------------------ model call
+    def forward(self, x, t, scale=None, cfg=False):
+        x = _f32c(x, self.device, "x")
+        B, F, one, T = x.shape
+        assert F * one == self.feats, (F, one, self.feats)
+        t = t.to(device=self.device, dtype=torch.int64).contiguous()
+        sc = None if scale is None else _f32c(scale, self.device, "scale")
+        out = torch.empty_like(x)
+        N.check(N.lib().mst_forward(self.handle, N.ptr(x), N.ptr(t), N.ptr(sc), B, T, int(bool(cfg)), N.ptr(out),
+                                    N.stream_ptr(self.device)))
+        return out
+
+    # ------------------------------------------------------------------------------ sampling
+    def sample_loop(self, schedule, x, t_start, t_end=0, sampler=SAMPLER_DDPM, eta=0.0, cfg=False, scale=None,
+                    mask=None, motion=None, mask_noise=True, clip_denoised=False, noise=None, seed=None,
+                    dump_xstart=False):
+        """Run diffusion indices t_start..t_end in place on `x` ([B,F,1,T] float32 GPU tensor).
+        noise: [nsteps,B,F,1,T] tensor (injected draws) or None -> in-kernel Philox with `seed`.
+        Returns x (and the [nsteps,B,F,1,T] x0-hat dump when requested)."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        B, F, one, T = x.shape
+        nsteps = t_start - t_end + 1
+        a = N.MstLoopArgs()
+        a.batch, a.frames, a.cfg, a.sampler = B, T, int(bool(cfg)), int(sampler)
+        a.mask_noise, a.clip_denoised = int(bool(mask_noise)), int(bool(clip_denoised))
+        a.t_start, a.t_end, a.eta = int(t_start), int(t_end), float(eta)
+        keep = []
+        if noise is not None:
+            noise = _f32c(noise, self.device, "noise")
+            assert noise.numel() == nsteps * x.numel(), (noise.shape, nsteps, x.shape)
+            a.noise_mode, a.noise_dev = NOISE_BUFFER, noise.data_ptr()
+            keep.append(noise)
+        else:
+            a.noise_mode, a.seed = NOISE_PHILOX, int(seed or 0)
+        for name, val in (("scale_dev", scale), ("inpainting_mask_dev", mask), ("inpainted_motion_dev", motion)):
+            if val is not None:
+                val = _f32c(val, self.device, name)
+                keep.append(val)
+                setattr(a, name, val.data_ptr())
+        a.x_dev = x.data_ptr()
+        dump = None
+        if dump_xstart:
+            dump = torch.empty((nsteps,) + tuple(x.shape), dtype=torch.float32, device=self.device)
+            a.xstart_dump_dev = dump.data_ptr()
+        N.check(N.lib().mst_sample_loop(self.handle, schedule.handle, C.byref(a), N.stream_ptr(self.device)))
+        self._loop_keepalive = keep
+        return (x, dump) if dump_xstart else x
+
+    def philox_normal(self, batch, frames, seed, step):
+        out = torch.empty((batch, self.feats, 1, frames), dtype=torch.float32, device=self.device)
+        N.check(N.lib().mst_philox_normal(N.ptr(out), batch, self.feats, frames, int(seed), int(step),
+                                          N.stream_ptr(self.device)))
+        return out
+
+    # ------------------------------------------------------------------------------ profiling / debug
+    def profile(self, on=True, period=16):
+        N.check(N.lib().mst_profile_enable(self.handle, (period if period > 1 else 1) if on else 0))
+
+    def profile_read(self):
+        torch.cuda.current_stream(self.device).synchronize()
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        n = (C.c_int32 * 16)()
+        k = N.lib().mst_profile_read(self.handle, names, ms, n, 16)
+        return {names[i].decode(): (float(ms[i]), int(n[i])) for i in range(k)}
+
+    def debug_stop_after(self, layer=-1, stage=-1):
+        N.check(N.lib().mst_debug_stop_after(self.handle, layer, stage))
+
+    def debug_buffer(self, which, rows, cols):
+        dt = torch.float32 if which in ("hs", "temb", "textproj") else torch.float16
+        out = torch.empty((rows, cols), dtype=dt, device=self.device)
+        N.check(N.lib().mst_debug_copy(self.handle, which.encode(), N.ptr(out), out.numel() * out.element_size(),
+                                       N.stream_ptr(self.device)))
+        return out

@@ -1,0 +1,196 @@
+/* mst_engine.h -- C ABI of the MI355X denoising engine (libmst_engine.so).
+ *
+ * The reference (hlcdyy/diffusion-based-motion-style-transfer) is 100 % Python and has no
+ * FFI/operator interface of its own, so nothing here mirrors an existing
+ * binding; each entry point instead REPLACES a group of reference Python functions, cited per
+ * function below as file:line under the reference root.  The library is called only from the
+ * boundary package (diffusion-based-motion-style-transfer_amd/_native.py via ctypes), never from
+ * user scripts.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; mst_last_error() then returns a
+ *     thread-local, NUL-terminated description.
+ *   - all pointers named *_dev are device (HBM) pointers owned by the caller (PyTorch tensors);
+ *     *_host are host pointers.  The engine owns only its weights copy and workspace.
+ *   - all work is enqueued on the hipStream_t passed as `void* stream` (NULL = default stream)
+ *     and is stream-ordered; one host thread per handle.
+ *   - tensors use the reference's layouts: clips are float32 [B, F, 1, T] (F = njoints*nfeats,
+ *     T contiguous), timesteps are int64 [B].
+ */
+#ifndef MST_ENGINE_H
+#define MST_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mst_engine mst_engine;     /* one MDM-shaped denoiser (weights + workspace)     */
+typedef struct mst_schedule mst_schedule; /* one (possibly respaced) diffusion process' tables */
+
+typedef struct mst_config {
+    int32_t feats;       /* F = njoints * nfeats, e.g. 263 (humanml), 181 (stylexia), 190 (bandai) */
+    int32_t max_frames;  /* largest T the engine must accept (<= 223; tokens S = T + 1)            */
+    int32_t max_rows;    /* largest number of clips through the transformer at once
+                            (= 2 * batch under classifier-free guidance)                           */
+    int32_t latent_dim;  /* must be 512  (utils/parser_util.py default; model_util.py:160-167)     */
+    int32_t num_heads;   /* must be 4    (hard-coded in utils/model_util.py:160-167)               */
+    int32_t ff_size;     /* must be 1024 (same)                                                    */
+    int32_t num_layers;  /* 1..16 (default 8)                                                      */
+    int32_t clip_dim;    /* width of the text embedding, 512                                       */
+    int32_t pe_len;      /* rows of the positional table (5000, mdm_forstyledataset.py:388)        */
+    int32_t device;      /* HIP device ordinal                                                     */
+} mst_config;
+
+/* -------------------------------------------------------------------------------------------
+ * lifetime
+ * ----------------------------------------------------------------------------------------- */
+const char* mst_last_error(void);
+int  mst_version(void);
+int  mst_engine_create(const mst_config* cfg, mst_engine** out);
+void mst_engine_destroy(mst_engine* e);
+
+/* Copy one parameter (float32, device memory) into the engine, converting dense matrices to the
+ * engine's padded f16 operand layout.  `name` is the key of the tensor in an MDM state dict
+ * (model/mdm_forstyledataset.py:183-270), i.e. the reference checkpoint layout:
+ *   seqTransEncoder.layers.{i}.self_attn.in_proj_weight [1536,512] / in_proj_bias
+ *   seqTransEncoder.layers.{i}.self_attn.out_proj.weight [512,512] / .bias
+ *   seqTransEncoder.layers.{i}.linear1.weight [1024,512] / .bias, linear2.weight [512,1024] / .bias
+ *   seqTransEncoder.layers.{i}.norm1.weight/.bias, norm2.weight/.bias
+ *   input_process.poseEmbedding.weight [512,F] / .bias      (InputProcess  :425-449)
+ *   output_process.poseFinal.weight   [F,512] / .bias       (OutputProcess :452-478)
+ *   embed_timestep.time_embed.0.weight/.bias, .2.weight/.bias (TimestepEmbedder :408-422)
+ *   embed_text.weight [512,clip_dim] / .bias                (:258)
+ *   sequence_pos_encoder.pe [pe_len,512]                    (PositionalEncoding :387-404)
+ * For StyleDiffusion the caller passes its own `seqTransEncoder.*` tensors and the frozen prior's
+ * (`motion_enc.mdm_model.*`) projections, which is exactly what StyleDiffusion.forward (:602-625)
+ * reads.  Replaces: nn.Module.load_state_dict / .to(device) for this path. */
+int mst_load_weight(mst_engine* e, const char* name, const float* src_dev,
+                    const int64_t* shape, int32_t ndim, void* stream);
+/* 0 when every tensor of the list above has been loaded. */
+int mst_weights_complete(const mst_engine* e);
+
+/* -------------------------------------------------------------------------------------------
+ * schedule: replaces GaussianDiffusion.__init__'s tables as consumed through
+ * _extract_into_tensor (diffusion/gaussian_diffusion.py:183-219, :1605-1618) and
+ * _WrappedModel's timestep_map (diffusion/respace.py:129-134).
+ * `tables_host` is float32 [MST_NTAB][num_steps] in the order of mst_table below: the float64
+ * numpy tables cast to float32, exactly what `.float()` at gaussian_diffusion.py:1615 yields.
+ * ----------------------------------------------------------------------------------------- */
+enum mst_table {
+    MST_TAB_SQRT_AC = 0,        /* sqrt_alphas_cumprod                */
+    MST_TAB_SQRT_1M_AC = 1,     /* sqrt_one_minus_alphas_cumprod      */
+    MST_TAB_COEF1 = 2,          /* posterior_mean_coef1               */
+    MST_TAB_COEF2 = 3,          /* posterior_mean_coef2               */
+    MST_TAB_LOGVAR = 4,         /* log-variance of the configured var type
+                                   (FIXED_SMALL: posterior_log_variance_clipped) */
+    MST_TAB_SQRT_RECIP_AC = 5,  /* sqrt_recip_alphas_cumprod          */
+    MST_TAB_SQRT_RECIPM1_AC = 6,/* sqrt_recipm1_alphas_cumprod        */
+    MST_TAB_AC = 7,             /* alphas_cumprod                     */
+    MST_TAB_AC_PREV = 8,        /* alphas_cumprod_prev                */
+    MST_NTAB = 9
+};
+int  mst_schedule_create(int32_t num_steps, const float* tables_host,
+                         const int32_t* timestep_map_host, int32_t device, mst_schedule** out);
+void mst_schedule_destroy(mst_schedule* s);
+
+/* -------------------------------------------------------------------------------------------
+ * conditioning: replaces embed_text(mask_cond(encode_text(...))) of StyleDiffusion.forward
+ * (:611-615, :592-600) / MDM.forward (:324-327).  CLIP itself stays outside; `text_emb_dev` is its
+ * float32 [batch, clip_dim] output.  keep_dev (float32 [batch], may be NULL = all ones) is the
+ * cond mask: 0 drops the text embedding of that clip (y['uncond'] / the Bernoulli mask).
+ * With cfg != 0 the engine prepares a doubled batch: rows [0,batch) conditional, rows
+ * [batch, 2*batch) unconditional (model/cfg_sampler.py:36-43).  The projection is constant over a
+ * sampling loop, so it is computed here once instead of once per step.
+ * ----------------------------------------------------------------------------------------- */
+int mst_set_text(mst_engine* e, const float* text_emb_dev, const float* keep_dev,
+                 int32_t batch, int32_t cfg, void* stream);
+
+/* -------------------------------------------------------------------------------------------
+ * one model evaluation: replaces StyleDiffusion.forward / MDM.forward (:602-625, :315-364) and,
+ * with cfg != 0, ClassifierFreeSampleModel.forward (model/cfg_sampler.py:36-43).
+ *   x_dev      float32 [batch, F, 1, frames]
+ *   t_dev      int64 [batch] ORIGINAL-process timesteps (after timestep_map)
+ *   scale_dev  float32 [batch] guidance scale (cfg only)
+ *   out_dev    float32 [batch, F, 1, frames]
+ * mst_set_text must have been called for this batch/cfg.
+ * ----------------------------------------------------------------------------------------- */
+int mst_forward(mst_engine* e, const float* x_dev, const int64_t* t_dev, const float* scale_dev,
+                int32_t batch, int32_t frames, int32_t cfg, float* out_dev, void* stream);
+
+/* -------------------------------------------------------------------------------------------
+ * sampling loop / single step: replaces p_sample_loop(_progressive), ddim_sample_loop
+ * (_progressive) (diffusion/gaussian_diffusion.py:644-794, :948-1082) with p_mean_variance
+ * (:311-424), p_sample (:532-585 / inpainting_gaussian_diffusion.py:25-64) and ddim_sample
+ * (inpainting_gaussian_diffusion.py:125-177) fused into the output-projection kernel.
+ * Runs diffusion indices t_start, t_start-1, ..., t_end (t_start == t_end: one step).
+ * ----------------------------------------------------------------------------------------- */
+enum { MST_SAMPLER_DDPM = 0, MST_SAMPLER_DDIM = 1 };
+enum { MST_NOISE_BUFFER = 0, MST_NOISE_PHILOX = 1 };
+
+typedef struct mst_loop_args {
+    int32_t batch;                  /* clips B                                                   */
+    int32_t frames;                 /* T                                                         */
+    int32_t cfg;                    /* classifier-free guidance: cond/uncond as one 2B batch     */
+    int32_t sampler;                /* MST_SAMPLER_*                                             */
+    int32_t mask_noise;             /* 1: InpaintingGaussianDiffusion (noise *= 1 - mask)        */
+    int32_t clip_denoised;          /* clamp x0-hat to [-1, 1] (callers pass 0)                  */
+    int32_t noise_mode;             /* MST_NOISE_*                                               */
+    int32_t t_start, t_end;         /* inclusive, t_start >= t_end >= 0                          */
+    float   eta;                    /* DDIM eta                                                  */
+    uint64_t seed;                  /* Philox key (MST_NOISE_PHILOX)                             */
+    const float* scale_dev;         /* [B] guidance scale (cfg)                                  */
+    const float* inpainting_mask_dev;   /* [B,F,1,T] float32 0/1, or NULL                        */
+    const float* inpainted_motion_dev;  /* [B,F,1,T], or NULL (blend needs both)                 */
+    const float* noise_dev;         /* MST_NOISE_BUFFER: [nsteps][B,F,1,T], step j at j*B*F*T    */
+    float* x_dev;                   /* [B,F,1,T]: x_{t_start} on entry, final sample on exit     */
+    float* xstart_dump_dev;         /* optional [nsteps][B,F,1,T]: x0-hat of every step          */
+} mst_loop_args;
+
+int mst_sample_loop(mst_engine* e, const mst_schedule* s, const mst_loop_args* a, void* stream);
+
+/* -------------------------------------------------------------------------------------------
+ * stand-alone elementwise kernels for callers that bring their own model callable
+ * (any nn.Module passed to p_sample / ddim_sample / q_sample):
+ *   mst_q_sample        diffusion/gaussian_diffusion.py:267-285,
+ *                       diffusion/inpainting_gaussian_diffusion.py:6-23
+ *   mst_step_epilogue   gaussian_diffusion.py:341-349 (blend), :387-412 (mean/variance),
+ *                       :569-585 / inpainting_gaussian_diffusion.py:51-63 (p_sample),
+ *                       inpainting_gaussian_diffusion.py:157-177 (ddim_sample)
+ * t_dev is int64 [batch] of indices into the schedule.  sample_out_dev / xstart_out_dev may be NULL.
+ * ----------------------------------------------------------------------------------------- */
+int mst_q_sample(const mst_schedule* s, const float* x_start_dev, const float* noise_dev,
+                 const float* mask_dev, const int64_t* t_dev, int32_t batch, int64_t per_clip,
+                 float* out_dev, void* stream);
+
+int mst_step_epilogue(const mst_schedule* s, const float* model_out_dev, const float* x_dev,
+                      const float* noise_dev, const float* mask_dev, const float* motion_dev,
+                      const int64_t* t_dev, int32_t batch, int64_t per_clip, int32_t sampler,
+                      float eta, int32_t mask_noise, int32_t clip_denoised,
+                      float* sample_out_dev, float* xstart_out_dev, void* stream);
+
+/* Standard-normal fill with the engine's Philox stream (the generator MST_NOISE_PHILOX uses
+ * inside the fused step), so a caller can reproduce in-loop noise: element (clip, f, t) of step
+ * `step`.  Replaces th.randn / th.randn_like draws (gaussian_diffusion.py:754, :569). */
+int mst_philox_normal(float* out_dev, int32_t batch, int32_t feats, int32_t frames, uint64_t seed,
+                      uint32_t step, void* stream);
+
+/* Per-kernel device timing of the most recent mst_sample_loop / mst_forward when profiling is
+ * enabled: HIP events recorded around every launch on the caller's stream.  names/ms are arrays
+ * of `cap` entries filled with per-kernel-family totals; returns the number of families. */
+int mst_profile_enable(mst_engine* e, int32_t on);
+int mst_profile_read(mst_engine* e, const char** names, float* total_ms, int32_t* launches,
+                     int32_t cap);
+
+/* Debug / test hooks (no reference counterpart): stop the encoder stack after (layer, stage) --
+ * stage 0 = token stream assembled, 1 = QKV, 2 = attention, 3 = out-proj + LayerNorm1, 4 = FFN1,
+ * 5 = FFN2 + LayerNorm2; layer = stage = -1 runs everything -- and copy a workspace buffer
+ * ("hs" f32 stream, "hx"/"qkv"/"att"/"hid" f16, "temb"/"textproj" f32) into caller memory. */
+int mst_debug_stop_after(mst_engine* e, int32_t layer, int32_t stage);
+int mst_debug_copy(mst_engine* e, const char* which, void* dst_dev, uint64_t nbytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MST_ENGINE_H */

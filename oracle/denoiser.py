@@ -33,8 +33,9 @@ def _linear(x, w, b, dt=None):
     return y + _t(b)
 
 
-def encoder_layer(x, w, prefix, nhead, key_padding_mask=None, dt=None):
-    """One post-norm encoder layer on x [B, S, d]."""
+def encoder_layer(x, w, prefix, nhead, key_padding_mask=None, dt=None, trace=None):
+    """One post-norm encoder layer on x [B, S, d].  `trace` (dict) receives the intermediates
+    qkv / attn / x1 / hid / x2 for stage-by-stage kernel tests."""
     B, S, d = x.shape
     hd = d // nhead
     qkv = _linear(x, w[prefix + "self_attn.in_proj_weight"], w[prefix + "self_attn.in_proj_bias"], dt)
@@ -48,13 +49,15 @@ def encoder_layer(x, w, prefix, nhead, key_padding_mask=None, dt=None):
     if key_padding_mask is not None:  # True = padded key
         scores = scores.masked_fill(key_padding_mask[:, None, None, :], float("-inf"))
     p = torch.softmax(scores, dim=-1)
-    a = (_rnd(p, dt) @ _rnd(v, dt)).permute(0, 2, 1, 3).reshape(B, S, d)
-    a = _linear(a, w[prefix + "self_attn.out_proj.weight"], w[prefix + "self_attn.out_proj.bias"], dt)
+    attn_heads = (_rnd(p, dt) @ _rnd(v, dt)).permute(0, 2, 1, 3).reshape(B, S, d)
+    a = _linear(attn_heads, w[prefix + "self_attn.out_proj.weight"], w[prefix + "self_attn.out_proj.bias"], dt)
     x = F.layer_norm(x + a, (d,), _t(w[prefix + "norm1.weight"]), _t(w[prefix + "norm1.bias"]), 1e-5)
-    h = F.gelu(_linear(x, w[prefix + "linear1.weight"], w[prefix + "linear1.bias"], dt))
-    h = _linear(h, w[prefix + "linear2.weight"], w[prefix + "linear2.bias"], dt)
-    x = F.layer_norm(x + h, (d,), _t(w[prefix + "norm2.weight"]), _t(w[prefix + "norm2.bias"]), 1e-5)
-    return x
+    hid = F.gelu(_linear(x, w[prefix + "linear1.weight"], w[prefix + "linear1.bias"], dt))
+    h = _linear(hid, w[prefix + "linear2.weight"], w[prefix + "linear2.bias"], dt)
+    x2 = F.layer_norm(x + h, (d,), _t(w[prefix + "norm2.weight"]), _t(w[prefix + "norm2.bias"]), 1e-5)
+    if trace is not None:
+        trace.update(qkv=qkv, attn=attn_heads, x1=x, hid=hid, x2=x2)
+    return x2
 
 
 def timestep_embedding(w, pe, t, prior=PRIOR):
@@ -64,6 +67,24 @@ def timestep_embedding(w, pe, t, prior=PRIOR):
     e = _linear(e, w[prior + "embed_timestep.time_embed.0.weight"], w[prior + "embed_timestep.time_embed.0.bias"])
     e = F.silu(e)
     return _linear(e, w[prior + "embed_timestep.time_embed.2.weight"], w[prior + "embed_timestep.time_embed.2.bias"])
+
+
+def token_stream(w, pe, x, t, text_emb, uncond=False, cond_keep=None, prior=PRIOR, dt=None):
+    """The [B, T+1, d] encoder input (conditioning token + embedded frames + positions)."""
+    x = _t(x).float()
+    B, Fe, one, T = x.shape
+    pe = _t(pe)
+    emb = timestep_embedding(w, pe, t, prior)
+    te = _t(text_emb).float()
+    if uncond:
+        te = torch.zeros_like(te)
+    elif cond_keep is not None:
+        te = te * _t(cond_keep).float().view(B, 1)
+    emb = emb + _linear(te, w[prior + "embed_text.weight"], w[prior + "embed_text.bias"])
+    frames = x.permute(0, 3, 1, 2).reshape(B, T, Fe * one)
+    h = _linear(frames, w[prior + "input_process.poseEmbedding.weight"],
+                w[prior + "input_process.poseEmbedding.bias"], dt)
+    return torch.cat([emb[:, None, :], h], dim=1) + pe[: T + 1][None]
 
 
 def forward(w, pe, x, t, text_emb, uncond=False, cond_keep=None, nhead=4, num_layers=8,
@@ -81,20 +102,7 @@ def forward(w, pe, x, t, text_emb, uncond=False, cond_keep=None, nhead=4, num_la
     """
     x = _t(x).float()
     B, Fe, one, T = x.shape
-    d = _t(w[prior + "embed_timestep.time_embed.0.weight"]).shape[0]
-    pe = _t(pe)
-    emb = timestep_embedding(w, pe, t, prior)                      # [B, d]
-    te = _t(text_emb).float()
-    if uncond:
-        te = torch.zeros_like(te)
-    elif cond_keep is not None:
-        te = te * _t(cond_keep).float().view(B, 1)
-    emb = emb + _linear(te, w[prior + "embed_text.weight"], w[prior + "embed_text.bias"])
-    # InputProcess: [B,F,1,T] -> frames as tokens
-    frames = x.permute(0, 3, 1, 2).reshape(B, T, Fe * one)
-    h = _linear(frames, w[prior + "input_process.poseEmbedding.weight"],
-                w[prior + "input_process.poseEmbedding.bias"], dt)
-    seq = torch.cat([emb[:, None, :], h], dim=1) + pe[: T + 1][None]   # token 0 = conditioning
+    seq = token_stream(w, pe, x, t, text_emb, uncond, cond_keep, prior, dt)   # token 0 = conditioning
     for i in range(num_layers):
         seq = encoder_layer(seq, w, f"{layer_prefix}{i}.", nhead, None, dt)
     out = _linear(seq[:, 1:], w[prior + "output_process.poseFinal.weight"],
