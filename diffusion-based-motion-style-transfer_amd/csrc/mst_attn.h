@@ -130,12 +130,10 @@ __global__ __launch_bounds__(512) void k_attention(const f16* __restrict__ qkv, 
                     (s16x4 __attribute__((address_space(3)))*)(vs + v_off(key, d)));
                 s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                     (s16x4 __attribute__((address_space(3)))*)(vs + v_off(key + 8, d)));
-                f16x8 vf;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    vf[j] = __builtin_bit_cast(f16, lo[j]);
-                    vf[4 + j] = __builtin_bit_cast(f16, hi[j]);
-                }
+                // whole-vector bit casts only: __builtin_bit_cast on an ext-vector ELEMENT (lo[j])
+                // makes clang (ROCm 7.2) read element 0 for every j.
+                const f16x4 lo_h = __builtin_bit_cast(f16x4, lo), hi_h = __builtin_bit_cast(f16x4, hi);
+                f16x8 vf = __builtin_shufflevector(lo_h, hi_h, 0, 1, 2, 3, 4, 5, 6, 7);
                 o = mfma_f16(vf, pf[kt][s2], o);
             }
         if (q_idx < S) {

@@ -66,8 +66,8 @@ class Schedule:
 
     def __del__(self):
         h = getattr(self, "handle", None)
-        if h:
-            N.lib().mst_schedule_destroy(h)
+        if h and N is not None and N._lib is not None:      # None during interpreter shutdown
+            N._lib.mst_schedule_destroy(h)
             self.handle = None
 
     # stand-alone elementwise kernels (any model callable) -------------------------------------
@@ -116,8 +116,8 @@ class DenoiserEngine:
 
     def __del__(self):
         h = getattr(self, "handle", None)
-        if h:
-            N.lib().mst_engine_destroy(h)
+        if h and N is not None and N._lib is not None:
+            N._lib.mst_engine_destroy(h)
             self.handle = None
 
     # ------------------------------------------------------------------------------ weights
