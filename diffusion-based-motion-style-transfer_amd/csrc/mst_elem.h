@@ -20,6 +20,25 @@ __global__ void k_copy_pad_f32(const float* __restrict__ src, int n, float* __re
     if (i < npad) dst[i] = i < n ? src[i] : 0.f;
 }
 
+// x [clips][F][T] float32 -> xt [clips*T][Kpad] f16 (frames as rows, features contiguous, zero padded):
+// the activation operand of the pose-embedding GEMM in the layout the LDS-DMA ring loads.
+__global__ __launch_bounds__(256) void k_frames_f16(const float* __restrict__ x, int F, int T, int Kpad, f16* __restrict__ xt) {
+    __shared__ float tile[32][33];
+    const int clip = blockIdx.z, f0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int j = ty; j < 32; j += 8) {
+        int f = f0 + j, t = t0 + tx;
+        tile[j][tx] = (f < F && t < T) ? x[((size_t)clip * F + f) * T + t] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = ty; j < 32; j += 8) {
+        int t = t0 + j, f = f0 + tx;
+        if (t < T && f < Kpad) xt[((size_t)clip * T + t) * Kpad + f] = (f16)tile[tx][j];
+    }
+}
+
 // K1/K2: y[row][n] = act(sum_k in[row][k] * rowscale[row] * W[n][k] + b[n]) in float32.
 // One wave per output element group: lanes stride K (coalesced W rows), shuffle reduce.
 // gather != null: input row = table[gather[row]] (timestep embedding: pe[t]).

@@ -12,8 +12,13 @@
 #include "mst_common.h"
 #include "mst_elem.h"
 #include "mst_gemm.h"
+#include "mst_gemm_dma.h"
 
 using namespace mst;
+
+#ifndef WIDE_NS
+#define WIDE_NS 3   // ring slots of the wide (QKV / FFN1) tiles: 3 x 24 KB lets two blocks share a CU
+#endif
 
 // ------------------------------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
@@ -67,7 +72,7 @@ struct mst_engine {
     float* pe = nullptr;
     // workspace
     float* hs = nullptr;
-    f16 *hx = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr;
+    f16 *hx = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr, *xt = nullptr;
     float *temb_hid = nullptr, *temb = nullptr, *textproj = nullptr;
     int temb_cap = 0;
     std::vector<std::string> loaded;
@@ -120,7 +125,7 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
         return fail("mst_engine_create: kernels are built for latent_dim 512 / 4 heads / ff 1024 (got %d/%d/%d)",
                     c->latent_dim, c->num_heads, c->ff_size);
     if (c->num_layers < 1 || c->num_layers > 16) return fail("mst_engine_create: num_layers must be 1..16");
-    if (c->feats < 1 || c->feats > 384) return fail("mst_engine_create: feats must be 1..384 (got %d)", c->feats);
+    if (c->feats < 1 || c->feats > 512) return fail("mst_engine_create: feats must be 1..512 (got %d)", c->feats);
     if (c->max_frames < 1 || c->max_frames > 223) return fail("mst_engine_create: max_frames must be 1..223 (got %d)", c->max_frames);
     if (c->max_rows < 1) return fail("mst_engine_create: max_rows must be >= 1");
     if (c->clip_dim < 1 || c->pe_len < c->max_frames + 1) return fail("mst_engine_create: bad clip_dim / pe_len");
@@ -131,8 +136,8 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     size_t M = (size_t)c->max_rows * e->S_max;
     e->M_pad = (int)(((M + 127) / 128) * 128);
     e->kin_pad = ((c->feats + 63) / 64) * 64;
-    e->nt_out = (c->feats + 127) / 128;
-    e->fout_pad = e->nt_out * 128;
+    e->nt_out = (c->feats + 255) / 256;              // output-projection tile = 256 * nt_out features
+    e->fout_pad = e->nt_out * 256;
     for (int l = 0; l < c->num_layers; l++) {
         LayerW& w = e->L[l];
         CHECK(dmalloc(&w.w_in, (size_t)3 * MST_D * MST_D));
@@ -164,6 +169,7 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     CHECK(dmalloc(&e->qkv, (size_t)e->M_pad * 3 * MST_D));
     CHECK(dmalloc(&e->att, (size_t)e->M_pad * MST_D));
     CHECK(dmalloc(&e->hid, (size_t)e->M_pad * MST_FF));
+    CHECK(dmalloc(&e->xt, ((size_t)c->max_rows * c->max_frames + 128) * e->kin_pad));
     e->temb_cap = c->max_rows > 1024 ? c->max_rows : 1024;
     CHECK(dmalloc(&e->temb_hid, (size_t)e->temb_cap * MST_D));
     CHECK(dmalloc(&e->temb, (size_t)e->temb_cap * MST_D));
@@ -180,7 +186,7 @@ extern "C" void mst_engine_destroy(mst_engine* e) {
         for (void* q : p) (void)hipFree(q);
     }
     void* p[] = {e->w_pose_in, e->b_pose_in, e->w_pose_out, e->b_pose_out, e->w_t0, e->b_t0, e->w_t2, e->b_t2,
-                 e->w_text, e->b_text, e->pe, e->hs, e->hx, e->qkv, e->att, e->hid, e->temb_hid, e->temb, e->textproj};
+                 e->w_text, e->b_text, e->pe, e->hs, e->hx, e->qkv, e->att, e->hid, e->xt, e->temb_hid, e->temb, e->textproj};
     for (void* q : p) (void)hipFree(q);
     for (auto& pp : e->prof_pts) {
         (void)hipEventDestroy(pp.a);
@@ -344,6 +350,23 @@ static int launch_gemm(dim3 grid, const XL& xl, const f16* W, int ldw, int K, co
     return 0;
 }
 
+template <int BT, int BF, int MT, int NT, int NS, int NX, class SRC, class EPI>
+static int launch_gemm_dma(dim3 grid, const SRC& xs, const f16* W, int ldw, int K, const EPI& epi, hipStream_t st) {
+    using TL = DTile<BT, BF, MT, NT, NS, NX>;
+    static_assert(EPI::template smem_bytes<BT, BF>() <= TL::SMEM, "epilogue tile must fit the ring");
+    static_assert(TL::SMEM <= 163840, "ring exceeds the 160 KiB LDS");
+    auto kern = k_gemm_dma<BT, BF, MT, NT, NS, NX, SRC, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TL::SMEM));
+        attr_set = true;
+    }
+    if (K < 32 * (NS - 1) || (K & 31)) return fail("gemm: K=%d unsupported by the %d-slot ring", K, NS);
+    hipLaunchKernelGGL(kern, grid, dim3(512), TL::SMEM, st, xs, W, ldw, K, epi);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
 template <int NKT>
 static int launch_attn_n(const f16* qkv, f16* out, int S, int rows, hipStream_t st) {
     auto kern = k_attention<NKT>;
@@ -412,14 +435,15 @@ static int run_trunk(mst_engine* e, const float* x, int clips_x, int rows, int T
         HIPCHECK(hipGetLastError());
     }
     {
-        // the doubled CFG batch feeds the same x to both halves: frames of clip r come from x[r % clips_x]
+        // frames -> f16 rows (transpose + convert), then the pose-embedding GEMM on the DMA ring.  The doubled
+        // CFG batch feeds the same x to both halves: embed once, store twice (dup).
         ProfScope ps(e, FAM_EMBED_IN, st);
-        for (int half = 0; half * clips_x < rows; half++) {
-            XInput xl{x, e->cfg.feats, T, clips_x * T};
-            size_t off = (size_t)half * clips_x * S * MST_D;
-            EpiEmbedIn epi{e->b_pose_in, e->pe, e->hs + off, e->hx + off, T, S, clips_x * T};
-            CHECK((launch_gemm<64, 4, 1>(dim3((clips_x * T + 63) / 64, 1), xl, e->w_pose_in, e->kin_pad, e->kin_pad, epi, st)));
-        }
+        const int F = e->cfg.feats, tot = clips_x * T;
+        hipLaunchKernelGGL(k_frames_f16, dim3((T + 31) / 32, e->kin_pad / 32, clips_x), dim3(256), 0, st, x, F, T, e->kin_pad, e->xt);
+        HIPCHECK(hipGetLastError());
+        DEpiEmbedIn epi{e->b_pose_in, e->pe, e->hs, e->hx, T, S, tot, rows > clips_x ? (size_t)clips_x * S * MST_D : 0};
+        CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1>(dim3((tot + 63) / 64, 1), RowsDirect{e->xt, e->kin_pad}, e->w_pose_in, e->kin_pad,
+                                                   e->kin_pad, epi, st)));
     }
     if (e->dbg_stage == 0) return 0;
 #define DBG_STOP(stage) if (e->dbg_layer == l && e->dbg_stage == stage) return 0;
@@ -427,9 +451,8 @@ static int run_trunk(mst_engine* e, const float* x, int clips_x, int rows, int T
         const LayerW& w = e->L[l];
         {
             ProfScope ps(e, FAM_QKV, st);
-            XRows xl{e->hx, MST_D};
-            EpiBiasF16 epi{w.b_in, e->qkv, 3 * MST_D, M, 0};
-            CHECK((launch_gemm<128, 4, 1>(dim3((M + 127) / 128, 3 * MST_D / 256), xl, w.w_in, MST_D, MST_D, epi, st)));
+            DEpiBiasF16 epi{w.b_in, e->qkv, 3 * MST_D, M, 0};
+            CHECK((launch_gemm_dma<128, 256, 2, 2, WIDE_NS, 1>(dim3((M + 127) / 128, 3 * MST_D / 256), RowsDirect{e->hx, MST_D}, w.w_in, MST_D, MST_D, epi, st)));
         }
         DBG_STOP(1)
         {
@@ -439,23 +462,20 @@ static int run_trunk(mst_engine* e, const float* x, int clips_x, int rows, int T
         DBG_STOP(2)
         {
             ProfScope ps(e, FAM_OUTPROJ_LN, st);
-            XRows xl{e->att, MST_D};
-            EpiResidLN epi{w.b_out, e->hs, w.g1, w.be1, e->hs, e->hx, M};
-            CHECK((launch_gemm<64, 4, 1>(dim3((M + 63) / 64, 1), xl, w.w_out, MST_D, MST_D, epi, st)));
+            DEpiResidLN epi{w.b_out, e->hs, w.g1, w.be1, e->hs, e->hx, M};
+            CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1>(dim3((M + 63) / 64, 1), RowsDirect{e->att, MST_D}, w.w_out, MST_D, MST_D, epi, st)));
         }
         DBG_STOP(3)
         {
             ProfScope ps(e, FAM_FFN1, st);
-            XRows xl{e->hx, MST_D};
-            EpiBiasF16 epi{w.b1, e->hid, MST_FF, M, 1};
-            CHECK((launch_gemm<128, 4, 1>(dim3((M + 127) / 128, MST_FF / 256), xl, w.w1, MST_D, MST_D, epi, st)));
+            DEpiBiasF16 epi{w.b1, e->hid, MST_FF, M, 1};
+            CHECK((launch_gemm_dma<128, 256, 2, 2, WIDE_NS, 1>(dim3((M + 127) / 128, MST_FF / 256), RowsDirect{e->hx, MST_D}, w.w1, MST_D, MST_D, epi, st)));
         }
         DBG_STOP(4)
         {
             ProfScope ps(e, FAM_FFN2_LN, st);
-            XRows xl{e->hid, MST_FF};
-            EpiResidLN epi{w.b2, e->hs, w.g2, w.be2, e->hs, e->hx, M};
-            CHECK((launch_gemm<64, 4, 1>(dim3((M + 63) / 64, 1), xl, w.w2, MST_FF, MST_FF, epi, st)));
+            DEpiResidLN epi{w.b2, e->hs, w.g2, w.be2, e->hs, e->hx, M};
+            CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1>(dim3((M + 63) / 64, 1), RowsDirect{e->hid, MST_FF}, w.w2, MST_FF, MST_FF, epi, st)));
         }
         DBG_STOP(5)
     }
@@ -463,16 +483,17 @@ static int run_trunk(mst_engine* e, const float* x, int clips_x, int rows, int T
     return 0;
 }
 
-template <int MODE, int NT, int NX>
+// output projection tiles: 64 frames x (256 * NTO) features, 8 waves as 1 x 8 with 2 x NTO MFMA tiles each
+template <int MODE, int NTO, int NX>
 static int launch_out(mst_engine* e, int batch, int T, float* out, const StepArgs& sa, hipStream_t st) {
     const int S = T + 1;
-    XFrames xl{e->hx, MST_D, T, S, batch * T, batch * S, 64};
-    EpiEmbedOut<MODE> epi{e->b_pose_out, e->cfg.feats, T, batch * T, out, sa};
-    return launch_gemm<64, NT, NX>(dim3((batch * T + 63) / 64, 1), xl, e->w_pose_out, MST_D, MST_D, epi, st);
+    RowsFrames xs{e->hx, MST_D, T, S, batch * T, 64, (size_t)batch * S};
+    DEpiEmbedOut<MODE> epi{e->b_pose_out, e->cfg.feats, T, batch * T, out, sa};
+    return launch_gemm_dma<64, 256 * NTO, 2, NTO, 4, NX>(dim3((batch * T + 63) / 64, 1), xs, e->w_pose_out, MST_D, MST_D, epi, st);
 }
-template <int MODE, int NT>
+template <int MODE, int NTO>
 static int launch_out_nx(mst_engine* e, int cfg, int batch, int T, float* out, const StepArgs& sa, hipStream_t st) {
-    return cfg ? launch_out<MODE, NT, 2>(e, batch, T, out, sa, st) : launch_out<MODE, NT, 1>(e, batch, T, out, sa, st);
+    return cfg ? launch_out<MODE, NTO, 2>(e, batch, T, out, sa, st) : launch_out<MODE, NTO, 1>(e, batch, T, out, sa, st);
 }
 template <int MODE>
 static int launch_out_nt(mst_engine* e, int cfg, int batch, int T, float* out, const StepArgs& sa, hipStream_t st) {
@@ -480,7 +501,6 @@ static int launch_out_nt(mst_engine* e, int cfg, int batch, int T, float* out, c
     switch (e->nt_out) {
         case 1: return launch_out_nx<MODE, 1>(e, cfg, batch, T, out, sa, st);
         case 2: return launch_out_nx<MODE, 2>(e, cfg, batch, T, out, sa, st);
-        case 3: return launch_out_nx<MODE, 3>(e, cfg, batch, T, out, sa, st);
     }
     return fail("output projection: feats %d unsupported", e->cfg.feats);
 }

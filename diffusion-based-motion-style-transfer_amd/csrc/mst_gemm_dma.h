@@ -1,0 +1,429 @@
+// Hot GEMMs (QKV, out-proj+LN, FFN1+GELU, FFN2+LN) on an LDS-DMA ring.
+//
+// Why a second mainloop: the register-staged loop of mst_gemm.h measured 67-79 % SQ_WAIT_ANY and
+// ~9 % MFMA busy on MI355X (profiles/r01_v0_*): with one 8-wave block per CU nothing hides the
+// L2 latency of the next K-slab.  Here K is consumed in 32-deep slabs through a 4-slot LDS ring
+// filled by `global_load_lds_dwordx4` (no VGPR staging, no ds_write); three slabs are always in
+// flight behind a COUNTED `s_waitcnt vmcnt(N)` and a raw `s_barrier` (a `__syncthreads()` would
+// drain the DMA queue: cdna guide section 5 "Pipelining across barriers").
+//
+// Slab image: [BT token rows | BF weight rows] x 64 B; 16-B chunk c of row r is stored at
+// chunk c ^ ((r >> 2) & 3) (four 64-B rows share one 256-B bank row; the XOR makes every
+// ds_read_b128 fragment read conflict-free).  A DMA wave-instruction writes 1 KiB = 16 rows
+// lane-linearly, so the swizzle is applied on the per-lane SOURCE address (guide rule 21).
+//
+// Wave tile = MT x NT MFMA tiles (2 x 2 here): 4 fragment reads feed 4 MFMAs per k-step.
+// Orientation as in mst_gemm.h: A operand = weights, B operand = activations, so a lane owns one
+// token and registers run over features.
+#pragma once
+#include "mst_common.h"
+#include "mst_gemm.h"   // StepArgs
+
+namespace mst {
+
+template <int BT, int BF, int MT, int NT, int NS = 4, int NX = 1>
+struct DTile {
+    static constexpr int WT = BT / (32 * MT);       // wave rows (token direction)
+    static constexpr int WN = 8 / WT;               // wave columns (feature direction)
+    static_assert(WT * WN == 8 && WN * NT * 32 == BF, "8 waves must tile BT x BF");
+    static constexpr int XROWS = NX * BT;           // NX = 2: a second token group (CFG: the uncond half)
+    static constexpr int ROWS = XROWS + BF;
+    static constexpr int STAGE = ROWS * 64;         // bytes per 32-deep slab
+    static constexpr int NSTAGE = NS;               // ring slots: NS - 1 slabs in flight
+    static constexpr int SMEM = NSTAGE * STAGE;
+    static constexpr int INSTR = ROWS / 16;         // 1-KiB DMA pieces per slab
+    static constexpr int PER = (INSTR + 7) / 8;     // pieces per wave per slab (uniform; extras duplicate)
+};
+
+__device__ __forceinline__ int ring_off(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
+
+// one 1-KiB LDS-DMA piece: every lane supplies its own global source; LDS destination is the
+// wave-uniform `lds_dst` + lane * 16 (M0 carries the base; saved/restored inside the statement
+// because M0 is compiler-reserved, cdna guide section 5.7).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <class TL>
+__device__ __forceinline__ void dma_issue(const char* const (&src)[TL::PER], const unsigned (&dst)[TL::PER],
+                                          unsigned smem_base, int kt) {
+    const unsigned base = smem_base + (kt % TL::NSTAGE) * TL::STAGE;
+#pragma unroll
+    for (int j = 0; j < TL::PER; j++)
+        glds16(src[j] + (size_t)kt * 64, __builtin_amdgcn_readfirstlane(base + dst[j]));
+}
+
+// Row sources: which global row feeds tile row r of the activation operand.
+struct RowsDirect {                       // tile row r = matrix row tok0 + r
+    const f16* X; int ld;
+    __device__ __forceinline__ const f16* row(int tok0, int r) const { return X + (size_t)(tok0 + r) * ld; }
+};
+struct RowsFrames {                       // tile row r = frame (tok0 + r) of the token stream, conditioning token skipped;
+    const f16* X; int ld; int T, S, total;   // rows >= BT (second group) come from the uncond half (+cfg_rows)
+    int BT; size_t cfg_rows;
+    __device__ __forceinline__ const f16* row(int tok0, int r) const {
+        int half = r >= BT ? 1 : 0;
+        int tok = tok0 + r - half * BT;
+        if (tok >= total) tok = total - 1;
+        int clip = tok / T, t = tok - clip * T;
+        return X + ((size_t)clip * S + 1 + t + half * cfg_rows) * ld;
+    }
+};
+
+template <class TL, int BT, int BF, int MT, int NT, int NX, class SRC>
+__device__ __forceinline__ void gemm_mainloop_dma(char* smem, const SRC& xs, const f16* __restrict__ W, int ldw,
+                                                  int tok0, int f0, int K, f32x16 (&acc)[NX][MT][NT]) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wt = wave / TL::WN, wn = wave % TL::WN;
+    const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    // per-lane source pointers of this wave's PER pieces (advance 64 B per slab)
+    const char* src[TL::PER];
+    unsigned dst[TL::PER];
+#pragma unroll
+    for (int j = 0; j < TL::PER; j++) {
+        int i = wave + 8 * j;
+        if (i >= TL::INSTR) i -= 8 * (TL::PER - 1);          // duplicate piece: same bytes, same place
+        int row = i * 16 + (lane >> 2);
+        int c = (lane & 3) ^ ((row >> 2) & 3);
+        const f16* g = row < TL::XROWS ? xs.row(tok0, row) : W + (size_t)(f0 + row - TL::XROWS) * ldw;
+        src[j] = reinterpret_cast<const char*>(g + c * 8);
+        dst[j] = i * 1024;
+    }
+    const int KT = K >> 5;
+    constexpr int AHEAD = TL::NSTAGE - 1;                    // slabs in flight
+#pragma unroll
+    for (int s = 0; s < AHEAD; s++)
+        if (s < KT) dma_issue<TL>(src, dst, smem_base, s);
+
+    for (int kt = 0; kt < KT; kt++) {
+        const int rem = KT - 1 - kt;                        // slabs already issued beyond kt: min(rem, AHEAD - 1)
+        if (rem >= AHEAD - 1) wait_vmcnt<(AHEAD - 1) * TL::PER>();
+        else if (AHEAD >= 3 && rem == 1) wait_vmcnt<TL::PER>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                       // slab kt landed for every wave; slot of slab kt-1 is free
+        if (kt + AHEAD < KT) dma_issue<TL>(src, dst, smem_base, kt + AHEAD);
+        const char* st = smem + (kt % TL::NSTAGE) * TL::STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            const int c = ks * 2 + (lane >> 5);
+            f16x8 xf[NX][MT], wf[NT];
+#pragma unroll
+            for (int x = 0; x < NX; x++)
+#pragma unroll
+                for (int m = 0; m < MT; m++)
+                    xf[x][m] = *reinterpret_cast<const f16x8*>(st + ring_off(x * BT + (wt * MT + m) * 32 + (lane & 31), c));
+#pragma unroll
+            for (int n = 0; n < NT; n++) wf[n] = *reinterpret_cast<const f16x8*>(st + ring_off(TL::XROWS + (wn * NT + n) * 32 + (lane & 31), c));
+#pragma unroll
+            for (int x = 0; x < NX; x++)
+#pragma unroll
+                for (int m = 0; m < MT; m++)
+#pragma unroll
+                    for (int n = 0; n < NT; n++) acc[x][m][n] = mfma_f16(wf[n], xf[x][m], acc[x][m][n]);
+        }
+    }
+    __builtin_amdgcn_s_barrier();                           // every wave done reading: smem reusable
+}
+
+template <int BT, int BF, int MT, int NT>
+struct DLane {
+    int hh, wt, wn, l31;
+    __device__ __forceinline__ DLane() {
+        using TL = DTile<BT, BF, MT, NT>;
+        int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        hh = lane >> 5;
+        l31 = lane & 31;
+        wt = wave / TL::WN;
+        wn = wave % TL::WN;
+    }
+    __device__ __forceinline__ int tok(int m) const { return (wt * MT + m) * 32 + l31; }
+    __device__ __forceinline__ int feat(int n, int g) const { return (wn * NT + n) * 32 + 8 * g + 4 * hh; }
+};
+
+// Epilogues.  Accumulators hold (lane = token, 4 consecutive features per register group); writing
+// them straight to row-major global memory is a 64-rows-per-instruction scatter that measured ~28 us
+// of fixed time per launch (address-processing bound, 2x write amplification).  Both epilogues
+// therefore transpose through the LDS ring (free after the main loop) and touch global memory only
+// with whole-row, fully coalesced 1-KiB wave accesses.
+
+// + bias (+ exact GELU) -> f16 row-major   (K4 QKV, K7 FFN1)
+struct DEpiBiasF16 {
+    const float* bias; f16* out; int ldo; int M; int gelu;
+    template <int BT, int BF> static constexpr int smem_bytes() { return BT * (BF * 2 + 16); }
+    template <int BT, int BF, int MT, int NT>
+    __device__ __forceinline__ void run(f32x16 (&acc)[1][MT][NT], int tok0, int f0, char* smem) const {
+        static_assert(BF == 256, "copy-out below assumes 512-byte tile rows");
+        constexpr int LD = BF * 2 + 16;                       // bytes per tile row (+16: spreads banks, keeps 16-B alignment)
+        DLane<BT, BF, MT, NT> lc;
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            char* trow = smem + lc.tok(m) * LD;
+#pragma unroll
+            for (int n = 0; n < NT; n++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    int f = lc.feat(n, g);
+                    f32x4 b = *reinterpret_cast<const f32x4*>(bias + f0 + f);
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        v[i] = acc[0][m][n][4 * g + i] + b[i];
+                        if (gelu) v[i] = gelu_erf(v[i]);
+                    }
+                    *reinterpret_cast<uint2*>(trow + f * 2) = pack4_f16(v[0], v[1], v[2], v[3]);
+                }
+        }
+        __syncthreads();
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int sub = lane >> 5, col = (lane & 31) * 16;    // one wave access = 2 rows x 512 B
+#pragma unroll
+        for (int p = 0; p < BT / 16; p++) {
+            int row = p * 16 + wave * 2 + sub;
+            int tok = tok0 + row;
+            uint4 v = *reinterpret_cast<const uint4*>(smem + row * LD + col);
+            if (tok < M) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(out + (size_t)tok * ldo + f0) + col) = v;
+        }
+    }
+};
+
+// + bias + residual -> LayerNorm -> fp32 stream + f16 operand copy   (K6, K8); BF must be 512.
+// After the transpose every wave owns whole rows: statistics are wave-level shuffles, no
+// cross-wave exchange.
+struct DEpiResidLN {
+    const float* bias; const float* res; const float* gamma; const float* beta;
+    float* out32; f16* out16; int M;
+    template <int BT, int BF> static constexpr int smem_bytes() { return BT * (MST_D * 4 + 16); }
+    template <int BT, int BF, int MT, int NT>
+    __device__ __forceinline__ void run(f32x16 (&acc)[1][MT][NT], int tok0, int f0, char* smem) const {
+        static_assert(BF == MST_D, "LayerNorm needs the whole row in one block");
+        constexpr int LD = MST_D * 4 + 16;                    // 2064-B rows: conflict-free b128 writes and reads
+        DLane<BT, BF, MT, NT> lc;
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            char* trow = smem + lc.tok(m) * LD;
+#pragma unroll
+            for (int n = 0; n < NT; n++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    f32x4 v = {acc[0][m][n][4 * g], acc[0][m][n][4 * g + 1], acc[0][m][n][4 * g + 2], acc[0][m][n][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(trow + lc.feat(n, g) * 4) = v;
+                }
+        }
+        __syncthreads();
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        // lane owns features [4*lane, 4*lane+4) and [256 + 4*lane, ...): two 1-KiB accesses per row
+        const int fa = lane * 4, fb = 256 + lane * 4;
+        const f32x4 ba = *reinterpret_cast<const f32x4*>(bias + fa), bb = *reinterpret_cast<const f32x4*>(bias + fb);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + fa), gb = *reinterpret_cast<const f32x4*>(gamma + fb);
+        const f32x4 ea = *reinterpret_cast<const f32x4*>(beta + fa), eb = *reinterpret_cast<const f32x4*>(beta + fb);
+        constexpr int RPW = BT / 8;                           // rows per wave
+        f32x4 ra[RPW], rb[RPW];
+#pragma unroll
+        for (int r = 0; r < RPW; r++) {                       // all residual loads in flight first
+            int tok = tok0 + wave * RPW + r;
+            size_t off = (size_t)(tok < M ? tok : 0) * MST_D;
+            ra[r] = *reinterpret_cast<const f32x4*>(res + off + fa);
+            rb[r] = *reinterpret_cast<const f32x4*>(res + off + fb);
+        }
+#pragma unroll
+        for (int r = 0; r < RPW; r++) {
+            const int row = wave * RPW + r, tok = tok0 + row;
+            f32x4 xa = *reinterpret_cast<const f32x4*>(smem + row * LD + fa * 4);
+            f32x4 xb = *reinterpret_cast<const f32x4*>(smem + row * LD + fb * 4);
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                xa[i] = xa[i] + ba[i] + ra[r][i];
+                xb[i] = xb[i] + bb[i] + rb[r][i];
+                s += xa[i] + xb[i];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            const float mean = s * (1.0f / MST_D);
+            float s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                xa[i] -= mean;
+                xb[i] -= mean;
+                s2 += xa[i] * xa[i] + xb[i] * xb[i];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
+            const float rstd = 1.0f / sqrtf(s2 * (1.0f / MST_D) + 1e-5f);
+            if (tok >= M) continue;
+            f32x4 ya, yb;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                ya[i] = xa[i] * rstd * ga[i] + ea[i];
+                yb[i] = xb[i] * rstd * gb[i] + eb[i];
+            }
+            const size_t off = (size_t)tok * MST_D;
+            *reinterpret_cast<f32x4*>(out32 + off + fa) = ya;
+            *reinterpret_cast<f32x4*>(out32 + off + fb) = yb;
+            *reinterpret_cast<uint2*>(out16 + off + fa) = pack4_f16(ya[0], ya[1], ya[2], ya[3]);
+            *reinterpret_cast<uint2*>(out16 + off + fb) = pack4_f16(yb[0], yb[1], yb[2], yb[3]);
+        }
+    }
+};
+
+// K3: frames x pose-embedding + bias + positional row -> token stream rows clip*S + 1 + t (fp32 + f16).
+// Same 64 x 512 tile and LDS transpose as the LayerNorm epilogue; `dup` > 0 also writes the rows of
+// the CFG uncond half (identical frames, only the conditioning token differs).
+struct DEpiEmbedIn {
+    const float* bias; const float* pe; float* out32; f16* out16; int T, S, total; size_t dup;
+    template <int BT, int BF> static constexpr int smem_bytes() { return BT * (MST_D * 4 + 16); }
+    template <int BT, int BF, int MT, int NT>
+    __device__ __forceinline__ void run(f32x16 (&acc)[1][MT][NT], int tok0, int f0, char* smem) const {
+        static_assert(BF == MST_D, "whole rows");
+        constexpr int LD = MST_D * 4 + 16;
+        DLane<BT, BF, MT, NT> lc;
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            char* trow = smem + lc.tok(m) * LD;
+#pragma unroll
+            for (int n = 0; n < NT; n++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    f32x4 v = {acc[0][m][n][4 * g], acc[0][m][n][4 * g + 1], acc[0][m][n][4 * g + 2], acc[0][m][n][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(trow + lc.feat(n, g) * 4) = v;
+                }
+        }
+        __syncthreads();
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int fa = lane * 4, fb = 256 + lane * 4;
+        const f32x4 ba = *reinterpret_cast<const f32x4*>(bias + fa), bb = *reinterpret_cast<const f32x4*>(bias + fb);
+        constexpr int RPW = BT / 8;
+#pragma unroll
+        for (int r = 0; r < RPW; r++) {
+            const int row = wave * RPW + r, tok = tok0 + row;
+            if (tok >= total) continue;
+            const int clip = tok / T, t = tok - clip * T;
+            const float* perow = pe + (size_t)(t + 1) * MST_D;
+            f32x4 xa = *reinterpret_cast<const f32x4*>(smem + row * LD + fa * 4);
+            f32x4 xb = *reinterpret_cast<const f32x4*>(smem + row * LD + fb * 4);
+            const f32x4 pa = *reinterpret_cast<const f32x4*>(perow + fa), pb = *reinterpret_cast<const f32x4*>(perow + fb);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                xa[i] = xa[i] + ba[i] + pa[i];
+                xb[i] = xb[i] + bb[i] + pb[i];
+            }
+            size_t off = ((size_t)clip * S + 1 + t) * MST_D;
+#pragma unroll
+            for (int rep = 0; rep < 2; rep++) {
+                *reinterpret_cast<f32x4*>(out32 + off + fa) = xa;
+                *reinterpret_cast<f32x4*>(out32 + off + fb) = xb;
+                *reinterpret_cast<uint2*>(out16 + off + fa) = pack4_f16(xa[0], xa[1], xa[2], xa[3]);
+                *reinterpret_cast<uint2*>(out16 + off + fb) = pack4_f16(xb[0], xb[1], xb[2], xb[3]);
+                if (dup == 0) break;
+                off += dup;
+            }
+        }
+    }
+};
+
+// K9 + K10/K10'/K11/K12 on the ring: output projection with the diffusion update in registers.
+// The lane owns a frame t, so every access to the [clip][feature][frame] tensors is 128 B
+// contiguous per half-wave.  MODE 0 model output only, 1 ancestral step, 2 DDIM step; NX = 2 is
+// the CFG doubled batch (group 0 = cond rows, group 1 = uncond rows of the same clips).
+template <int MODE>
+struct DEpiEmbedOut {
+    const float* bias; int F, T, total; float* out; StepArgs sa;
+    template <int BT, int BF> static constexpr int smem_bytes() { return 0; }
+    template <int BT, int BF, int MT, int NT, int NX = 1>
+    __device__ __forceinline__ void run(f32x16 (&acc)[NX][MT][NT], int tok0, int f0, char*) const {
+        DLane<BT, BF, MT, NT> lc;
+        StepCoef sc;
+        if (MODE != 0) sc = step_coef(sa.tab, sa.nsteps, sa.t, sa.eta);
+        const bool blend = sa.mask != nullptr && sa.motion != nullptr;
+        const bool use_mask = sa.mask != nullptr, use_noise = !sa.philox && sa.noise != nullptr;
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            int tok = tok0 + lc.tok(m);
+            const bool tok_ok = tok < total;
+            if (!tok_ok) tok = total - 1;
+            const int clip = tok / T, t = tok - clip * T;
+            float gs = 0.f;
+            if (NX == 2) gs = sa.scale[clip];
+            const size_t cbase = (size_t)clip * F * T + t;
+#pragma unroll
+            for (int n = 0; n < NT; n++) {
+                if (f0 + (lc.wn * NT + n) * 32 >= F) continue;        // wave-uniform: tile entirely in the padding
+                // ---- gather phase: every load of this 32x32 tile is issued before any is used
+                float xv[16], mk[16], mot[16], nzv[16], bv[16];
+                bool ok[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int fi = f0 + lc.feat(n, r >> 2) + (r & 3);
+                    ok[r] = tok_ok && fi < F;
+                    const size_t idx = cbase + (size_t)(fi < F ? fi : F - 1) * T;
+                    bv[r] = bias[fi < F ? fi : F - 1];
+                    if (MODE != 0) {
+                        xv[r] = sa.x[idx];
+                        mk[r] = use_mask ? sa.mask[idx] : 0.f;
+                        mot[r] = blend ? sa.motion[idx] : 0.f;
+                        nzv[r] = use_noise ? sa.noise[idx] : 0.f;
+                    }
+                }
+                if (MODE != 0 && sa.philox) {
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        float nrm[4];
+                        philox_normal4((unsigned)t, (unsigned)((f0 + lc.feat(n, g)) >> 2), (unsigned)clip, sa.step, sa.seed, nrm);
+#pragma unroll
+                        for (int i = 0; i < 4; i++) nzv[4 * g + i] = nrm[i];
+                    }
+                }
+                // ---- update + store phase
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int fi = f0 + lc.feat(n, r >> 2) + (r & 3);
+                    float mo = acc[0][m][n][r] + bv[r];
+                    if (NX == 2) {                       // model/cfg_sampler.py:43
+                        float un = acc[NX - 1][m][n][r] + bv[r];
+                        mo = un + gs * (mo - un);
+                    }
+                    const size_t idx = cbase + (size_t)fi * T;
+                    if (MODE == 0) {
+                        if (ok[r]) out[idx] = mo;
+                    } else {
+                        float pred;
+                        const float nx = step_update<MODE == 2 ? 1 : 0>(sc, mo, xv[r], nzv[r], blend, mk[r], mot[r],
+                                                                       sa.mask_noise && use_mask, sa.clip, &pred);
+                        if (ok[r]) {
+                            sa.sample[idx] = nx;
+                            if (sa.xstart) sa.xstart[idx] = pred;
+                        }
+                    }
+                }
+            }
+        }
+    }
+};
+
+template <int BT, int BF, int MT, int NT, int NS, int NX, class SRC, class EPI>
+__global__ __launch_bounds__(512) void k_gemm_dma(SRC xs, const f16* __restrict__ W, int ldw, int K, EPI epi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using TL = DTile<BT, BF, MT, NT, NS, NX>;
+    const int tok0 = blockIdx.x * BT;
+    const int f0 = blockIdx.y * BF;
+    f32x16 acc[NX][MT][NT];
+#pragma unroll
+    for (int x = 0; x < NX; x++)
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+#pragma unroll
+            for (int n = 0; n < NT; n++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[x][m][n][r] = 0.f;
+    gemm_mainloop_dma<TL, BT, BF, MT, NT, NX, SRC>(smem, xs, W, ldw, tok0, f0, K, acc);
+    if constexpr (NX == 1) epi.template run<BT, BF, MT, NT>(acc, tok0, f0, smem);
+    else epi.template run<BT, BF, MT, NT, NX>(acc, tok0, f0, smem);
+}
+
+}  // namespace mst

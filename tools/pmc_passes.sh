@@ -1,0 +1,9 @@
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+B="python3 bench.py --steps 1 --warmup 0 --denoise-steps 12 --no-cpu-baseline"
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d gpurun_out/pmcA -- $B > gpurun_out/pmcA.log 2>&1 &&
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_WAIT_INST_LDS SQ_LDS_DATA_FIFO_FULL SQ_INSTS_VALU_MFMA_MOPS_F16 --output-format csv -d gpurun_out/pmcB -- $B > gpurun_out/pmcB.log 2>&1 &&
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmcC -- $B > gpurun_out/pmcC.log 2>&1 &&
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmcD -- $B > gpurun_out/pmcD.log 2>&1 &&
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmcE -- $B > gpurun_out/pmcE.log 2>&1
+echo rc=$?
+ls gpurun_out/pmcA/*/ | head

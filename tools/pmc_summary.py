@@ -1,0 +1,15 @@
+"""Summarise rocprofv3 --pmc counter_collection.csv files: per-kernel mean of each counter."""
+import csv, glob, sys, collections, re
+def short(n):
+    n = re.sub(r"^_ZN3mst\d+", "", n)
+    for a, b in (("k_gemmILi128ELi4ELi1ENS_5XRowsENS_10EpiBiasF16E", "gemm_wide(qkv/ffn1)"), ("k_gemmILi64ELi4ELi1ENS_5XRowsENS_10EpiResidLNE", "gemm_ln(outproj/ffn2)"),
+                 ("k_gemmILi64ELi4ELi1ENS_6XInputENS_10EpiEmbedInE", "embed_in"), ("k_attentionILi7E", "attention7"), ("k_gemmILi64ELi3ELi1ENS_7XFramesENS_11EpiEmbedOutILi1E", "embed_out_ddpm")):
+        if a in n: return b
+    return n[:40]
+for d in sys.argv[1:]:
+    for f in glob.glob(d + "/*/*counter_collection.csv"):
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, cs in acc.items():
+            print(f"{k:28s}", "  ".join(f"{c}={sum(v)/len(v):.4g}" for c, v in sorted(cs.items())), f"(n={len(next(iter(cs.values())))})")
