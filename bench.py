@@ -65,7 +65,7 @@ def main():
     import numpy as np
     import torch
     import mst_amd  # noqa: F401
-    from mst_amd import synthetic as syn
+    from mst_amd import sharding, synthetic as syn
     from mst_amd.engine import DenoiserEngine, Schedule, SAMPLER_DDPM
     from mst_amd.diffusion.gaussian_diffusion import schedule_tables
 
@@ -103,13 +103,11 @@ def main():
     def one_pass(k):
         x = x_T.clone()
         eng.sample_loop(sch, x, NS - 1, 0, SAMPLER_DDPM, cfg=args.cfg, scale=scale, mask=mask, motion=motion,
-                        mask_noise=True, seed=1000 * rank + k)
+                        mask_noise=True, seed=sharding.rank_seed(seed, rank, k))
         return x
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+        sharding.barrier(dev)
 
     for k in range(args.warmup):
         one_pass(k)
@@ -125,10 +123,7 @@ def main():
     eng.profile(False)
     assert torch.isfinite(last).all()
     assert torch.equal(last[:, :3], motion[:, :3]), "inpainted rows must equal the content clip exactly"
-    if dist is not None:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt = sharding.max_over_ranks(dt, dev)
 
     if rank == 0:
         clips = world * B * args.steps
@@ -170,6 +165,7 @@ def cpu_baseline(w, pe, tab, tmap, B, F, T, NS, sample_steps, seed):
     import torch
     from mst_amd import synthetic as syn
     from oracle import denoiser, diffusion
+    torch.set_num_threads(min(16, os.cpu_count() or 1))      # the box's CPU share for one GPU
     cores = torch.get_num_threads()
     shape = (B, F, 1, T)
     txt = syn.normal(seed, "bench/txt", (B, 512))

@@ -80,7 +80,7 @@ def text_embedding(prompt):
 def recorded_noise(tag):
     """Replace torch.randn / randn_like by the k-th tensor of a seeded sequence."""
     state = {"k": 0}
-    orig = (torch.randn, torch.randn_like)
+    orig = (torch.randn, torch.randn_like, torch.rand_like)
 
     def draw(shape):
         a = syn.normal(SEED, f"{tag}/noise/{state['k']}", tuple(shape))
@@ -89,10 +89,17 @@ def recorded_noise(tag):
 
     torch.randn = lambda *shape, **kw: draw(shape[0] if isinstance(shape[0], (tuple, list)) else shape)
     torch.randn_like = lambda x, **kw: draw(x.shape)
+
+    def draw_uniform(x, **kw):          # th.rand_like (gaussian_diffusion.py:1332)
+        a = syn.uniform(SEED, f"{tag}/uniform/{state['k']}", tuple(x.shape), 0.0, 1.0)
+        state["k"] += 1
+        return torch.from_numpy(a)
+
+    torch.rand_like = draw_uniform
     try:
         yield state
     finally:
-        torch.randn, torch.randn_like = orig
+        torch.randn, torch.randn_like, torch.rand_like = orig
 
 
 # -------------------------------------------------------------------------------------- reference
@@ -268,6 +275,31 @@ def main():
                                              clip_denoised=False, model_kwargs=y_c,
                                              skip_timesteps=990, init_image=motion[:1])
                 out["xia|cfgloop|sample"] = s.numpy()
+                # ---- fine-tune objective (few_shot_style_finetune_losses) in eval mode: dropout and the
+                # Bernoulli cond mask are off, every draw is recorded; loss terms + one gradient norm
+                t2m = torch.from_numpy(syn.normal(SEED, "xia/t2m", (B, F, 1, T)))
+                fm = torch.ones(B, 1, 1, T)
+                fm[1, ..., T - 9:] = 0
+                y_t2m = {"y": {"text": prompts, "mask": fm, "inpainting_mask": mask.double(),
+                               "inpainted_motion": t2m}}
+                style = torch.from_numpy(syn.normal(SEED, "xia/style", shp))
+                for use_ddim, dd in ((1, d_ddim), (0, d_full)):
+                    model.zero_grad()
+                    for p_ in model.parameters_wo_enc():
+                        p_.requires_grad_(True)
+                    with torch.enable_grad(), recorded_noise(f"xia/ft{use_ddim}"):
+                        terms = dd.few_shot_style_finetune_losses(
+                            model, t2m, torch.tensor([2, 4]), motion[:1], style, skip_steps=700 if use_ddim else 995,
+                            model_kwargs=y1, model_t2m_kwargs=y_t2m, semantic_guidance=1, use_ddim=use_ddim, Ls=10)
+                    with torch.enable_grad():
+                        terms["loss"].backward()
+                    out[f"xia|ft{use_ddim}|rot_mse"] = terms["rot_mse"].detach().numpy()
+                    out[f"xia|ft{use_ddim}|text_cosine"] = terms["text_cosine"].detach().numpy()
+                    out[f"xia|ft{use_ddim}|loss"] = terms["loss"].detach().numpy()
+                    gsd = dict(model.named_parameters())
+                    out[f"xia|ft{use_ddim}|grad_l0_inproj"] = gsd["seqTransEncoder.layers.0.self_attn.in_proj_weight"].grad[:8, :8].numpy().copy()
+                    out[f"xia|ft{use_ddim}|grad_l7_lin2_norm"] = np.array(gsd["seqTransEncoder.layers.7.linear2.weight"].grad.norm().item())
+                model.zero_grad()
             else:
                 shp = (B, F, 1, T)
                 with recorded_noise("hml/tail8"):

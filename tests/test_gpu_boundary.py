@@ -1,0 +1,265 @@
+"""The drop-in boundary on the GPU: the calls the reference's own scripts make
+(sample/demo_style_transfer.py:234-258, train/finetune_style_diffusion.py:195-212,
+train/training_loop.py:249-263) issued against this package's `utils.model_util`, `diffusion.*` and
+`model.*`, compared with what the REFERENCE returned for the same seeded inputs and recorded noise
+(tests/golden/denoise.npz).  Tolerance: north_star's 1e-3 relative L2."""
+import contextlib
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import mst_amd  # noqa: F401
+import mst_amd.synthetic as syn
+from conftest import SEED, rel_l2
+from mst_amd.model.cfg_sampler import ClassifierFreeSampleModel
+from mst_amd.model.mdm_forstyledataset import StyleDiffusion
+from mst_amd.utils import model_util
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+PROMPTS = ["a person walks proudly", "an old man jumps"]
+F, T = 181, 76
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+def make_args():
+    return types.SimpleNamespace(dataset="stylexia_posrot", latent_dim=512, layers=8, cond_mask_prob=0.1, arch="trans_enc",
+                                 emb_trans_dec=False, diffusion_steps=1000, noise_schedule="cosine", sigma_small=True,
+                                 lambda_vel=0.0, lambda_rcxyz=0.0, lambda_fc=0.0)
+
+
+@contextlib.contextmanager
+def recorded_noise(tag):
+    """The same draw sequence tests/golden/make_golden.py fed the reference."""
+    state = {"k": 0}
+    orig = (torch.randn, torch.randn_like, torch.rand_like)
+
+    def draw(shape, device):
+        a = syn.normal(SEED, f"{tag}/noise/{state['k']}", tuple(shape))
+        state["k"] += 1
+        return torch.from_numpy(a).to(device)
+
+    def draw_u(x, **kw):
+        a = syn.uniform(SEED, f"{tag}/uniform/{state['k']}", tuple(x.shape), 0.0, 1.0)
+        state["k"] += 1
+        return torch.from_numpy(a).to(x.device)
+
+    torch.randn = lambda *s, device=None, **kw: draw(s[0] if isinstance(s[0], (tuple, list)) else s, device)
+    torch.randn_like = lambda x, **kw: draw(x.shape, x.device)
+    torch.rand_like = draw_u
+    try:
+        yield
+    finally:
+        torch.randn, torch.randn_like, torch.rand_like = orig
+
+
+_CACHE = {}
+
+
+def build():
+    if "m" not in _CACHE:
+        model, d_ddim, d_plain = model_util.creat_serval_diffusion(make_args(), StyleDiffusion, "ddim20")
+        _, d_100, d_full = model_util.creat_ddpm_ddim_diffusion(make_args(), StyleDiffusion, "100")
+        sd = {k: torch.from_numpy(np.ascontiguousarray(syn.tensor_for(SEED, k, tuple(v.shape))))
+              for k, v in model.state_dict().items() if not k.endswith(".pe") and "clip_model" not in k}
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        assert not unexpected and all(k.endswith(".pe") for k in missing)
+        model.motion_enc.mdm_model.set_text_encoder(
+            lambda texts: torch.stack([torch.from_numpy(syn.normal(SEED, "text/" + t, (512,))) for t in texts]))
+        model = model.to(dev()).eval()
+        _CACHE.update(m=model, ddim=d_ddim, plain=d_plain, r100=d_100, full=d_full)
+    return _CACHE
+
+
+def inputs():
+    x = cu(syn.normal(SEED, "xia/x", (2, F, 1, T)))
+    t = torch.tensor([3, 957], device=dev())
+    y = {"text": PROMPTS, "mask": torch.ones(2, 1, 1, T, device=dev())}
+    mask = cu(syn.root_horizontal_mask(2, F, T))
+    motion = cu(syn.normal(SEED, "xia/motion", (2, F, 1, T)))
+    return x, t, y, mask, motion
+
+
+def test_model_call_and_cfg_wrapper(golden):
+    c = build()
+    g = golden["denoise"]
+    x, t, y, _, _ = inputs()
+    with torch.no_grad():
+        out = c["m"](x, t, y=y)
+        out_u = c["m"](x, t, y={**y, "uncond": True})
+        out_p = c["m"].motion_enc.mdm_model(x, t, y=y)
+        out_c = ClassifierFreeSampleModel(c["m"])(x, t, {**y, "scale": torch.tensor([2.5, 1.5], device=dev())})
+    assert rel_l2(out.cpu().numpy(), g["xia|fwd_cond"]) < TOL
+    assert rel_l2(out_u.cpu().numpy(), g["xia|fwd_uncond"]) < TOL
+    assert rel_l2(out_p.cpu().numpy(), g["xia|prior_fwd"]) < TOL
+    assert rel_l2(out_c.cpu().numpy(), g["xia|cfg"]) < TOL
+
+
+def test_single_steps_through_diffusion_objects(golden):
+    c = build()
+    g = golden["denoise"]
+    x, t, y, mask, motion = inputs()
+    yk = {"y": {**y, "inpainting_mask": mask, "inpainted_motion": motion}}
+    with torch.no_grad():
+        with recorded_noise("xia/q"):
+            q = c["full"].q_sample(motion, torch.tensor([10, 700], device=dev()), model_kwargs=yk)
+        assert rel_l2(q.cpu().numpy(), g["xia|q_sample"]) < 2e-6
+        for name, dd, tt in (("full", c["full"], [0, 500]), ("ddim", c["ddim"], [0, 19]), ("r100", c["r100"], [1, 99])):
+            tt = torch.tensor(tt, device=dev())
+            with recorded_noise(f"xia/ps_{name}"):
+                r = dd.p_sample(c["m"], x, tt, clip_denoised=False, model_kwargs=yk)
+            assert rel_l2(r["sample"].cpu().numpy(), g[f"xia|p_sample_{name}|sample"]) < TOL
+            assert rel_l2(r["pred_xstart"].cpu().numpy(), g[f"xia|p_sample_{name}|pred_xstart"]) < TOL
+            assert torch.equal(r["pred_xstart"][:, :3], motion[:, :3])          # inpainting rows bit-exact
+            with recorded_noise(f"xia/dd_{name}"):
+                r = dd.ddim_sample(c["m"], x, tt, clip_denoised=False, model_kwargs=yk)
+            assert rel_l2(r["sample"].cpu().numpy(), g[f"xia|ddim_sample_{name}|sample"]) < TOL
+            with recorded_noise(f"xia/dd5_{name}"):
+                r = dd.ddim_sample(c["m"], x, tt, clip_denoised=False, model_kwargs=yk, eta=0.5)
+            assert rel_l2(r["sample"].cpu().numpy(), g[f"xia|ddim_sample_eta_{name}|sample"]) < TOL
+        with recorded_noise("xia/ps_base"):      # plain SpacedDiffusion: noise not masked
+            r = c["plain"].p_sample(c["m"], x, torch.tensor([7, 400], device=dev()), clip_denoised=False, model_kwargs=yk)
+        assert rel_l2(r["sample"].cpu().numpy(), g["xia|p_sample_base|sample"]) < TOL
+
+
+def test_script_level_loops(golden):
+    """The four loop shapes the scripts use, issued exactly as the reference was called when the
+    golden vectors were made."""
+    c = build()
+    g = golden["denoise"]
+    x, t, y, mask, motion = inputs()
+    shp = (1, F, 1, T)
+    y1 = {"y": {"text": PROMPTS[:1], "mask": torch.ones(1, 1, 1, T, device=dev()),
+                "inpainting_mask": mask[:1], "inpainted_motion": motion[:1]}}
+    with recorded_noise("xia/loop100"):        # BASELINE.json configs[0]
+        s = c["r100"].p_sample_loop(c["m"], shp, clip_denoised=False, model_kwargs=y1)
+    assert rel_l2(s.cpu().numpy(), g["xia|loop100|sample"]) < TOL
+    assert torch.equal(s[:, :3], motion[:1, :3])
+    with recorded_noise("xia/demo"):           # sample/demo_style_transfer.py:244-258
+        dump = c["ddim"].ddim_sample_loop(c["m"], shp, clip_denoised=False, model_kwargs=y1, skip_timesteps=14,
+                                          init_image=motion[:1], progress=False, dump_all_xstart=True)
+    assert len(dump) == 6
+    assert rel_l2(torch.cat(dump).cpu().numpy(), g["xia|demo|xstart"]) < TOL
+    y_n = {"y": {"text": PROMPTS[:1], "mask": torch.ones(1, 1, 1, T, device=dev()),
+                 "inpainting_mask": torch.zeros(shp, device=dev()), "inpainted_motion": motion[:1]}}
+    with recorded_noise("xia/neutral"):        # train/finetune_style_diffusion.py:195-212
+        dump = c["full"].p_sample_loop(c["m"].motion_enc.mdm_model, shp, clip_denoised=False, model_kwargs=y_n,
+                                       skip_timesteps=0, init_image=motion[:1], stop_timesteps=990, dump_all_xstart=True)
+    assert len(dump) == 10
+    assert rel_l2(dump[-1].cpu().numpy(), g["xia|neutral|xstart_last"]) < TOL
+    y_c = {"y": {**y1["y"], "scale": torch.tensor([2.5], device=dev())}}
+    with recorded_noise("xia/cfgloop"):        # BASELINE.json configs[2] at toy length
+        s = c["full"].p_sample_loop(ClassifierFreeSampleModel(c["m"]), shp, clip_denoised=False, model_kwargs=y_c,
+                                    skip_timesteps=990, init_image=motion[:1])
+    assert rel_l2(s.cpu().numpy(), g["xia|cfgloop|sample"]) < TOL
+    # model_kwargs must not be mutated by sampling
+    assert set(y_c["y"]) == {"text", "mask", "inpainting_mask", "inpainted_motion", "scale"}
+
+
+def test_progressive_generator_and_dump_steps():
+    c = build()
+    x, t, y, mask, motion = inputs()
+    shp = (1, F, 1, T)
+    y1 = {"y": {"text": PROMPTS[:1], "mask": torch.ones(1, 1, 1, T, device=dev()),
+                "inpainting_mask": mask[:1], "inpainted_motion": motion[:1]}}
+    with recorded_noise("p/a"):
+        ref = c["ddim"].p_sample_loop(c["m"], shp, clip_denoised=False, model_kwargs=y1, skip_timesteps=15)
+    with recorded_noise("p/a"):
+        outs = list(c["ddim"].p_sample_loop_progressive(c["m"], shp, clip_denoised=False, model_kwargs=y1, skip_timesteps=15))
+    assert len(outs) == 5 and all(o["sample"] is not None for o in outs)
+    assert torch.equal(outs[-1]["sample"], ref)
+    with recorded_noise("p/a"):
+        dumped = c["ddim"].p_sample_loop(c["m"], shp, clip_denoised=False, model_kwargs=y1, skip_timesteps=15, dump_steps=[1, 4])
+    assert len(dumped) == 2 and torch.equal(dumped[1], ref) and torch.equal(dumped[0], outs[1]["sample"])
+    # philox noise source: no torch RNG call inside the loop, still deterministic per torch seed
+    c["ddim"].noise_source = "philox"
+    try:
+        torch.manual_seed(5)
+        a = c["ddim"].p_sample_loop(c["m"], shp, clip_denoised=False, model_kwargs=y1, noise=x[:1].clone())
+        torch.manual_seed(5)
+        b = c["ddim"].p_sample_loop(c["m"], shp, clip_denoised=False, model_kwargs=y1, noise=x[:1].clone())
+    finally:
+        c["ddim"].noise_source = "torch"
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+
+
+def test_generic_model_callable_uses_fused_step_kernel():
+    """Any callable works as `model`: the blend / posterior / noise math is the HIP step kernel."""
+    from oracle import diffusion, schedule
+    c = build()
+    x, t, y, mask, motion = inputs()
+    yk = {"y": {"inpainting_mask": mask, "inpainted_motion": motion}}
+    fake = cu(syn.normal(SEED, "fake/out", (2, F, 1, T)))
+
+    class Fake(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+            self.seen = None
+
+        def forward(self, xx, ts, y=None):
+            self.seen = ts.clone()
+            return fake
+
+    fm = Fake().to(dev())
+    tt = torch.tensor([0, 19], device=dev())
+    with recorded_noise("g/a"):
+        r = c["ddim"].p_sample(fm, x, tt, clip_denoised=False, model_kwargs=yk)
+    assert fm.seen.tolist() == [0, 950]                       # respace.py:129-131 remap
+    tab, _ = schedule.make("cosine", 1000, "ddim20")
+    ref = diffusion.p_sample(tab, fake.cpu(), x.cpu(), tt.cpu(), torch.from_numpy(syn.normal(SEED, "g/a/noise/0", (2, F, 1, T))),
+                             True, mask.cpu(), motion.cpu())
+    assert rel_l2(r["sample"].cpu().numpy(), ref["sample"].numpy()) < 2e-6
+
+
+def test_finetune_objective_matches_reference(golden):
+    """few_shot_style_finetune_losses (gaussian_diffusion.py:1317-1399) with the model in eval mode:
+    loss terms and gradients against the reference's (autograd path: torch ops on the GPU)."""
+    c = build()
+    g = golden["denoise"]
+    x, t, y, mask, motion = inputs()
+    shp = (1, F, 1, T)
+    y1 = {"y": {"text": PROMPTS[:1], "mask": torch.ones(1, 1, 1, T, device=dev()),
+                "inpainting_mask": mask[:1], "inpainted_motion": motion[:1]}}
+    t2m = cu(syn.normal(SEED, "xia/t2m", (2, F, 1, T)))
+    fm = torch.ones(2, 1, 1, T, device=dev())
+    fm[1, ..., T - 9:] = 0
+    y_t2m = {"y": {"text": PROMPTS, "mask": fm, "inpainting_mask": mask.double(), "inpainted_motion": t2m}}
+    style = cu(syn.normal(SEED, "xia/style", shp))
+    model = c["m"]
+    for use_ddim, dd in ((1, c["ddim"]), (0, c["full"])):
+        model.zero_grad()
+        with recorded_noise(f"xia/ft{use_ddim}"):
+            terms = dd.few_shot_style_finetune_losses(model, t2m, torch.tensor([2, 4], device=dev()), motion[:1], style,
+                                                      skip_steps=700 if use_ddim else 995, model_kwargs=y1,
+                                                      model_t2m_kwargs=y_t2m, semantic_guidance=1, use_ddim=use_ddim, Ls=10)
+        terms["loss"].backward()
+        assert rel_l2(terms["rot_mse"].detach().cpu().numpy(), g[f"xia|ft{use_ddim}|rot_mse"]) < 1e-4
+        assert abs(float(terms["text_cosine"]) - float(g[f"xia|ft{use_ddim}|text_cosine"])) < 1e-4
+        assert abs(float(terms["loss"]) - float(g[f"xia|ft{use_ddim}|loss"])) < 1e-3 * abs(float(g[f"xia|ft{use_ddim}|loss"]))
+        grads = dict(model.named_parameters())
+        g0 = grads["seqTransEncoder.layers.0.self_attn.in_proj_weight"].grad[:8, :8].cpu().numpy()
+        assert rel_l2(g0, g[f"xia|ft{use_ddim}|grad_l0_inproj"]) < 5e-3
+        gn = float(grads["seqTransEncoder.layers.7.linear2.weight"].grad.norm())
+        assert abs(gn - float(g[f"xia|ft{use_ddim}|grad_l7_lin2_norm"])) < 5e-3 * gn
+        assert all(p.grad is None for p in model.motion_enc.parameters())     # frozen parts get no gradient
+    model.zero_grad()
+    # after an optimizer-style in-place update the engine must pick up the new weights
+    with torch.no_grad():
+        bias = model.seqTransEncoder.layers[0].linear1.bias
+        saved = bias.clone()
+        before = model(x, t, y=y)
+        bias.add_(0.5)
+        after = model(x, t, y=y)
+        bias.copy_(saved)
+        again = model(x, t, y=y)
+    assert not torch.equal(before, after) and torch.equal(before, again)
