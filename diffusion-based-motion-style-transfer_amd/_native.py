@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (loads the HIP runtime the library must share)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmst_engine.so")
+LIB_PATH = os.environ.get("MST_ENGINE_LIB") or os.path.join(_HERE, "libmst_engine.so")   # env: A/B builds
 _lib = None
 
 

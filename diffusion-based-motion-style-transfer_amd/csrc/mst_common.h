@@ -41,18 +41,27 @@ __device__ __forceinline__ uint2 pack4_f16(float a, float b, float c, float d) {
     return __builtin_bit_cast(uint2, v);
 }
 
-// LDS image of a [rows][64] f16 K-slab (128-B rows): 16-B chunk c of row `row` lives at
-// chunk c ^ ((row >> 1) & 7).  With two rows per 256-B bank row this makes the ds_read_b128
-// fragment reads of a 32-row tile conflict-free (lane groups {0-3,12-15,20-27} ... see DESIGN.md).
-__device__ __forceinline__ int slab_off(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
 
-// exact-erf GELU (nn.TransformerEncoderLayer activation="gelu", mdm_forstyledataset.py:539-543)
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf-form GELU (nn.TransformerEncoderLayer activation="gelu", mdm_forstyledataset.py:539-543).
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 absolute): branch-free, ~14 VALU ops + one
+// v_exp + one v_rcp.  libm's erff inlines to ~50 ops with data-dependent branches per element, which
+// measured ~15-20 us per FFN1 launch; its extra accuracy is invisible behind the f16 store (2^-11).
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float y = 1.0f - p * t * __expf(-ax * ax);
+    return copysignf(y, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
 
 // ------------------------------------------------------------------------------------------
 // Philox4x32-10 + Box-Muller: counter-based normals for the in-kernel noise mode.
-// Element (clip, f, t) of step `step` = component (f & 3) of the 4 normals generated from
-// counter (t, f >> 2, clip, step) under key (seed_lo, seed_hi).
+// Element (clip, f, t) of step `step` = component (t & 3) of the 4 normals generated from
+// counter (t >> 2, f, clip, step) under key (seed_lo, seed_hi): one call serves 4 consecutive frames.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
@@ -67,10 +76,10 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-__device__ __forceinline__ void philox_normal4(uint32_t t, uint32_t fq, uint32_t clip, uint32_t step,
+__device__ __forceinline__ void philox_normal4(uint32_t tq, uint32_t f, uint32_t clip, uint32_t step,
                                                uint64_t seed, float (&n)[4]) {
     uint32_t r[4];
-    philox4x32_10(t, fq, clip, step, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    philox4x32_10(tq, f, clip, step, (uint32_t)seed, (uint32_t)(seed >> 32), r);
     // u in (0, 1]: never log(0)
     float u0 = ((float)(r[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);
     float u1 = (float)(r[1] >> 8) * (1.0f / 16777216.0f);
@@ -130,3 +139,16 @@ __device__ __forceinline__ float step_update(const StepCoef& c, float model_out,
         return mean_pred + c.sigma_ddim * noise;
     }
 }
+
+// arguments of the fused diffusion step (output-projection epilogue)
+struct StepArgs {
+    const float* tab; int nsteps; int t;          // schedule tables (device) and the diffusion index
+    float eta;
+    const float* mask; const float* motion;       // [B,F,1,T] or null
+    const float* noise;                           // [B,F,1,T] or null (-> philox)
+    const float* scale;                           // [B] guidance scale (cfg)
+    const float* x;                               // x_t
+    float* sample; float* xstart;                 // outputs (xstart may be null)
+    unsigned long long seed; unsigned step;
+    int mask_noise, clip, philox;
+};

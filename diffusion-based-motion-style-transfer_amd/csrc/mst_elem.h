@@ -125,18 +125,18 @@ __global__ void k_step_epilogue(const float* __restrict__ tab, int nsteps, float
     }
 }
 
-// same counter mapping as the fused epilogue: element (clip, f, t) <- component f & 3
+// same counter mapping as the fused epilogue: element (clip, f, t) <- component t & 3 of counter (t >> 2, f, clip, step)
 __global__ void k_philox_normal(float* __restrict__ out, int F, int T, unsigned long long seed, unsigned step) {
     const int clip = blockIdx.y;
-    const int FQ = (F + 3) >> 2;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < FQ * T; i += gridDim.x * blockDim.x) {
-        int fq = i / T, t = i - fq * T;
+    const int TQ = (T + 3) >> 2;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < F * TQ; i += gridDim.x * blockDim.x) {
+        int f = i / TQ, tq = i - f * TQ;
         float n[4];
-        philox_normal4((unsigned)t, (unsigned)fq, (unsigned)clip, step, seed, n);
+        philox_normal4((unsigned)tq, (unsigned)f, (unsigned)clip, step, seed, n);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            int f = fq * 4 + j;
-            if (f < F) out[((size_t)clip * F + f) * T + t] = n[j];
+            int t = tq * 4 + j;
+            if (t < T) out[((size_t)clip * F + f) * T + t] = n[j];
         }
     }
 }

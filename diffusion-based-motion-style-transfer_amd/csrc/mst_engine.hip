@@ -11,14 +11,31 @@
 #include "mst_attn.h"
 #include "mst_common.h"
 #include "mst_elem.h"
-#include "mst_gemm.h"
 #include "mst_gemm_dma.h"
 
 using namespace mst;
 
-#ifndef WIDE_NS
-#define WIDE_NS 3   // ring slots of the wide (QKV / FFN1) tiles: 3 x 24 KB lets two blocks share a CU
+// wide (QKV / FFN1) tile: WIDE_BT tokens x 256 features, 8 waves of (WIDE_BT/64) x 2 MFMA tiles
+#ifndef WIDE_BT
+#define WIDE_BT 128   // same-box A/B (tools/ab.sh): 128/3-slot/XCD 52.4 clips/s, 128/4-slot 47.2, 256/4-slot 47.5
 #endif
+#ifndef WIDE_NS
+#define WIDE_NS 3     // 3 x 24 KB ring: two blocks share a CU
+#endif
+// ablation builds only (tools/ab.sh): ABL_LN == 2 shortens the LN GEMMs' K loop to 3 slabs
+#if defined(ABL_LN) && ABL_LN == 2
+#define ABL_K(k) 96
+#else
+#define ABL_K(k) (k)
+#endif
+#ifndef WIDE_XCD
+#define WIDE_XCD 1
+#endif
+// launch geometry of a wide GEMM over nx token tiles x ny feature tiles (1-D when XCD-aware)
+static dim3 wide_grid(int M, int ny) {
+    const int nx = (M + WIDE_BT - 1) / WIDE_BT;
+    return WIDE_XCD ? dim3(((nx + 7) / 8) * 8 * ny, 1, 1) : dim3(nx, ny, 1);
+}
 
 // ------------------------------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
@@ -134,7 +151,7 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     e->cfg = *c;
     e->S_max = c->max_frames + 1;
     size_t M = (size_t)c->max_rows * e->S_max;
-    e->M_pad = (int)(((M + 127) / 128) * 128);
+    e->M_pad = (int)(((M + 255) / 256) * 256);
     e->kin_pad = ((c->feats + 63) / 64) * 64;
     e->nt_out = (c->feats + 255) / 256;              // output-projection tile = 256 * nt_out features
     e->fout_pad = e->nt_out * 256;
@@ -336,22 +353,8 @@ struct ProfScope {
 };
 
 // ------------------------------------------------------------------------------------------ launches
-template <int BT, int NT, int NX, class XL, class EPI>
-static int launch_gemm(dim3 grid, const XL& xl, const f16* W, int ldw, int K, const EPI& epi, hipStream_t st) {
-    using TL = Tile<BT, NT, NX>;
-    auto kern = k_gemm<BT, NT, NX, XL, EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TL::SMEM));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(512), TL::SMEM, st, xl, W, ldw, K, epi);
-    HIPCHECK(hipGetLastError());
-    return 0;
-}
-
 template <int BT, int BF, int MT, int NT, int NS, int NX, class SRC, class EPI>
-static int launch_gemm_dma(dim3 grid, const SRC& xs, const f16* W, int ldw, int K, const EPI& epi, hipStream_t st) {
+static int launch_gemm_dma(dim3 grid, const SRC& xs, const f16* W, int ldw, int K, const EPI& epi, hipStream_t st, int xcd_ny = 0) {
     using TL = DTile<BT, BF, MT, NT, NS, NX>;
     static_assert(EPI::template smem_bytes<BT, BF>() <= TL::SMEM, "epilogue tile must fit the ring");
     static_assert(TL::SMEM <= 163840, "ring exceeds the 160 KiB LDS");
@@ -362,7 +365,7 @@ static int launch_gemm_dma(dim3 grid, const SRC& xs, const f16* W, int ldw, int 
         attr_set = true;
     }
     if (K < 32 * (NS - 1) || (K & 31)) return fail("gemm: K=%d unsupported by the %d-slot ring", K, NS);
-    hipLaunchKernelGGL(kern, grid, dim3(512), TL::SMEM, st, xs, W, ldw, K, epi);
+    hipLaunchKernelGGL(kern, grid, dim3(512), TL::SMEM, st, xs, W, ldw, K, xcd_ny, epi);
     HIPCHECK(hipGetLastError());
     return 0;
 }
@@ -451,8 +454,8 @@ static int run_trunk(mst_engine* e, const float* x, int clips_x, int rows, int T
         const LayerW& w = e->L[l];
         {
             ProfScope ps(e, FAM_QKV, st);
-            DEpiBiasF16 epi{w.b_in, e->qkv, 3 * MST_D, M, 0};
-            CHECK((launch_gemm_dma<128, 256, 2, 2, WIDE_NS, 1>(dim3((M + 127) / 128, 3 * MST_D / 256), RowsDirect{e->hx, MST_D}, w.w_in, MST_D, MST_D, epi, st)));
+            DEpiBiasF16<false> epi{w.b_in, e->qkv, 3 * MST_D, M};
+            CHECK((launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, 3 * MST_D / 256), RowsDirect{e->hx, MST_D}, w.w_in, MST_D, MST_D, epi, st, WIDE_XCD ? 3 * MST_D / 256 : 0)));
         }
         DBG_STOP(1)
         {
@@ -463,19 +466,19 @@ static int run_trunk(mst_engine* e, const float* x, int clips_x, int rows, int T
         {
             ProfScope ps(e, FAM_OUTPROJ_LN, st);
             DEpiResidLN epi{w.b_out, e->hs, w.g1, w.be1, e->hs, e->hx, M};
-            CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1>(dim3((M + 63) / 64, 1), RowsDirect{e->att, MST_D}, w.w_out, MST_D, MST_D, epi, st)));
+            CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1>(dim3((M + 63) / 64, 1), RowsDirect{e->att, MST_D}, w.w_out, MST_D, ABL_K(MST_D), epi, st)));
         }
         DBG_STOP(3)
         {
             ProfScope ps(e, FAM_FFN1, st);
-            DEpiBiasF16 epi{w.b1, e->hid, MST_FF, M, 1};
-            CHECK((launch_gemm_dma<128, 256, 2, 2, WIDE_NS, 1>(dim3((M + 127) / 128, MST_FF / 256), RowsDirect{e->hx, MST_D}, w.w1, MST_D, MST_D, epi, st)));
+            DEpiBiasF16<true> epi{w.b1, e->hid, MST_FF, M};
+            CHECK((launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, MST_FF / 256), RowsDirect{e->hx, MST_D}, w.w1, MST_D, MST_D, epi, st, WIDE_XCD ? MST_FF / 256 : 0)));
         }
         DBG_STOP(4)
         {
             ProfScope ps(e, FAM_FFN2_LN, st);
             DEpiResidLN epi{w.b2, e->hs, w.g2, w.be2, e->hs, e->hx, M};
-            CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1>(dim3((M + 63) / 64, 1), RowsDirect{e->hid, MST_FF}, w.w2, MST_FF, MST_FF, epi, st)));
+            CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1>(dim3((M + 63) / 64, 1), RowsDirect{e->hid, MST_FF}, w.w2, MST_FF, ABL_K(MST_FF), epi, st)));
         }
         DBG_STOP(5)
     }
@@ -611,7 +614,7 @@ extern "C" int mst_step_epilogue(const mst_schedule* s, const float* model_out, 
 extern "C" int mst_philox_normal(float* out, int32_t batch, int32_t feats, int32_t frames, uint64_t seed, uint32_t step,
                                  void* stream) {
     if (!out || batch < 1 || feats < 1 || frames < 1) return fail("mst_philox_normal: bad arguments");
-    int n = ((feats + 3) / 4) * frames;
+    int n = feats * ((frames + 3) / 4);
     hipLaunchKernelGGL(k_philox_normal, dim3((n + 255) / 256, batch), dim3(256), 0, (hipStream_t)stream, out, feats, frames,
                        (unsigned long long)seed, (unsigned)step);
     HIPCHECK(hipGetLastError());

@@ -1,6 +1,6 @@
 // Hot GEMMs (QKV, out-proj+LN, FFN1+GELU, FFN2+LN) on an LDS-DMA ring.
 //
-// Why a second mainloop: the register-staged loop of mst_gemm.h measured 67-79 % SQ_WAIT_ANY and
+// Why LDS-DMA: the first, register-staged loop (global -> VGPR -> ds_write, double buffer) measured 67-79 % SQ_WAIT_ANY and
 // ~9 % MFMA busy on MI355X (profiles/r01_v0_*): with one 8-wave block per CU nothing hides the
 // L2 latency of the next K-slab.  Here K is consumed in 32-deep slabs through a 4-slot LDS ring
 // filled by `global_load_lds_dwordx4` (no VGPR staging, no ds_write); three slabs are always in
@@ -13,11 +13,10 @@
 // lane-linearly, so the swizzle is applied on the per-lane SOURCE address (guide rule 21).
 //
 // Wave tile = MT x NT MFMA tiles (2 x 2 here): 4 fragment reads feed 4 MFMAs per k-step.
-// Orientation as in mst_gemm.h: A operand = weights, B operand = activations, so a lane owns one
-// token and registers run over features.
+// Orientation: the MFMA A operand is the WEIGHT fragment, B the ACTIVATION fragment, so in the 32x32
+// result a lane owns one token and its 16 registers run over features in groups of 4 consecutive ones.
 #pragma once
 #include "mst_common.h"
-#include "mst_gemm.h"   // StepArgs
 
 namespace mst {
 
@@ -152,42 +151,52 @@ struct DLane {
 // therefore transpose through the LDS ring (free after the main loop) and touch global memory only
 // with whole-row, fully coalesced 1-KiB wave accesses.
 
-// + bias (+ exact GELU) -> f16 row-major   (K4 QKV, K7 FFN1)
+// + bias (+ erf GELU) -> f16 row-major   (K4 QKV: GELU = false, K7 FFN1: GELU = true)
+template <bool GELU>
 struct DEpiBiasF16 {
-    const float* bias; f16* out; int ldo; int M; int gelu;
-    template <int BT, int BF> static constexpr int smem_bytes() { return BT * (BF * 2 + 16); }
+    const float* bias; f16* out; int ldo; int M;
+    __device__ __forceinline__ int rows() const { return M; }
+    template <int BT, int BF> static constexpr int smem_bytes() { return (BT < 128 ? BT : 128) * (BF * 2 + 16); }
     template <int BT, int BF, int MT, int NT>
     __device__ __forceinline__ void run(f32x16 (&acc)[1][MT][NT], int tok0, int f0, char* smem) const {
         static_assert(BF == 256, "copy-out below assumes 512-byte tile rows");
         constexpr int LD = BF * 2 + 16;                       // bytes per tile row (+16: spreads banks, keeps 16-B alignment)
+        constexpr int PR = BT < 128 ? BT : 128;               // rows transposed per pass
+        constexpr int PASSES = BT / PR;
         DLane<BT, BF, MT, NT> lc;
-#pragma unroll
-        for (int m = 0; m < MT; m++) {
-            char* trow = smem + lc.tok(m) * LD;
-#pragma unroll
-            for (int n = 0; n < NT; n++)
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    int f = lc.feat(n, g);
-                    f32x4 b = *reinterpret_cast<const f32x4*>(bias + f0 + f);
-                    float v[4];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        v[i] = acc[0][m][n][4 * g + i] + b[i];
-                        if (gelu) v[i] = gelu_erf(v[i]);
-                    }
-                    *reinterpret_cast<uint2*>(trow + f * 2) = pack4_f16(v[0], v[1], v[2], v[3]);
-                }
-        }
-        __syncthreads();
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int sub = lane >> 5, col = (lane & 31) * 16;    // one wave access = 2 rows x 512 B
 #pragma unroll
-        for (int p = 0; p < BT / 16; p++) {
-            int row = p * 16 + wave * 2 + sub;
-            int tok = tok0 + row;
-            uint4 v = *reinterpret_cast<const uint4*>(smem + row * LD + col);
-            if (tok < M) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(out + (size_t)tok * ldo + f0) + col) = v;
+        for (int pass = 0; pass < PASSES; pass++) {
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                const int tl = lc.tok(m);
+                if (tl / PR != pass) continue;                // wave-uniform
+                char* trow = smem + (tl - pass * PR) * LD;
+#pragma unroll
+                for (int n = 0; n < NT; n++)
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        int f = lc.feat(n, g);
+                        f32x4 b = *reinterpret_cast<const f32x4*>(bias + f0 + f);
+                        float v[4];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            v[i] = acc[0][m][n][4 * g + i] + b[i];
+                            if (GELU) v[i] = gelu_erf(v[i]);
+                        }
+                        *reinterpret_cast<uint2*>(trow + f * 2) = pack4_f16(v[0], v[1], v[2], v[3]);
+                    }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < PR / 16; p++) {
+                int row = p * 16 + wave * 2 + sub;
+                int tok = tok0 + pass * PR + row;
+                uint4 v = *reinterpret_cast<const uint4*>(smem + row * LD + col);
+                if (tok < M) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(out + (size_t)tok * ldo + f0) + col) = v;
+            }
+            if (pass + 1 < PASSES) __syncthreads();
         }
     }
 };
@@ -198,10 +207,19 @@ struct DEpiBiasF16 {
 struct DEpiResidLN {
     const float* bias; const float* res; const float* gamma; const float* beta;
     float* out32; f16* out16; int M;
+    __device__ __forceinline__ int rows() const { return M; }
     template <int BT, int BF> static constexpr int smem_bytes() { return BT * (MST_D * 4 + 16); }
     template <int BT, int BF, int MT, int NT>
     __device__ __forceinline__ void run(f32x16 (&acc)[1][MT][NT], int tok0, int f0, char* smem) const {
         static_assert(BF == MST_D, "LayerNorm needs the whole row in one block");
+#if defined(ABL_LN) && ABL_LN == 1      // ablation build: no epilogue (keep the accumulators alive)
+        {
+            float keep = 0.f;
+            for (int m = 0; m < MT; m++) for (int n = 0; n < NT; n++) for (int r = 0; r < 16; r++) keep += acc[0][m][n][r];
+            if (keep == 123.456f) out32[0] = keep;
+            return;
+        }
+#endif
         constexpr int LD = MST_D * 4 + 16;                    // 2064-B rows: conflict-free b128 writes and reads
         DLane<BT, BF, MT, NT> lc;
 #pragma unroll
@@ -220,48 +238,63 @@ struct DEpiResidLN {
         // lane owns features [4*lane, 4*lane+4) and [256 + 4*lane, ...): two 1-KiB accesses per row
         const int fa = lane * 4, fb = 256 + lane * 4;
         const f32x4 ba = *reinterpret_cast<const f32x4*>(bias + fa), bb = *reinterpret_cast<const f32x4*>(bias + fb);
-        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + fa), gb = *reinterpret_cast<const f32x4*>(gamma + fb);
-        const f32x4 ea = *reinterpret_cast<const f32x4*>(beta + fa), eb = *reinterpret_cast<const f32x4*>(beta + fb);
         constexpr int RPW = BT / 8;                           // rows per wave
-        f32x4 ra[RPW], rb[RPW];
-#pragma unroll
-        for (int r = 0; r < RPW; r++) {                       // all residual loads in flight first
-            int tok = tok0 + wave * RPW + r;
-            size_t off = (size_t)(tok < M ? tok : 0) * MST_D;
-            ra[r] = *reinterpret_cast<const f32x4*>(res + off + fa);
-            rb[r] = *reinterpret_cast<const f32x4*>(res + off + fb);
-        }
+        // all residual loads in flight first (they overlap the LDS reads below)
+        f32x4 xa[RPW], xb[RPW];
 #pragma unroll
         for (int r = 0; r < RPW; r++) {
-            const int row = wave * RPW + r, tok = tok0 + row;
-            f32x4 xa = *reinterpret_cast<const f32x4*>(smem + row * LD + fa * 4);
-            f32x4 xb = *reinterpret_cast<const f32x4*>(smem + row * LD + fb * 4);
-            float s = 0.f;
+            int tok = tok0 + wave * RPW + r;
+            size_t off = (size_t)(tok < M ? tok : 0) * MST_D;
+            xa[r] = *reinterpret_cast<const f32x4*>(res + off + fa);
+            xb[r] = *reinterpret_cast<const f32x4*>(res + off + fb);
+        }
+        // row sums for ALL rows first, then the shuffle ladders step by step across rows: RPW
+        // independent ds_bpermutes per step instead of RPW serial 6-deep dependency chains
+        float s[RPW], s2[RPW];
+#pragma unroll
+        for (int r = 0; r < RPW; r++) {
+            const int row = wave * RPW + r;
+            const f32x4 ta = *reinterpret_cast<const f32x4*>(smem + row * LD + fa * 4);
+            const f32x4 tb = *reinterpret_cast<const f32x4*>(smem + row * LD + fb * 4);
+            s[r] = 0.f;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                xa[i] = xa[i] + ba[i] + ra[r][i];
-                xb[i] = xb[i] + bb[i] + rb[r][i];
-                s += xa[i] + xb[i];
+                xa[r][i] = ta[i] + ba[i] + xa[r][i];
+                xb[r][i] = tb[i] + bb[i] + xb[r][i];
+                s[r] += xa[r][i] + xb[r][i];
             }
+        }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            const float mean = s * (1.0f / MST_D);
-            float s2 = 0.f;
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int r = 0; r < RPW; r++) s[r] += __shfl_xor(s[r], o);
+#pragma unroll
+        for (int r = 0; r < RPW; r++) {
+            const float mean = s[r] * (1.0f / MST_D);
+            s2[r] = 0.f;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                xa[i] -= mean;
-                xb[i] -= mean;
-                s2 += xa[i] * xa[i] + xb[i] * xb[i];
+                xa[r][i] -= mean;
+                xb[r][i] -= mean;
+                s2[r] += xa[r][i] * xa[r][i] + xb[r][i] * xb[r][i];
             }
+        }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
-            const float rstd = 1.0f / sqrtf(s2 * (1.0f / MST_D) + 1e-5f);
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int r = 0; r < RPW; r++) s2[r] += __shfl_xor(s2[r], o);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + fa), gb = *reinterpret_cast<const f32x4*>(gamma + fb);
+        const f32x4 ea = *reinterpret_cast<const f32x4*>(beta + fa), eb = *reinterpret_cast<const f32x4*>(beta + fb);
+#pragma unroll
+        for (int r = 0; r < RPW; r++) {
+            const int tok = tok0 + wave * RPW + r;
             if (tok >= M) continue;
+            const float rstd = 1.0f / sqrtf(s2[r] * (1.0f / MST_D) + 1e-5f);
             f32x4 ya, yb;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                ya[i] = xa[i] * rstd * ga[i] + ea[i];
-                yb[i] = xb[i] * rstd * gb[i] + eb[i];
+                ya[i] = xa[r][i] * rstd * ga[i] + ea[i];
+                yb[i] = xb[r][i] * rstd * gb[i] + eb[i];
             }
             const size_t off = (size_t)tok * MST_D;
             *reinterpret_cast<f32x4*>(out32 + off + fa) = ya;
@@ -277,6 +310,7 @@ struct DEpiResidLN {
 // the CFG uncond half (identical frames, only the conditioning token differs).
 struct DEpiEmbedIn {
     const float* bias; const float* pe; float* out32; f16* out16; int T, S, total; size_t dup;
+    __device__ __forceinline__ int rows() const { return total; }
     template <int BT, int BF> static constexpr int smem_bytes() { return BT * (MST_D * 4 + 16); }
     template <int BT, int BF, int MT, int NT>
     __device__ __forceinline__ void run(f32x16 (&acc)[1][MT][NT], int tok0, int f0, char* smem) const {
@@ -327,79 +361,102 @@ struct DEpiEmbedIn {
     }
 };
 
-// K9 + K10/K10'/K11/K12 on the ring: output projection with the diffusion update in registers.
-// The lane owns a frame t, so every access to the [clip][feature][frame] tensors is 128 B
-// contiguous per half-wave.  MODE 0 model output only, 1 ancestral step, 2 DDIM step; NX = 2 is
-// the CFG doubled batch (group 0 = cond rows, group 1 = uncond rows of the same clips).
+// K9 + K10/K10'/K11/K12 on the ring: output projection with the diffusion update fused in.
+// Accumulators (lane = frame, registers = features; CFG halves blended first, model/cfg_sampler.py:43) are
+// transposed through LDS into [feature][frame] rows; then ALL 512 threads walk (feature, 4 consecutive
+// frames) items with float4 accesses to x_t / mask / motion / noise / outputs -- the [clip][feature][frame]
+// tensors are frame-contiguous, so a wave touches 256-B runs.  (First version: per-lane scalar gathers
+// straight from the accumulator layout, all work in 4-5 of the 8 waves: 36 us even at batch 16.)
+// MODE 0 model output only, 1 ancestral step, 2 DDIM step; NX = 2 is the CFG doubled batch.
 template <int MODE>
 struct DEpiEmbedOut {
     const float* bias; int F, T, total; float* out; StepArgs sa;
-    template <int BT, int BF> static constexpr int smem_bytes() { return 0; }
+    __device__ __forceinline__ int rows() const { return total; }
+    template <int BT, int BF> static constexpr int smem_bytes() { return BF * (BT + 4) * 4; }
+
+    __device__ __forceinline__ void one(const StepCoef& sc, float mo, size_t idx, float nz, bool blend, bool use_mask) const {
+        if (MODE == 0) { out[idx] = mo; return; }
+        const float mk = use_mask ? sa.mask[idx] : 0.f, mot = blend ? sa.motion[idx] : 0.f;
+        float pred;
+        const float nx = step_update<MODE == 2 ? 1 : 0>(sc, mo, sa.x[idx], nz, blend, mk, mot, sa.mask_noise && use_mask, sa.clip, &pred);
+        sa.sample[idx] = nx;
+        if (sa.xstart) sa.xstart[idx] = pred;
+    }
+
     template <int BT, int BF, int MT, int NT, int NX = 1>
-    __device__ __forceinline__ void run(f32x16 (&acc)[NX][MT][NT], int tok0, int f0, char*) const {
+    __device__ __forceinline__ void run(f32x16 (&acc)[NX][MT][NT], int tok0, int f0, char* smem) const {
+        constexpr int LDT = BT + 4;                          // floats per feature row of the tile
         DLane<BT, BF, MT, NT> lc;
-        StepCoef sc;
-        if (MODE != 0) sc = step_coef(sa.tab, sa.nsteps, sa.t, sa.eta);
-        const bool blend = sa.mask != nullptr && sa.motion != nullptr;
-        const bool use_mask = sa.mask != nullptr, use_noise = !sa.philox && sa.noise != nullptr;
+        float* tile = reinterpret_cast<float*>(smem);
 #pragma unroll
         for (int m = 0; m < MT; m++) {
-            int tok = tok0 + lc.tok(m);
-            const bool tok_ok = tok < total;
-            if (!tok_ok) tok = total - 1;
-            const int clip = tok / T, t = tok - clip * T;
+            const int tl = lc.tok(m), tok = tok0 + tl;
             float gs = 0.f;
-            if (NX == 2) gs = sa.scale[clip];
-            const size_t cbase = (size_t)clip * F * T + t;
+            if (NX == 2) gs = sa.scale[(tok < total ? tok : total - 1) / T];
 #pragma unroll
-            for (int n = 0; n < NT; n++) {
-                if (f0 + (lc.wn * NT + n) * 32 >= F) continue;        // wave-uniform: tile entirely in the padding
-                // ---- gather phase: every load of this 32x32 tile is issued before any is used
-                float xv[16], mk[16], mot[16], nzv[16], bv[16];
-                bool ok[16];
+            for (int n = 0; n < NT; n++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
-                    const int fi = f0 + lc.feat(n, r >> 2) + (r & 3);
-                    ok[r] = tok_ok && fi < F;
-                    const size_t idx = cbase + (size_t)(fi < F ? fi : F - 1) * T;
-                    bv[r] = bias[fi < F ? fi : F - 1];
-                    if (MODE != 0) {
-                        xv[r] = sa.x[idx];
-                        mk[r] = use_mask ? sa.mask[idx] : 0.f;
-                        mot[r] = blend ? sa.motion[idx] : 0.f;
-                        nzv[r] = use_noise ? sa.noise[idx] : 0.f;
-                    }
+                    const int f = f0 + lc.feat(n, r >> 2) + (r & 3);
+                    float v = acc[0][m][n][r];
+                    if (NX == 2) { const float u = acc[NX - 1][m][n][r]; v = u + gs * (v - u); }
+                    if (f < F) tile[f * LDT + tl] = v;
                 }
-                if (MODE != 0 && sa.philox) {
+        }
+        __syncthreads();
+        StepCoef sc;
+        if (MODE != 0) sc = step_coef(sa.tab, sa.nsteps, sa.t, sa.eta);
+        const bool blend = sa.mask != nullptr && sa.motion != nullptr, use_mask = sa.mask != nullptr;
+        const bool use_noise = !sa.philox && sa.noise != nullptr;
+        const bool vec = (T & 3) == 0;                       // 4 consecutive frames never straddle a clip
+        constexpr int TG = BT / 4;
+        for (int it = threadIdx.x; it < F * TG; it += 512) {
+            const int f = it / TG, tg = it - f * TG;
+            const int tok = tok0 + tg * 4;
+            if (tok >= total) continue;
+            const f32x4 acc4 = *reinterpret_cast<const f32x4*>(tile + f * LDT + tg * 4);
+            const float b = bias[f];
+            if (vec) {
+                const int clip = tok / T, t = tok - clip * T;
+                const size_t idx = ((size_t)clip * F + f) * T + t;
+                f32x4 mo;
 #pragma unroll
-                    for (int g = 0; g < 4; g++) {
+                for (int j = 0; j < 4; j++) mo[j] = acc4[j] + b;
+                if (MODE == 0) { *reinterpret_cast<f32x4*>(out + idx) = mo; continue; }
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(sa.x + idx);
+                f32x4 mk = {0.f, 0.f, 0.f, 0.f}, mot = mk, nz = mk;
+                if (use_mask) mk = *reinterpret_cast<const f32x4*>(sa.mask + idx);
+                if (blend) mot = *reinterpret_cast<const f32x4*>(sa.motion + idx);
+                if (use_noise) nz = *reinterpret_cast<const f32x4*>(sa.noise + idx);
+                if (sa.philox) {
+                    float nrm[4];
+                    philox_normal4((unsigned)(t >> 2), (unsigned)f, (unsigned)clip, sa.step, sa.seed, nrm);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) nz[j] = nrm[j];
+                }
+                f32x4 nx, pred;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    float p;
+                    nx[j] = step_update<MODE == 2 ? 1 : 0>(sc, mo[j], xv[j], nz[j], blend, mk[j], mot[j], sa.mask_noise && use_mask, sa.clip, &p);
+                    pred[j] = p;
+                }
+                *reinterpret_cast<f32x4*>(sa.sample + idx) = nx;
+                if (sa.xstart) *reinterpret_cast<f32x4*>(sa.xstart + idx) = pred;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int tk = tok + j;
+                    if (tk >= total) break;
+                    const int clip = tk / T, t = tk - clip * T;
+                    const size_t idx = ((size_t)clip * F + f) * T + t;
+                    float nz = use_noise ? sa.noise[idx] : 0.f;
+                    if (MODE != 0 && sa.philox) {
                         float nrm[4];
-                        philox_normal4((unsigned)t, (unsigned)((f0 + lc.feat(n, g)) >> 2), (unsigned)clip, sa.step, sa.seed, nrm);
-#pragma unroll
-                        for (int i = 0; i < 4; i++) nzv[4 * g + i] = nrm[i];
+                        philox_normal4((unsigned)(t >> 2), (unsigned)f, (unsigned)clip, sa.step, sa.seed, nrm);
+                        nz = nrm[t & 3];
                     }
-                }
-                // ---- update + store phase
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int fi = f0 + lc.feat(n, r >> 2) + (r & 3);
-                    float mo = acc[0][m][n][r] + bv[r];
-                    if (NX == 2) {                       // model/cfg_sampler.py:43
-                        float un = acc[NX - 1][m][n][r] + bv[r];
-                        mo = un + gs * (mo - un);
-                    }
-                    const size_t idx = cbase + (size_t)fi * T;
-                    if (MODE == 0) {
-                        if (ok[r]) out[idx] = mo;
-                    } else {
-                        float pred;
-                        const float nx = step_update<MODE == 2 ? 1 : 0>(sc, mo, xv[r], nzv[r], blend, mk[r], mot[r],
-                                                                       sa.mask_noise && use_mask, sa.clip, &pred);
-                        if (ok[r]) {
-                            sa.sample[idx] = nx;
-                            if (sa.xstart) sa.xstart[idx] = pred;
-                        }
-                    }
+                    one(sc, acc4[j] + b, idx, nz, blend, use_mask);
                 }
             }
         }
@@ -407,11 +464,21 @@ struct DEpiEmbedOut {
 };
 
 template <int BT, int BF, int MT, int NT, int NS, int NX, class SRC, class EPI>
-__global__ __launch_bounds__(512) void k_gemm_dma(SRC xs, const f16* __restrict__ W, int ldw, int K, EPI epi) {
+__global__ __launch_bounds__(512) void k_gemm_dma(SRC xs, const f16* __restrict__ W, int ldw, int K, int xcd_ny, EPI epi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using TL = DTile<BT, BF, MT, NT, NS, NX>;
-    const int tok0 = blockIdx.x * BT;
-    const int f0 = blockIdx.y * BF;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (xcd_ny > 0) {
+        // XCD-aware order (1-D launch over ceil(nx/8)*8*ny ids): workgroups are dealt round-robin over the
+        // 8 XCDs, so give every feature tile of one token tile the same id % 8: the token rows are then
+        // fetched into ONE XCD's L2 instead of up to ny of them.  Speed only, never correctness.
+        const int ny = xcd_ny, id = blockIdx.x, xcd = id & 7, s = id >> 3;
+        bx = (s / ny) * 8 + xcd;
+        by = s % ny;
+        if (bx * BT >= epi.rows()) return;                        // padding ids of the last group of 8 token tiles
+    }
+    const int tok0 = bx * BT;
+    const int f0 = by * BF;
     f32x16 acc[NX][MT][NT];
 #pragma unroll
     for (int x = 0; x < NX; x++)
