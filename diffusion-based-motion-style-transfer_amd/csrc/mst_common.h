@@ -149,6 +149,6 @@ struct StepArgs {
     const float* scale;                           // [B] guidance scale (cfg)
     const float* x;                               // x_t
     float* sample; float* xstart;                 // outputs (xstart may be null)
-    unsigned long long seed; unsigned step;
+    unsigned long long seed; unsigned step; unsigned clip0;   // clip0: batch index of the slice's first clip (Philox counter)
     int mask_noise, clip, philox;
 };

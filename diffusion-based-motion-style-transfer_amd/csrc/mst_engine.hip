@@ -3,6 +3,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -95,6 +96,9 @@ struct mst_engine {
     std::vector<std::string> loaded;
     int text_batch = 0, text_cfg = 0;
     int dbg_layer = -1, dbg_stage = -1;   // stop the trunk after (layer, stage); -1 = run everything
+    int nsplit = 2;                       // sampling loops run the batch as this many independent slices on separate streams
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // profiling
     int prof_on = 0, prof_now = 0, prof_period = 16;
     std::vector<ProfPoint> prof_pts;
@@ -191,6 +195,10 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     CHECK(dmalloc(&e->temb_hid, (size_t)e->temb_cap * MST_D));
     CHECK(dmalloc(&e->temb, (size_t)e->temb_cap * MST_D));
     CHECK(dmalloc(&e->textproj, (size_t)c->max_rows * MST_D));
+    HIPCHECK(hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking));
+    HIPCHECK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    if (const char* v = getenv("MST_STREAMS")) e->nsplit = atoi(v) >= 2 ? 2 : 1;
     *out = e;
     return 0;
 }
@@ -205,6 +213,9 @@ extern "C" void mst_engine_destroy(mst_engine* e) {
     void* p[] = {e->w_pose_in, e->b_pose_in, e->w_pose_out, e->b_pose_out, e->w_t0, e->b_t0, e->w_t2, e->b_t2,
                  e->w_text, e->b_text, e->pe, e->hs, e->hx, e->qkv, e->att, e->hid, e->xt, e->temb_hid, e->temb, e->textproj};
     for (void* q : p) (void)hipFree(q);
+    if (e->aux_stream) (void)hipStreamDestroy(e->aux_stream);
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     for (auto& pp : e->prof_pts) {
         (void)hipEventDestroy(pp.a);
         (void)hipEventDestroy(pp.b);
@@ -427,14 +438,25 @@ extern "C" int mst_set_text(mst_engine* e, const float* text_emb, const float* k
     return 0;
 }
 
+// A slice of the workspace: clips [r0, r0 + n) of the batch get their own rows of every buffer, so slices can
+// run concurrently on different streams (tiles may over-READ into a neighbour's rows; they never write them).
+struct WS {
+    float* hs; f16 *hx, *qkv, *att, *hid, *xt; float* textproj;
+};
+static WS ws_slice(const mst_engine* e, int r0, int T) {
+    const size_t row = (size_t)r0 * (T + 1);
+    return WS{e->hs + row * MST_D, e->hx + row * MST_D, e->qkv + row * 3 * MST_D, e->att + row * MST_D, e->hid + row * MST_FF,
+              e->xt + (size_t)r0 * T * e->kin_pad, e->textproj + (size_t)r0 * MST_D};
+}
+
 // K3 .. K8: token stream through the encoder stack.  rows = clips through the transformer.
-static int run_trunk(mst_engine* e, const float* x, int clips_x, int rows, int T, int temb_uniform_row, int temb_mod,
+static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, int rows, int T, int temb_uniform_row, int temb_mod,
                      hipStream_t st) {
     const int S = T + 1, M = rows * S;
     {
         ProfScope ps(e, FAM_COND, st);
         hipLaunchKernelGGL(k_cond_token, dim3((rows * MST_D + 255) / 256), dim3(256), 0, st, e->temb, temb_uniform_row,
-                           temb_mod, e->textproj, e->pe, S, rows, e->hs, e->hx);
+                           temb_mod, ws.textproj, e->pe, S, rows, ws.hs, ws.hx);
         HIPCHECK(hipGetLastError());
     }
     {
@@ -442,10 +464,10 @@ static int run_trunk(mst_engine* e, const float* x, int clips_x, int rows, int T
         // CFG batch feeds the same x to both halves: embed once, store twice (dup).
         ProfScope ps(e, FAM_EMBED_IN, st);
         const int F = e->cfg.feats, tot = clips_x * T;
-        hipLaunchKernelGGL(k_frames_f16, dim3((T + 31) / 32, e->kin_pad / 32, clips_x), dim3(256), 0, st, x, F, T, e->kin_pad, e->xt);
+        hipLaunchKernelGGL(k_frames_f16, dim3((T + 31) / 32, e->kin_pad / 32, clips_x), dim3(256), 0, st, x, F, T, e->kin_pad, ws.xt);
         HIPCHECK(hipGetLastError());
-        DEpiEmbedIn epi{e->b_pose_in, e->pe, e->hs, e->hx, T, S, tot, rows > clips_x ? (size_t)clips_x * S * MST_D : 0};
-        CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1>(dim3((tot + 63) / 64, 1), RowsDirect{e->xt, e->kin_pad}, e->w_pose_in, e->kin_pad,
+        DEpiEmbedIn epi{e->b_pose_in, e->pe, ws.hs, ws.hx, T, S, tot, rows > clips_x ? (size_t)clips_x * S * MST_D : 0};
+        CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1>(dim3((tot + 63) / 64, 1), RowsDirect{ws.xt, e->kin_pad}, e->w_pose_in, e->kin_pad,
                                                    e->kin_pad, epi, st)));
     }
     if (e->dbg_stage == 0) return 0;
@@ -454,31 +476,31 @@ static int run_trunk(mst_engine* e, const float* x, int clips_x, int rows, int T
         const LayerW& w = e->L[l];
         {
             ProfScope ps(e, FAM_QKV, st);
-            DEpiBiasF16<false> epi{w.b_in, e->qkv, 3 * MST_D, M};
-            CHECK((launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, 3 * MST_D / 256), RowsDirect{e->hx, MST_D}, w.w_in, MST_D, MST_D, epi, st, WIDE_XCD ? 3 * MST_D / 256 : 0)));
+            DEpiBiasF16<false> epi{w.b_in, ws.qkv, 3 * MST_D, M};
+            CHECK((launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, 3 * MST_D / 256), RowsDirect{ws.hx, MST_D}, w.w_in, MST_D, MST_D, epi, st, WIDE_XCD ? 3 * MST_D / 256 : 0)));
         }
         DBG_STOP(1)
         {
             ProfScope ps(e, FAM_ATTN, st);
-            CHECK(launch_attn(e->qkv, e->att, S, rows, st));
+            CHECK(launch_attn(ws.qkv, ws.att, S, rows, st));
         }
         DBG_STOP(2)
         {
             ProfScope ps(e, FAM_OUTPROJ_LN, st);
-            DEpiResidLN epi{w.b_out, e->hs, w.g1, w.be1, e->hs, e->hx, M};
-            CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1>(dim3((M + 63) / 64, 1), RowsDirect{e->att, MST_D}, w.w_out, MST_D, ABL_K(MST_D), epi, st)));
+            DEpiResidLN epi{w.b_out, ws.hs, w.g1, w.be1, ws.hs, ws.hx, M};
+            CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1>(dim3((M + 63) / 64, 1), RowsDirect{ws.att, MST_D}, w.w_out, MST_D, ABL_K(MST_D), epi, st)));
         }
         DBG_STOP(3)
         {
             ProfScope ps(e, FAM_FFN1, st);
-            DEpiBiasF16<true> epi{w.b1, e->hid, MST_FF, M};
-            CHECK((launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, MST_FF / 256), RowsDirect{e->hx, MST_D}, w.w1, MST_D, MST_D, epi, st, WIDE_XCD ? MST_FF / 256 : 0)));
+            DEpiBiasF16<true> epi{w.b1, ws.hid, MST_FF, M};
+            CHECK((launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, MST_FF / 256), RowsDirect{ws.hx, MST_D}, w.w1, MST_D, MST_D, epi, st, WIDE_XCD ? MST_FF / 256 : 0)));
         }
         DBG_STOP(4)
         {
             ProfScope ps(e, FAM_FFN2_LN, st);
-            DEpiResidLN epi{w.b2, e->hs, w.g2, w.be2, e->hs, e->hx, M};
-            CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1>(dim3((M + 63) / 64, 1), RowsDirect{e->hid, MST_FF}, w.w2, MST_FF, ABL_K(MST_FF), epi, st)));
+            DEpiResidLN epi{w.b2, ws.hs, w.g2, w.be2, ws.hs, ws.hx, M};
+            CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1>(dim3((M + 63) / 64, 1), RowsDirect{ws.hid, MST_FF}, w.w2, MST_FF, ABL_K(MST_FF), epi, st)));
         }
         DBG_STOP(5)
     }
@@ -488,22 +510,22 @@ static int run_trunk(mst_engine* e, const float* x, int clips_x, int rows, int T
 
 // output projection tiles: 64 frames x (256 * NTO) features, 8 waves as 1 x 8 with 2 x NTO MFMA tiles each
 template <int MODE, int NTO, int NX>
-static int launch_out(mst_engine* e, int batch, int T, float* out, const StepArgs& sa, hipStream_t st) {
+static int launch_out(mst_engine* e, const WS& ws, int batch, int T, float* out, const StepArgs& sa, hipStream_t st) {
     const int S = T + 1;
-    RowsFrames xs{e->hx, MST_D, T, S, batch * T, 64, (size_t)batch * S};
+    RowsFrames xs{ws.hx, MST_D, T, S, batch * T, 64, (size_t)batch * S};
     DEpiEmbedOut<MODE> epi{e->b_pose_out, e->cfg.feats, T, batch * T, out, sa};
     return launch_gemm_dma<64, 256 * NTO, 2, NTO, 4, NX>(dim3((batch * T + 63) / 64, 1), xs, e->w_pose_out, MST_D, MST_D, epi, st);
 }
 template <int MODE, int NTO>
-static int launch_out_nx(mst_engine* e, int cfg, int batch, int T, float* out, const StepArgs& sa, hipStream_t st) {
-    return cfg ? launch_out<MODE, NTO, 2>(e, batch, T, out, sa, st) : launch_out<MODE, NTO, 1>(e, batch, T, out, sa, st);
+static int launch_out_nx(mst_engine* e, const WS& ws, int cfg, int batch, int T, float* out, const StepArgs& sa, hipStream_t st) {
+    return cfg ? launch_out<MODE, NTO, 2>(e, ws, batch, T, out, sa, st) : launch_out<MODE, NTO, 1>(e, ws, batch, T, out, sa, st);
 }
 template <int MODE>
-static int launch_out_nt(mst_engine* e, int cfg, int batch, int T, float* out, const StepArgs& sa, hipStream_t st) {
+static int launch_out_nt(mst_engine* e, const WS& ws, int cfg, int batch, int T, float* out, const StepArgs& sa, hipStream_t st) {
     ProfScope ps(e, FAM_EMBED_OUT, st);
     switch (e->nt_out) {
-        case 1: return launch_out_nx<MODE, 1>(e, cfg, batch, T, out, sa, st);
-        case 2: return launch_out_nx<MODE, 2>(e, cfg, batch, T, out, sa, st);
+        case 1: return launch_out_nx<MODE, 1>(e, ws, cfg, batch, T, out, sa, st);
+        case 2: return launch_out_nx<MODE, 2>(e, ws, cfg, batch, T, out, sa, st);
     }
     return fail("output projection: feats %d unsupported", e->cfg.feats);
 }
@@ -528,10 +550,15 @@ extern "C" int mst_forward(mst_engine* e, const float* x, const int64_t* t, cons
     e->prof_now = e->prof_on;
     CHECK(timestep_rows(e, (const long long*)t, batch, st));
     const int rows = cfg ? 2 * batch : batch;
-    CHECK(run_trunk(e, x, batch, rows, frames, -1, batch, st));
+    const WS ws = ws_slice(e, 0, frames);
+    CHECK(run_trunk(e, ws, x, batch, rows, frames, -1, batch, st));
     StepArgs sa{};
     sa.scale = scale;
-    return launch_out_nt<0>(e, cfg, batch, frames, out, sa, st);
+    return launch_out_nt<0>(e, ws, cfg, batch, frames, out, sa, st);
+}
+
+extern "C" int mst_loop_slices(const mst_engine* e, int32_t batch, int32_t cfg) {
+    return (e && e->nsplit >= 2 && !cfg && batch >= 16 && e->dbg_stage < 0) ? 2 : 1;
 }
 
 extern "C" int mst_sample_loop(mst_engine* e, const mst_schedule* s, const mst_loop_args* a, void* stream) {
@@ -550,29 +577,61 @@ extern "C" int mst_sample_loop(mst_engine* e, const mst_schedule* s, const mst_l
     // K1 hoisted: the timestep MLP for every index this loop visits (row j <-> index t_end + j)
     e->prof_now = 0;
     CHECK(timestep_rows(e, s->tmap + a->t_end, nrun, st));
+    // Clips are independent, so the batch runs as `nsplit` slices on separate streams: one slice's kernels fill
+    // the CUs the other leaves idle in its prologues, tails and launch gaps (per-launch time is per-CU bound and
+    // flat in the block count at this size).  CFG already has 2x the rows and stays one slice.
+    const int nsl = mst_loop_slices(e, a->batch, a->cfg);
+    const size_t per_clip = (size_t)e->cfg.feats * a->frames;
+    hipStream_t streams[2] = {st, e->aux_stream};
+    bool forked = false;
     for (int j = 0; j < nrun; j++) {
         const int ti = a->t_start - j;
         e->prof_now = e->prof_on && (j % e->prof_period == 0);
-        CHECK(run_trunk(e, a->x_dev, a->batch, rows, a->frames, ti - a->t_end, 0, st));
-        StepArgs sa{};
-        sa.tab = s->tab;
-        sa.nsteps = s->n;
-        sa.t = ti;
-        sa.eta = a->eta;
-        sa.mask = a->inpainting_mask_dev;
-        sa.motion = a->inpainted_motion_dev;
-        sa.noise = a->noise_mode == MST_NOISE_BUFFER ? a->noise_dev + (size_t)j * clip_elems : nullptr;
-        sa.scale = a->scale_dev;
-        sa.x = a->x_dev;
-        sa.sample = a->x_dev;
-        sa.xstart = a->xstart_dump_dev ? a->xstart_dump_dev + (size_t)j * clip_elems : nullptr;
-        sa.seed = a->seed;
-        sa.step = (unsigned)j;
-        sa.mask_noise = a->mask_noise;
-        sa.clip = a->clip_denoised;
-        sa.philox = a->noise_mode == MST_NOISE_PHILOX;
-        if (a->sampler == MST_SAMPLER_DDPM) CHECK(launch_out_nt<1>(e, a->cfg, a->batch, a->frames, nullptr, sa, st));
-        else CHECK(launch_out_nt<2>(e, a->cfg, a->batch, a->frames, nullptr, sa, st));
+        // instrumented steps run as ONE full-batch slice so the HIP-event durations are those of isolated
+        // full-batch launches (the roofline figures); all other steps use the concurrent slices
+        const int nsj = e->prof_now ? 1 : nsl;
+        if (nsj == 2 && !forked) {
+            HIPCHECK(hipEventRecord(e->ev_fork, st));
+            HIPCHECK(hipStreamWaitEvent(e->aux_stream, e->ev_fork, 0));
+            forked = true;
+        } else if (nsj == 1 && forked) {
+            HIPCHECK(hipEventRecord(e->ev_join, e->aux_stream));
+            HIPCHECK(hipStreamWaitEvent(st, e->ev_join, 0));
+            forked = false;
+        }
+        for (int sl = 0; sl < nsj; sl++) {
+            const int half = (a->batch + 1) / 2;
+            const int c0 = sl == 0 ? 0 : half;
+            const int nb = nsj == 1 ? a->batch : (sl == 0 ? half : a->batch - half);
+            const size_t eo = (size_t)c0 * per_clip;
+            const WS ws = ws_slice(e, c0, a->frames);
+            hipStream_t ss = streams[sl];
+            CHECK(run_trunk(e, ws, a->x_dev + eo, nb, a->cfg ? 2 * nb : nb, a->frames, ti - a->t_end, 0, ss));
+            StepArgs sa{};
+            sa.tab = s->tab;
+            sa.nsteps = s->n;
+            sa.t = ti;
+            sa.eta = a->eta;
+            sa.mask = a->inpainting_mask_dev ? a->inpainting_mask_dev + eo : nullptr;
+            sa.motion = a->inpainted_motion_dev ? a->inpainted_motion_dev + eo : nullptr;
+            sa.noise = a->noise_mode == MST_NOISE_BUFFER ? a->noise_dev + (size_t)j * clip_elems + eo : nullptr;
+            sa.scale = a->scale_dev;
+            sa.x = a->x_dev + eo;
+            sa.sample = a->x_dev + eo;
+            sa.xstart = a->xstart_dump_dev ? a->xstart_dump_dev + (size_t)j * clip_elems + eo : nullptr;
+            sa.seed = a->seed;
+            sa.step = (unsigned)j;
+            sa.clip0 = (unsigned)c0;
+            sa.mask_noise = a->mask_noise;
+            sa.clip = a->clip_denoised;
+            sa.philox = a->noise_mode == MST_NOISE_PHILOX;
+            if (a->sampler == MST_SAMPLER_DDPM) CHECK(launch_out_nt<1>(e, ws, a->cfg, nb, a->frames, nullptr, sa, ss));
+            else CHECK(launch_out_nt<2>(e, ws, a->cfg, nb, a->frames, nullptr, sa, ss));
+        }
+    }
+    if (forked) {
+        HIPCHECK(hipEventRecord(e->ev_join, e->aux_stream));
+        HIPCHECK(hipStreamWaitEvent(st, e->ev_join, 0));
     }
     e->prof_now = 0;
     return 0;

@@ -430,7 +430,7 @@ struct DEpiEmbedOut {
                 if (use_noise) nz = *reinterpret_cast<const f32x4*>(sa.noise + idx);
                 if (sa.philox) {
                     float nrm[4];
-                    philox_normal4((unsigned)(t >> 2), (unsigned)f, (unsigned)clip, sa.step, sa.seed, nrm);
+                    philox_normal4((unsigned)(t >> 2), (unsigned)f, (unsigned)clip + sa.clip0, sa.step, sa.seed, nrm);
 #pragma unroll
                     for (int j = 0; j < 4; j++) nz[j] = nrm[j];
                 }
@@ -453,7 +453,7 @@ struct DEpiEmbedOut {
                     float nz = use_noise ? sa.noise[idx] : 0.f;
                     if (MODE != 0 && sa.philox) {
                         float nrm[4];
-                        philox_normal4((unsigned)(t >> 2), (unsigned)f, (unsigned)clip, sa.step, sa.seed, nrm);
+                        philox_normal4((unsigned)(t >> 2), (unsigned)f, (unsigned)clip + sa.clip0, sa.step, sa.seed, nrm);
                         nz = nrm[t & 3];
                     }
                     one(sc, acc4[j] + b, idx, nz, blend, use_mask);
