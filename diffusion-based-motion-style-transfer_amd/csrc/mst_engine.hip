@@ -156,7 +156,8 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     e->S_max = c->max_frames + 1;
     size_t M = (size_t)c->max_rows * e->S_max;
     e->M_pad = (int)(((M + 255) / 256) * 256);
-    e->kin_pad = ((c->feats + 63) / 64) * 64;
+    e->kin_pad = ((c->feats + 31) / 32) * 32;           // K of the pose-embedding GEMM: whole 32-deep slabs,
+    if (e->kin_pad < 96) e->kin_pad = 96;               // and at least the 3 slabs the ring keeps in flight
     e->nt_out = (c->feats + 255) / 256;              // output-projection tile = 256 * nt_out features
     e->fout_pad = e->nt_out * 256;
     for (int l = 0; l < c->num_layers; l++) {
