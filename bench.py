@@ -47,6 +47,7 @@ def flops_per_launch(family, rows, T, F, kin_pad):
         "embed_in": 2.0 * rows * T * D * F,
         "embed_out_step": 2.0 * rows * T * F * D,
         "cond_token": 0.0,
+        "qkv_attention_fused": 2.0 * M * 3 * D * D + 2.0 * 2 * rows * H * S * S * (D // H),
     }[family]
 
 
@@ -135,8 +136,8 @@ def main():
         dom = max(fam_tot, key=fam_tot.get)
         fl = flops_per_launch(dom, rows, T, F, 320)
         achieved = fl / (fam_ms[dom] * 1e-3) / 1e12 if fam_ms[dom] > 0 else 0.0
-        total_flops_step = sum(flops_per_launch(k, rows, T, F, 320) * (8 if k in ("qkv_gemm", "attention", "outproj_ln_gemm", "ffn1_gelu_gemm", "ffn2_ln_gemm") else 1)
-                                        for k in fam_tot)
+        # whole path: 7.353 GFLOP per clip per denoise step (14.706 with CFG), SURVEY.md section 8d
+        flops_per_clip = 7.353e9 * NS * (2 if args.cfg else 1)
         line = {
             "metric": "denoised motion clips/sec (1000-step DDPM, Bx263x196)",
             "value": round(value, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -150,7 +151,7 @@ def main():
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
                          "avg_launch_us": round(1e3 * fam_ms[dom], 2), "launches_timed": prof[dom][1],
                          "clips_per_timed_launch": rows, "concurrent_slices_elsewhere": slices,
-                         "whole_step_tflops": round(total_flops_step * NS * args.steps * 1e-12 / dt, 2),
+                         "whole_path_tflops": round(value * flops_per_clip * 1e-12, 2),
                          "kernel_avg_us": {k: round(1e3 * v, 2) for k, v in fam_ms.items()}},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -12,6 +12,7 @@
 // scalar, and the output store is 8 bytes per lane (4 consecutive d of one query).
 #pragma once
 #include "mst_common.h"
+#include "mst_gemm_dma.h"   // ring_off, dma_issue, wait_vmcnt
 
 namespace mst {
 
@@ -137,6 +138,211 @@ __global__ __launch_bounds__(512) void k_attention(const f16* __restrict__ qkv, 
                 o = mfma_f16(vf, pf[kt][s2], o);
             }
         if (q_idx < S) {
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                int dd = dt * 32 + 8 * gq + 4 * hh;
+                *reinterpret_cast<uint2*>(orow + dd) =
+                    pack4_f16(o[4 * gq] * inv_l, o[4 * gq + 1] * inv_l, o[4 * gq + 2] * inv_l, o[4 * gq + 3] * inv_l);
+            }
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// K4 + K5 fused: QKV projection of ONE head + attention, one workgroup per (clip, head).
+//
+// Why: as separate kernels the f16 `qkv` tensor (38.7 MB at batch 64) is written by one launch and read back by
+// the next, and the QKV GEMM restages every weight tile once per 128-token block (228 MB of L2->LDS traffic per
+// layer, the per-CU DMA rate being what bounds these loops).  Here a workgroup streams its head's 384 weight rows
+// (q|k|v x 128) and the clip's S token rows through the DMA ring once (581 KB), wave w accumulating token tile w
+// against all 12 feature tiles; then
+//   * Q never leaves registers: the accumulator layout (lane = token, registers = features) IS the B-operand
+//     fragment of St = K.Q^T in the permuted k order slot(hh, j) <-> d = 16 ks + 8 (j >> 2) + 4 hh + (j & 3)
+//     (cdna guide section 3, "accumulator tile as the next MFMA's operand");
+//   * K is written to its LDS image with the 4-element groups of every 16-d run swapped the same way, so the
+//     A-operand read stays ONE ds_read_b128 at the usual chunk 2 ks + hh;
+//   * V is written in natural order into the transposed-read image.
+// The attention core that follows is k_attention's.  `qkv` is not materialised at all.
+// ------------------------------------------------------------------------------------------------------------
+template <int NKT>
+struct QATile {
+    static constexpr int XR = NKT * 32;                 // token rows staged per slab
+    static constexpr int WR = 3 * MST_HD;               // 384 weight rows: q | k | v of this head
+    static constexpr int ROWS = XR + WR;
+    static constexpr int STAGE = ROWS * 64;
+    static constexpr int NSTAGE = 3;
+    static constexpr int INSTR = ROWS / 16;
+    static constexpr int PER = (INSTR + 7) / 8;
+    static constexpr int RING = NSTAGE * STAGE;
+    static constexpr int KV = NKT * 32 * 256 * 2;       // K and V images afterwards (reuse the ring)
+    static constexpr int SMEM = RING > KV ? RING : KV;
+};
+
+template <int NKT>
+__global__ __launch_bounds__(512) void k_qkv_attention(const f16* __restrict__ hx, const f16* __restrict__ w_in,
+                                                       const float* __restrict__ b_in, f16* __restrict__ out, int S) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using TL = QATile<NKT>;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int clip = blockIdx.x / MST_H, head = blockIdx.x % MST_H;
+    const int hh = lane >> 5, l31 = lane & 31;
+    const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const f16* xbase = hx + (size_t)clip * S * MST_D;
+
+    // ---- per-lane DMA sources: tile rows [0, XR) = tokens (clamped), [XR, XR+384) = q|k|v weight rows of the head
+    const char* src[TL::PER];
+    unsigned dst[TL::PER];
+#pragma unroll
+    for (int j = 0; j < TL::PER; j++) {
+        int i = wave + 8 * j;
+        if (i >= TL::INSTR) i -= 8 * (TL::PER - 1);
+        int row = i * 16 + (lane >> 2);
+        int c = (lane & 3) ^ ((row >> 2) & 3);
+        const f16* g;
+        if (row < TL::XR) {
+            g = xbase + (size_t)(row < S ? row : S - 1) * MST_D;
+        } else {
+            int r = row - TL::XR;
+            g = w_in + (size_t)((r >> 7) * MST_D + head * MST_HD + (r & 127)) * MST_D;
+        }
+        src[j] = reinterpret_cast<const char*>(g + c * 8);
+        dst[j] = i * 1024;
+    }
+    f32x16 acc[12];
+#pragma unroll
+    for (int n = 0; n < 12; n++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[n][r] = 0.f;
+
+    constexpr int KT = MST_D / 32, AHEAD = TL::NSTAGE - 1;
+#pragma unroll
+    for (int s = 0; s < AHEAD; s++) dma_issue<TL>(src, dst, smem_base, s);
+    const bool active = wave < NKT;
+    for (int kt = 0; kt < KT; kt++) {
+        if (KT - 1 - kt >= AHEAD - 1) wait_vmcnt<(AHEAD - 1) * TL::PER>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + AHEAD < KT) dma_issue<TL>(src, dst, smem_base, kt + AHEAD);
+        if (active) {
+            const char* st = smem + (kt % TL::NSTAGE) * TL::STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const int c = ks * 2 + hh;
+                const f16x8 xf = *reinterpret_cast<const f16x8*>(st + ring_off(wave * 32 + l31, c));
+#pragma unroll
+                for (int n = 0; n < 12; n++) {
+                    const f16x8 wf = *reinterpret_cast<const f16x8*>(st + ring_off(TL::XR + n * 32 + l31, c));
+                    acc[n] = mfma_f16(wf, xf, acc[n]);
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_s_barrier();                       // ring dead: reuse it for the K / V images
+
+    char* ks_img = smem;
+    char* vs_img = smem + NKT * 32 * 256;
+    f16x8 qf[8];
+    const int tok = wave * 32 + l31;                    // this lane's token = query = key row
+    if (active) {
+        const float scale = 0.08838834764831845f;       // 1/sqrt(128), applied to q in fp32 before rounding
+        const float* bq = b_in + head * MST_HD;
+        const float* bk = b_in + MST_D + head * MST_HD;
+        const float* bv = b_in + 2 * MST_D + head * MST_HD;
+#pragma unroll
+        for (int n = 0; n < 4; n++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int d = n * 32 + 8 * g + 4 * hh;  // 4 consecutive d of this head held in registers 4g..4g+3
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bq + d);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(bk + d);
+                const f32x4 b2 = *reinterpret_cast<const f32x4*>(bv + d);
+                // Q fragment: k-step 2n + (g >> 1), elements 4 (g & 1) .. +3
+#pragma unroll
+                for (int i = 0; i < 4; i++) qf[2 * n + (g >> 1)][4 * (g & 1) + i] = (f16)((acc[n][4 * g + i] + b0[i]) * scale);
+                // K image: column = 32 n + 16 (g >> 1) + 8 hh + 4 (g & 1)  (the 4-groups of each 16-d run swapped)
+                const int kcol = n * 32 + 16 * (g >> 1) + 8 * hh + 4 * (g & 1);
+                *reinterpret_cast<uint2*>(ks_img + k_off(tok, kcol >> 3) + (kcol & 7) * 2) =
+                    pack4_f16(acc[4 + n][4 * g] + b1[0], acc[4 + n][4 * g + 1] + b1[1], acc[4 + n][4 * g + 2] + b1[2], acc[4 + n][4 * g + 3] + b1[3]);
+                // V image: natural order; key rows beyond S must be zero (P = 0 there, never 0 * garbage)
+                uint2 vv = pack4_f16(acc[8 + n][4 * g] + b2[0], acc[8 + n][4 * g + 1] + b2[1], acc[8 + n][4 * g + 2] + b2[2], acc[8 + n][4 * g + 3] + b2[3]);
+                if (tok >= S) vv = make_uint2(0u, 0u);
+                *reinterpret_cast<uint2*>(vs_img + v_off(tok, d)) = vv;
+            }
+    }
+    __syncthreads();
+    if (!active) return;
+
+    // ---- attention core (as k_attention, Q already in registers)
+    f32x16 sc[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; kt++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) sc[kt][r] = 0.f;
+        const int row = kt * 32 + l31;
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            f16x8 kf = *reinterpret_cast<const f16x8*>(ks_img + k_off(row, 2 * s + hh));
+            sc[kt] = mfma_f16(kf, qf[s], sc[kt]);
+        }
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; kt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float v = sc[kt][r];
+            if (kt == NKT - 1) {
+                int key = kt * 32 + mfma_row(r, lane);
+                if (key >= S) v = -INFINITY;
+            }
+            sc[kt][r] = v;
+            m = fmaxf(m, v);
+        }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; kt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float p = __expf(sc[kt][r] - m);
+            sc[kt][r] = p;
+            l += p;
+        }
+    l += __shfl_xor(l, 32);
+    const float inv_l = 1.0f / l;
+    f16x8 pf[NKT][2];
+#pragma unroll
+    for (int kt = 0; kt < NKT; kt++)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) pf[kt][s2][j] = (f16)sc[kt][8 * s2 + j];
+
+    const int i16 = lane & 15, g16 = lane >> 4;
+    const int key_lane = 4 * hh + (i16 >> 2);
+    const int d_lane = 16 * (g16 & 1) + 4 * (i16 & 3);
+    const int q_ld = tok < S ? tok : S - 1;
+    f16* orow = out + ((size_t)clip * S + q_ld) * MST_D + head * MST_HD;
+#pragma unroll
+    for (int dt = 0; dt < 4; dt++) {
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; kt++)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) {
+                int key = kt * 32 + 16 * s2 + key_lane;
+                int d = dt * 32 + d_lane;
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vs_img + v_off(key, d)));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vs_img + v_off(key + 8, d)));
+                const f16x4 lo_h = __builtin_bit_cast(f16x4, lo), hi_h = __builtin_bit_cast(f16x4, hi);
+                f16x8 vf = __builtin_shufflevector(lo_h, hi_h, 0, 1, 2, 3, 4, 5, 6, 7);
+                o = mfma_f16(vf, pf[kt][s2], o);
+            }
+        if (tok < S) {
 #pragma unroll
             for (int gq = 0; gq < 4; gq++) {
                 int dd = dt * 32 + 8 * gq + 4 * hh;

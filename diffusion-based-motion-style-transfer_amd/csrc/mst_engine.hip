@@ -74,9 +74,9 @@ struct LayerW {
     float *g1 = nullptr, *be1 = nullptr, *g2 = nullptr, *be2 = nullptr;
 };
 
-enum Family { FAM_COND = 0, FAM_EMBED_IN, FAM_QKV, FAM_ATTN, FAM_OUTPROJ_LN, FAM_FFN1, FAM_FFN2_LN, FAM_EMBED_OUT, FAM_COUNT };
+enum Family { FAM_COND = 0, FAM_EMBED_IN, FAM_QKV, FAM_ATTN, FAM_OUTPROJ_LN, FAM_FFN1, FAM_FFN2_LN, FAM_EMBED_OUT, FAM_QKV_ATTN, FAM_COUNT };
 static const char* kFamilyNames[FAM_COUNT] = {"cond_token", "embed_in", "qkv_gemm", "attention", "outproj_ln_gemm",
-                                              "ffn1_gelu_gemm", "ffn2_ln_gemm", "embed_out_step"};
+                                              "ffn1_gelu_gemm", "ffn2_ln_gemm", "embed_out_step", "qkv_attention_fused"};
 
 struct ProfPoint { int fam; hipEvent_t a, b; };
 
@@ -96,6 +96,7 @@ struct mst_engine {
     std::vector<std::string> loaded;
     int text_batch = 0, text_cfg = 0;
     int dbg_layer = -1, dbg_stage = -1;   // stop the trunk after (layer, stage); -1 = run everything
+    int fuse_qkv_attn = 1;                // K4 + K5 as one kernel per (clip, head); MST_FUSE_QKV_ATTN=0 keeps them apart
     int nsplit = 2;                       // sampling loops run the batch as this many independent slices on separate streams
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -200,6 +201,7 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     HIPCHECK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     HIPCHECK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     if (const char* v = getenv("MST_STREAMS")) e->nsplit = atoi(v) >= 2 ? 2 : 1;
+    if (const char* v = getenv("MST_FUSE_QKV_ATTN")) e->fuse_qkv_attn = atoi(v) != 0;
     *out = e;
     return 0;
 }
@@ -396,6 +398,34 @@ static int launch_attn_n(const f16* qkv, f16* out, int S, int rows, hipStream_t 
     return 0;
 }
 
+template <int NKT>
+static int launch_qkv_attn_n(const f16* hx, const f16* w_in, const float* b_in, f16* out, int S, int rows, hipStream_t st) {
+    auto kern = k_qkv_attention<NKT>;
+    static bool attr_set = false;
+    constexpr int smem = QATile<NKT>::SMEM;
+    static_assert(smem <= 163840, "fused QKV+attention exceeds the 160 KiB LDS");
+    if (!attr_set) {
+        HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(rows * MST_H), dim3(512), smem, st, hx, w_in, b_in, out, S);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+static int launch_qkv_attn(const f16* hx, const f16* w_in, const float* b_in, f16* out, int S, int rows, hipStream_t st) {
+    switch ((S + 31) / 32) {
+        case 1: return launch_qkv_attn_n<1>(hx, w_in, b_in, out, S, rows, st);
+        case 2: return launch_qkv_attn_n<2>(hx, w_in, b_in, out, S, rows, st);
+        case 3: return launch_qkv_attn_n<3>(hx, w_in, b_in, out, S, rows, st);
+        case 4: return launch_qkv_attn_n<4>(hx, w_in, b_in, out, S, rows, st);
+        case 5: return launch_qkv_attn_n<5>(hx, w_in, b_in, out, S, rows, st);
+        case 6: return launch_qkv_attn_n<6>(hx, w_in, b_in, out, S, rows, st);
+        case 7: return launch_qkv_attn_n<7>(hx, w_in, b_in, out, S, rows, st);
+    }
+    return fail("attention: S=%d unsupported", S);
+}
+
 static int launch_attn(const f16* qkv, f16* out, int S, int rows, hipStream_t st) {
     switch ((S + 31) / 32) {
         case 1: return launch_attn_n<1>(qkv, out, S, rows, st);
@@ -475,15 +505,20 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
 #define DBG_STOP(stage) if (e->dbg_layer == l && e->dbg_stage == stage) return 0;
     for (int l = 0; l < e->cfg.num_layers; l++) {
         const LayerW& w = e->L[l];
-        {
-            ProfScope ps(e, FAM_QKV, st);
-            DEpiBiasF16<false> epi{w.b_in, ws.qkv, 3 * MST_D, M};
-            CHECK((launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, 3 * MST_D / 256), RowsDirect{ws.hx, MST_D}, w.w_in, MST_D, MST_D, epi, st, WIDE_XCD ? 3 * MST_D / 256 : 0)));
-        }
-        DBG_STOP(1)
-        {
-            ProfScope ps(e, FAM_ATTN, st);
-            CHECK(launch_attn(ws.qkv, ws.att, S, rows, st));
+        if (e->fuse_qkv_attn && !(e->dbg_layer == l && e->dbg_stage == 1)) {
+            ProfScope ps(e, FAM_QKV_ATTN, st);
+            CHECK(launch_qkv_attn(ws.hx, w.w_in, w.b_in, ws.att, S, rows, st));
+        } else {
+            {
+                ProfScope ps(e, FAM_QKV, st);
+                DEpiBiasF16<false> epi{w.b_in, ws.qkv, 3 * MST_D, M};
+                CHECK((launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, 3 * MST_D / 256), RowsDirect{ws.hx, MST_D}, w.w_in, MST_D, MST_D, epi, st, WIDE_XCD ? 3 * MST_D / 256 : 0)));
+            }
+            DBG_STOP(1)
+            {
+                ProfScope ps(e, FAM_ATTN, st);
+                CHECK(launch_attn(ws.qkv, ws.att, S, rows, st));
+            }
         }
         DBG_STOP(2)
         {
