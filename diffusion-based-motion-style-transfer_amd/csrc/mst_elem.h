@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_rowwise_linear(const float* __restrict_
 // uniform_row < 0: clip uses temb row (clip % temb_mod) (per-clip t; the CFG halves share rows).
 __global__ void k_cond_token(const float* __restrict__ temb, int uniform_row, int temb_mod,
                              const float* __restrict__ textproj, const float* __restrict__ pe, int S, int rows,
-                             float* __restrict__ h32, f16* __restrict__ h16) {
+                             f16* __restrict__ hi, f16* __restrict__ lo) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * MST_D) return;
     int clip = i / MST_D, f = i - clip * MST_D;
@@ -82,8 +82,15 @@ __global__ void k_cond_token(const float* __restrict__ temb, int uniform_row, in
     float v = temb[(size_t)tr * MST_D + f] + textproj[(size_t)clip * MST_D + f];
     v += pe[f];
     size_t o = (size_t)clip * S * MST_D + f;
-    h32[o] = v;
-    h16[o] = (f16)v;
+    const f16 h = (f16)v;
+    hi[o] = h;
+    lo[o] = (f16)(v - (float)h);
+}
+
+// debug / tests: the stream as float32
+__global__ void k_join_stream(const f16* __restrict__ hi, const f16* __restrict__ lo, float* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = (float)hi[i] + (float)lo[i];
 }
 
 // K11 stand-alone: x_t = sqrt(abar_t) x0 + sqrt(1-abar_t) (noise * (1 - mask))

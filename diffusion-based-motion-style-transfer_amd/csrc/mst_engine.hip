@@ -89,7 +89,7 @@ struct mst_engine {
     float *w_t0 = nullptr, *b_t0 = nullptr, *w_t2 = nullptr, *b_t2 = nullptr, *w_text = nullptr, *b_text = nullptr;
     float* pe = nullptr;
     // workspace
-    float* hs = nullptr;
+    f16* hl = nullptr;        // lo half of the stream (hx is the hi half)
     f16 *hx = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr, *xt = nullptr;
     float *temb_hid = nullptr, *temb = nullptr, *textproj = nullptr;
     int temb_cap = 0;
@@ -187,7 +187,7 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     CHECK(dmalloc(&e->w_text, (size_t)MST_D * c->clip_dim));
     CHECK(dmalloc(&e->b_text, MST_D));
     CHECK(dmalloc(&e->pe, (size_t)c->pe_len * MST_D));
-    CHECK(dmalloc(&e->hs, (size_t)e->M_pad * MST_D));
+    CHECK(dmalloc(&e->hl, (size_t)e->M_pad * MST_D));
     CHECK(dmalloc(&e->hx, (size_t)e->M_pad * MST_D));
     CHECK(dmalloc(&e->qkv, (size_t)e->M_pad * 3 * MST_D));
     CHECK(dmalloc(&e->att, (size_t)e->M_pad * MST_D));
@@ -214,7 +214,7 @@ extern "C" void mst_engine_destroy(mst_engine* e) {
         for (void* q : p) (void)hipFree(q);
     }
     void* p[] = {e->w_pose_in, e->b_pose_in, e->w_pose_out, e->b_pose_out, e->w_t0, e->b_t0, e->w_t2, e->b_t2,
-                 e->w_text, e->b_text, e->pe, e->hs, e->hx, e->qkv, e->att, e->hid, e->xt, e->temb_hid, e->temb, e->textproj};
+                 e->w_text, e->b_text, e->pe, e->hl, e->hx, e->qkv, e->att, e->hid, e->xt, e->temb_hid, e->temb, e->textproj};
     for (void* q : p) (void)hipFree(q);
     if (e->aux_stream) (void)hipStreamDestroy(e->aux_stream);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
@@ -472,11 +472,11 @@ extern "C" int mst_set_text(mst_engine* e, const float* text_emb, const float* k
 // A slice of the workspace: clips [r0, r0 + n) of the batch get their own rows of every buffer, so slices can
 // run concurrently on different streams (tiles may over-READ into a neighbour's rows; they never write them).
 struct WS {
-    float* hs; f16 *hx, *qkv, *att, *hid, *xt; float* textproj;
+    f16 *hl, *hx, *qkv, *att, *hid, *xt; float* textproj;
 };
 static WS ws_slice(const mst_engine* e, int r0, int T) {
     const size_t row = (size_t)r0 * (T + 1);
-    return WS{e->hs + row * MST_D, e->hx + row * MST_D, e->qkv + row * 3 * MST_D, e->att + row * MST_D, e->hid + row * MST_FF,
+    return WS{e->hl + row * MST_D, e->hx + row * MST_D, e->qkv + row * 3 * MST_D, e->att + row * MST_D, e->hid + row * MST_FF,
               e->xt + (size_t)r0 * T * e->kin_pad, e->textproj + (size_t)r0 * MST_D};
 }
 
@@ -487,7 +487,7 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
     {
         ProfScope ps(e, FAM_COND, st);
         hipLaunchKernelGGL(k_cond_token, dim3((rows * MST_D + 255) / 256), dim3(256), 0, st, e->temb, temb_uniform_row,
-                           temb_mod, ws.textproj, e->pe, S, rows, ws.hs, ws.hx);
+                           temb_mod, ws.textproj, e->pe, S, rows, ws.hx, ws.hl);
         HIPCHECK(hipGetLastError());
     }
     {
@@ -497,7 +497,7 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
         const int F = e->cfg.feats, tot = clips_x * T;
         hipLaunchKernelGGL(k_frames_f16, dim3((T + 31) / 32, e->kin_pad / 32, clips_x), dim3(256), 0, st, x, F, T, e->kin_pad, ws.xt);
         HIPCHECK(hipGetLastError());
-        DEpiEmbedIn epi{e->b_pose_in, e->pe, ws.hs, ws.hx, T, S, tot, rows > clips_x ? (size_t)clips_x * S * MST_D : 0};
+        DEpiEmbedIn epi{e->b_pose_in, e->pe, ws.hx, ws.hl, T, S, tot, rows > clips_x ? (size_t)clips_x * S * MST_D : 0};
         CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1>(dim3((tot + 63) / 64, 1), RowsDirect{ws.xt, e->kin_pad}, e->w_pose_in, e->kin_pad,
                                                    e->kin_pad, epi, st)));
     }
@@ -523,7 +523,7 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
         DBG_STOP(2)
         {
             ProfScope ps(e, FAM_OUTPROJ_LN, st);
-            DEpiResidLN epi{w.b_out, ws.hs, w.g1, w.be1, ws.hs, ws.hx, M};
+            DEpiResidLN epi{w.b_out, w.g1, w.be1, ws.hx, ws.hl, M};
             CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1>(dim3((M + 63) / 64, 1), RowsDirect{ws.att, MST_D}, w.w_out, MST_D, ABL_K(MST_D), epi, st)));
         }
         DBG_STOP(3)
@@ -535,7 +535,7 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
         DBG_STOP(4)
         {
             ProfScope ps(e, FAM_FFN2_LN, st);
-            DEpiResidLN epi{w.b2, ws.hs, w.g2, w.be2, ws.hs, ws.hx, M};
+            DEpiResidLN epi{w.b2, w.g2, w.be2, ws.hx, ws.hl, M};
             CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1>(dim3((M + 63) / 64, 1), RowsDirect{ws.hid, MST_FF}, w.w2, MST_FF, ABL_K(MST_FF), epi, st)));
         }
         DBG_STOP(5)
@@ -729,8 +729,14 @@ extern "C" int mst_debug_copy(mst_engine* e, const char* which, void* dst_dev, u
     std::string w(which);
     const void* src = nullptr;
     size_t cap = 0;
-    if (w == "hs") { src = e->hs; cap = (size_t)e->M_pad * MST_D * 4; }
-    else if (w == "hx") { src = e->hx; cap = (size_t)e->M_pad * MST_D * 2; }
+    if (w == "hs") {           // the stream as float32: joined from its f16 hi/lo halves on the fly
+        const size_t n = nbytes / 4;
+        if (nbytes > (size_t)e->M_pad * MST_D * 4) return fail("mst_debug_copy: hs holds %zu bytes", (size_t)e->M_pad * MST_D * 4);
+        hipLaunchKernelGGL(k_join_stream, dim3(1024), dim3(256), 0, (hipStream_t)stream, e->hx, e->hl, (float*)dst_dev, n);
+        HIPCHECK(hipGetLastError());
+        return 0;
+    }
+    if (w == "hx") { src = e->hx; cap = (size_t)e->M_pad * MST_D * 2; }
     else if (w == "qkv") { src = e->qkv; cap = (size_t)e->M_pad * 3 * MST_D * 2; }
     else if (w == "att") { src = e->att; cap = (size_t)e->M_pad * MST_D * 2; }
     else if (w == "hid") { src = e->hid; cap = (size_t)e->M_pad * MST_FF * 2; }

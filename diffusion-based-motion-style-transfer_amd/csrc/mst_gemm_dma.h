@@ -205,8 +205,8 @@ struct DEpiBiasF16 {
 // After the transpose every wave owns whole rows: statistics are wave-level shuffles, no
 // cross-wave exchange.
 struct DEpiResidLN {
-    const float* bias; const float* res; const float* gamma; const float* beta;
-    float* out32; f16* out16; int M;
+    const float* bias; const float* gamma; const float* beta;
+    f16* hi; f16* lo; int M;                 // the stream (read as residual, rewritten in place): hi + lo pair
     __device__ __forceinline__ int rows() const { return M; }
     template <int BT, int BF> static constexpr int smem_bytes() { return BT * (MST_D * 4 + 16); }
     template <int BT, int BF, int MT, int NT>
@@ -216,7 +216,7 @@ struct DEpiResidLN {
         {
             float keep = 0.f;
             for (int m = 0; m < MT; m++) for (int n = 0; n < NT; n++) for (int r = 0; r < 16; r++) keep += acc[0][m][n][r];
-            if (keep == 123.456f) out32[0] = keep;
+            if (keep == 123.456f) hi[0] = (f16)keep;
             return;
         }
 #endif
@@ -245,8 +245,8 @@ struct DEpiResidLN {
         for (int r = 0; r < RPW; r++) {
             int tok = tok0 + wave * RPW + r;
             size_t off = (size_t)(tok < M ? tok : 0) * MST_D;
-            xa[r] = *reinterpret_cast<const f32x4*>(res + off + fa);
-            xb[r] = *reinterpret_cast<const f32x4*>(res + off + fb);
+            xa[r] = join4_f16(*reinterpret_cast<const uint2*>(hi + off + fa), *reinterpret_cast<const uint2*>(lo + off + fa));
+            xb[r] = join4_f16(*reinterpret_cast<const uint2*>(hi + off + fb), *reinterpret_cast<const uint2*>(lo + off + fb));
         }
         // row sums for ALL rows first, then the shuffle ladders step by step across rows: RPW
         // independent ds_bpermutes per step instead of RPW serial 6-deep dependency chains
@@ -297,10 +297,13 @@ struct DEpiResidLN {
                 yb[i] = xb[r][i] * rstd * gb[i] + eb[i];
             }
             const size_t off = (size_t)tok * MST_D;
-            *reinterpret_cast<f32x4*>(out32 + off + fa) = ya;
-            *reinterpret_cast<f32x4*>(out32 + off + fb) = yb;
-            *reinterpret_cast<uint2*>(out16 + off + fa) = pack4_f16(ya[0], ya[1], ya[2], ya[3]);
-            *reinterpret_cast<uint2*>(out16 + off + fb) = pack4_f16(yb[0], yb[1], yb[2], yb[3]);
+            uint2 h, l;
+            split4_f16(ya, h, l);
+            *reinterpret_cast<uint2*>(hi + off + fa) = h;
+            *reinterpret_cast<uint2*>(lo + off + fa) = l;
+            split4_f16(yb, h, l);
+            *reinterpret_cast<uint2*>(hi + off + fb) = h;
+            *reinterpret_cast<uint2*>(lo + off + fb) = l;
         }
     }
 };
@@ -309,7 +312,7 @@ struct DEpiResidLN {
 // Same 64 x 512 tile and LDS transpose as the LayerNorm epilogue; `dup` > 0 also writes the rows of
 // the CFG uncond half (identical frames, only the conditioning token differs).
 struct DEpiEmbedIn {
-    const float* bias; const float* pe; float* out32; f16* out16; int T, S, total; size_t dup;
+    const float* bias; const float* pe; f16* hi; f16* lo; int T, S, total; size_t dup;
     __device__ __forceinline__ int rows() const { return total; }
     template <int BT, int BF> static constexpr int smem_bytes() { return BT * (MST_D * 4 + 16); }
     template <int BT, int BF, int MT, int NT>
@@ -348,12 +351,15 @@ struct DEpiEmbedIn {
                 xb[i] = xb[i] + bb[i] + pb[i];
             }
             size_t off = ((size_t)clip * S + 1 + t) * MST_D;
+            uint2 ha, la, hb, lb;
+            split4_f16(xa, ha, la);
+            split4_f16(xb, hb, lb);
 #pragma unroll
             for (int rep = 0; rep < 2; rep++) {
-                *reinterpret_cast<f32x4*>(out32 + off + fa) = xa;
-                *reinterpret_cast<f32x4*>(out32 + off + fb) = xb;
-                *reinterpret_cast<uint2*>(out16 + off + fa) = pack4_f16(xa[0], xa[1], xa[2], xa[3]);
-                *reinterpret_cast<uint2*>(out16 + off + fb) = pack4_f16(xb[0], xb[1], xb[2], xb[3]);
+                *reinterpret_cast<uint2*>(hi + off + fa) = ha;
+                *reinterpret_cast<uint2*>(lo + off + fa) = la;
+                *reinterpret_cast<uint2*>(hi + off + fb) = hb;
+                *reinterpret_cast<uint2*>(lo + off + fb) = lb;
                 if (dup == 0) break;
                 off += dup;
             }

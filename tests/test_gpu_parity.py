@@ -81,7 +81,8 @@ def test_layer0_stage_by_stage(tag):
     print("stage errors", tag, errs)
     for stage, e in errs.items():
         assert e < TOL, (stage, errs)
-    # the f16 operand copy of the stream must be the rounding of the fp32 stream
+    # the stream is kept as an f16 hi/lo pair: hi (the MFMA operand copy) must be the f16 rounding of the
+    # stream value, i.e. within half an f16 ulp of hi + lo
     eng.debug_stop_after(0, 5)
     try:
         eng.forward(cu(x), cu(t))
@@ -89,7 +90,9 @@ def test_layer0_stage_by_stage(tag):
         hx = eng.debug_buffer("hx", B * S, 512)
     finally:
         eng.debug_stop_after(-1, -1)
-    assert torch.equal(hs.half(), hx)
+    err = (hs - hx.float()).abs()
+    assert bool((err <= hs.abs() * 2.0 ** -11 * 1.001 + 2.0 ** -25).all())
+    assert float((hs.half() != hx).float().mean()) < 1e-3      # ties aside, it IS the rounding
 
 
 # ------------------------------------------------------------------------------ model forward
