@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--denoise-steps", type=int, default=1000)
     ap.add_argument("--cfg", action="store_true", help="configs[2]: classifier-free guidance (doubled batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--shared-device", action="store_true",
+                    help="rehearsal on a 1-GPU box: every rank uses cuda:0 (use with --backend gloo)")
     ap.add_argument("--cpu-sample-steps", type=int, default=24)
     args = ap.parse_args()
 
@@ -76,10 +79,15 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     dist = None
+    if args.shared_device:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -124,7 +132,7 @@ def main():
     eng.profile(False)
     assert torch.isfinite(last).all()
     assert torch.equal(last[:, :3], motion[:, :3]), "inpainted rows must equal the content clip exactly"
-    dt = sharding.max_over_ranks(dt, dev)
+    dt = sharding.max_over_ranks(dt, dev if args.backend == "nccl" else "cpu")
 
     if rank == 0:
         clips = world * B * args.steps

@@ -29,6 +29,9 @@ using namespace mst;
 #else
 #define ABL_K(k) (k)
 #endif
+#ifndef FFN1_BF
+#define FFN1_BF 256   // same-box A/B: 128x512 tiles (one 8-wave block per CU) 40 us vs 35 us for two co-resident 128x256 blocks
+#endif
 #ifndef WIDE_XCD
 #define WIDE_XCD 1
 #endif
@@ -530,7 +533,12 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
         {
             ProfScope ps(e, FAM_FFN1, st);
             DEpiBiasF16<true> epi{w.b1, ws.hid, MST_FF, M};
+#if FFN1_BF == 512      // 128 x 512 tiles: 198 blocks at batch 64, one per CU, 640 KB staged per block
+            const int nx = (M + 127) / 128;
+            CHECK((launch_gemm_dma<128, 512, 2, 4, 3, 1>(dim3(((nx + 7) / 8) * 8 * 2, 1, 1), RowsDirect{ws.hx, MST_D}, w.w1, MST_D, MST_D, epi, st, 2)));
+#else
             CHECK((launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, MST_FF / 256), RowsDirect{ws.hx, MST_D}, w.w1, MST_D, MST_D, epi, st, WIDE_XCD ? MST_FF / 256 : 0)));
+#endif
         }
         DBG_STOP(4)
         {

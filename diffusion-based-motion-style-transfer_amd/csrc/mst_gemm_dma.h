@@ -156,16 +156,19 @@ template <bool GELU>
 struct DEpiBiasF16 {
     const float* bias; f16* out; int ldo; int M;
     __device__ __forceinline__ int rows() const { return M; }
-    template <int BT, int BF> static constexpr int smem_bytes() { return (BT < 128 ? BT : 128) * (BF * 2 + 16); }
+    // rows transposed per pass: as many as fit ~68 KB (128 rows of 512 B, 64 rows of 1 KiB)
+    template <int BT, int BF> static constexpr int pass_rows() { return (BT * (BF * 2 + 16) <= 69632) ? BT : (BF == 512 ? 64 : 128); }
+    template <int BT, int BF> static constexpr int smem_bytes() { return pass_rows<BT, BF>() * (BF * 2 + 16); }
     template <int BT, int BF, int MT, int NT>
     __device__ __forceinline__ void run(f32x16 (&acc)[1][MT][NT], int tok0, int f0, char* smem) const {
-        static_assert(BF == 256, "copy-out below assumes 512-byte tile rows");
+        static_assert(BF == 256 || BF == 512, "copy-out assumes 512-byte or 1-KiB tile rows");
         constexpr int LD = BF * 2 + 16;                       // bytes per tile row (+16: spreads banks, keeps 16-B alignment)
-        constexpr int PR = BT < 128 ? BT : 128;               // rows transposed per pass
+        constexpr int PR = pass_rows<BT, BF>();
         constexpr int PASSES = BT / PR;
+        constexpr int RPA = 1024 / (BF * 2);                  // tile rows covered by one 1-KiB wave access (2 or 1)
         DLane<BT, BF, MT, NT> lc;
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int sub = lane >> 5, col = (lane & 31) * 16;    // one wave access = 2 rows x 512 B
+        const int sub = RPA == 2 ? lane >> 5 : 0, col = (RPA == 2 ? (lane & 31) : lane) * 16;
 #pragma unroll
         for (int pass = 0; pass < PASSES; pass++) {
 #pragma unroll
@@ -190,8 +193,8 @@ struct DEpiBiasF16 {
             }
             __syncthreads();
 #pragma unroll
-            for (int p = 0; p < PR / 16; p++) {
-                int row = p * 16 + wave * 2 + sub;
+            for (int p = 0; p < PR / (8 * RPA); p++) {
+                int row = p * 8 * RPA + wave * RPA + sub;
                 int tok = tok0 + pass * PR + row;
                 uint4 v = *reinterpret_cast<const uint4*>(smem + row * LD + col);
                 if (tok < M) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(out + (size_t)tok * ldo + f0) + col) = v;
