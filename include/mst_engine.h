@@ -150,7 +150,7 @@ typedef struct mst_loop_args {
 
 int mst_sample_loop(mst_engine* e, const mst_schedule* s, const mst_loop_args* a, void* stream);
 
-/* Number of independent clip slices (1 or 2) mst_sample_loop runs on separate streams for this
+/* Number of independent clip slices (1..4) mst_sample_loop runs on separate streams for this
  * batch: clips never interact (no cross-sample op in mdm_forstyledataset.py:602-625), so two
  * half-batches overlap each other's launch gaps, prologues and tails.  MST_STREAMS=1 in the
  * environment at engine creation forces one slice.  Per-launch work = batch / slices clips. */

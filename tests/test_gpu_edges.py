@@ -70,12 +70,12 @@ def test_forward_and_loop_on_ragged_shapes(F, T, B):
 
 
 def test_odd_batch_across_the_two_slices_equals_single_slice():
-    """Batch 17 is split 9 + 8 over two streams; results must not depend on the split."""
+    """Batch 17 is split 9 + 8 over two streams (8-clip minimum per slice); results must not depend on the split."""
     from mst_amd.engine import Schedule, SAMPLER_DDPM
     from oracle import schedule
     F, T, B = 181, 76, 17
     eng, w, pe = make(F, T, B)
-    assert eng.loop_slices(B) == 2 and eng.loop_slices(B, cfg=True) == 1 and eng.loop_slices(8) == 1
+    assert eng.loop_slices(B) == 2 and eng.loop_slices(B, cfg=True) == 1 and eng.loop_slices(8) == 1 and eng.loop_slices(64) == 3
     shape = (B, F, 1, T)
     tab, tmap = schedule.make("cosine", 1000, "")
     sch = Schedule(tab, tmap, dev())
