@@ -12,7 +12,7 @@
 // scalar, and the output store is 8 bytes per lane (4 consecutive d of one query).
 #pragma once
 #include "mst_common.h"
-#include "mst_gemm_dma.h"   // ring_off, dma_issue, wait_vmcnt
+#include "mst_gemm_dma.h"   // ring_off, DmaPlan, wait_vmcnt
 
 namespace mst {
 
@@ -175,6 +175,7 @@ struct QATile {
     static constexpr int INSTR = ROWS / 16;
     static constexpr int PER = (INSTR + 7) / 8;
     static constexpr int RING = NSTAGE * STAGE;
+    static constexpr int XROWS = XR;
     static constexpr int KV = NKT * 32 * 256 * 2;       // K and V images afterwards (reuse the ring)
     static constexpr int SMEM = RING > KV ? RING : KV;
 };
@@ -191,25 +192,15 @@ __global__ __launch_bounds__(512) void k_qkv_attention(const f16* __restrict__ h
     const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     const f16* xbase = hx + (size_t)clip * S * MST_D;
 
-    // ---- per-lane DMA sources: tile rows [0, XR) = tokens (clamped), [XR, XR+384) = q|k|v weight rows of the head
-    const char* src[TL::PER];
-    unsigned dst[TL::PER];
-#pragma unroll
-    for (int j = 0; j < TL::PER; j++) {
-        int i = wave + 8 * j;
-        if (i >= TL::INSTR) i -= 8 * (TL::PER - 1);
-        int row = i * 16 + (lane >> 2);
-        int c = (lane & 3) ^ ((row >> 2) & 3);
-        const f16* g;
-        if (row < TL::XR) {
-            g = xbase + (size_t)(row < S ? row : S - 1) * MST_D;
-        } else {
-            int r = row - TL::XR;
-            g = w_in + (size_t)((r >> 7) * MST_D + head * MST_HD + (r & 127)) * MST_D;
-        }
-        src[j] = reinterpret_cast<const char*>(g + c * 8);
-        dst[j] = i * 1024;
-    }
+    // ---- DMA plan: tile rows [0, XR) = the clip's tokens (clamped), [XR, XR+384) = q|k|v weight rows of the head
+    DmaPlan<TL> plan;
+    plan.init(wave, lane, [&](int row) {
+        if (row < TL::XR) return (unsigned)(row < S ? row : S - 1) * (unsigned)(MST_D * 2);
+        const int r = row - TL::XR;
+        return (unsigned)((r >> 7) * MST_D + head * MST_HD + (r & 127)) * (unsigned)(MST_D * 2);
+    });
+    const char* xb = reinterpret_cast<const char*>(xbase);
+    const char* wb = reinterpret_cast<const char*>(w_in);
     f32x16 acc[12];
 #pragma unroll
     for (int n = 0; n < 12; n++)
@@ -218,13 +209,13 @@ __global__ __launch_bounds__(512) void k_qkv_attention(const f16* __restrict__ h
 
     constexpr int KT = MST_D / 32, AHEAD = TL::NSTAGE - 1;
 #pragma unroll
-    for (int s = 0; s < AHEAD; s++) dma_issue<TL>(src, dst, smem_base, s);
+    for (int s = 0; s < AHEAD; s++) plan.issue(smem_base, s, s, xb, wb);
     const bool active = wave < NKT;
     for (int kt = 0; kt < KT; kt++) {
         if (KT - 1 - kt >= AHEAD - 1) wait_vmcnt<(AHEAD - 1) * TL::PER>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        if (kt + AHEAD < KT) dma_issue<TL>(src, dst, smem_base, kt + AHEAD);
+        if (kt + AHEAD < KT) plan.issue(smem_base, kt + AHEAD, kt + AHEAD, xb, wb);
         if (active) {
             const char* st = smem + (kt % TL::NSTAGE) * TL::STAGE;
 #pragma unroll

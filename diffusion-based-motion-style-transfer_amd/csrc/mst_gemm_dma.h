@@ -36,40 +36,93 @@ struct DTile {
 
 __device__ __forceinline__ int ring_off(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
 
-// one 1-KiB LDS-DMA piece: every lane supplies its own global source; LDS destination is the
-// wave-uniform `lds_dst` + lane * 16 (M0 carries the base; saved/restored inside the statement
-// because M0 is compiler-reserved, cdna guide section 5.7).
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+// LDS-DMA issue.  One `global_load_lds_dwordx4` moves 1 KiB (64 lanes x 16 B): LDS destination = M0 + imm + 16 * lane,
+// global source = SGPR base + per-lane 32-bit offset + imm -- the SAME immediate is added on both sides (verified with
+// csrc/probes/probe_glds.hip).  A wave owns PER CONSECUTIVE pieces of a slab, so up to four of them share one M0 write
+// with imm = 0 / 1024 / 2048 / 3072 and the per-lane offset pre-compensated by -imm; the slab-to-slab advance is a
+// scalar add on the two operand bases.  (First version: one piece per asm statement with M0 save/set/restore and a
+// 64-bit VALU address add each -- ~150 issue cycles per piece, which is what bounded the slab loop at ~0.6 us.)
+template <int G>
+__device__ __forceinline__ void glds_group(const unsigned (&voff)[5], const unsigned long long (&sb)[5], int j0, unsigned lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    if constexpr (G == 4)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %2, %6\n\tglobal_load_lds_dwordx4 %3, %7 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %4, %8 offset:2048\n\tglobal_load_lds_dwordx4 %5, %9 offset:3072\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(lds_dst), "v"(voff[j0]), "v"(voff[j0 + 1]), "v"(voff[j0 + 2]), "v"(voff[j0 + 3]),
+                       "s"(sb[j0]), "s"(sb[j0 + 1]), "s"(sb[j0 + 2]), "s"(sb[j0 + 3]) : "memory");
+    else if constexpr (G == 3)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %2, %5\n\tglobal_load_lds_dwordx4 %3, %6 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %4, %7 offset:2048\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(lds_dst), "v"(voff[j0]), "v"(voff[j0 + 1]), "v"(voff[j0 + 2]),
+                       "s"(sb[j0]), "s"(sb[j0 + 1]), "s"(sb[j0 + 2]) : "memory");
+    else if constexpr (G == 2)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %2, %4\n\tglobal_load_lds_dwordx4 %3, %5 offset:1024\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(lds_dst), "v"(voff[j0]), "v"(voff[j0 + 1]), "s"(sb[j0]), "s"(sb[j0 + 1]) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(lds_dst), "v"(voff[j0]), "s"(sb[j0]) : "memory");
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// Per-wave DMA state of one GEMM: piece j of this wave (tile rows 16 * (start + j) ..) comes from operand
+// `isx[j] ? X : W` at per-lane byte offset voff[j] (bias and immediate already folded in).
+constexpr unsigned kDmaBias = 4096;      // keeps (offset - imm) non-negative; subtracted from the scalar bases
 template <class TL>
-__device__ __forceinline__ void dma_issue(const char* const (&src)[TL::PER], const unsigned (&dst)[TL::PER],
-                                          unsigned smem_base, int kt) {
-    const unsigned base = smem_base + (kt % TL::NSTAGE) * TL::STAGE;
+struct DmaPlan {
+    static_assert(TL::PER <= 5 && TL::INSTR >= TL::PER, "piece plan");
+    unsigned voff[5];
+    bool isx[5];
+    int start;
+    // rowbyte(r): byte offset of tile row r inside its operand (X rows for r < XROWS, else W rows)
+    template <class F>
+    __device__ __forceinline__ void init(int wave, int lane, F rowbyte) {
+        start = wave * TL::PER;
+        if (start > TL::INSTR - TL::PER) start = TL::INSTR - TL::PER;   // last wave re-issues a few of its neighbour's
 #pragma unroll
-    for (int j = 0; j < TL::PER; j++)
-        glds16(src[j] + (size_t)kt * 64, __builtin_amdgcn_readfirstlane(base + dst[j]));
-}
+        for (int j = 0; j < 5; j++) {
+            if (j < TL::PER) {
+                const int row = (start + j) * 16 + (lane >> 2);
+                const int c = (lane & 3) ^ ((row >> 2) & 3);
+                isx[j] = (start + j) * 16 < TL::XROWS;               // wave-uniform
+                voff[j] = rowbyte(row) + c * 16 + kDmaBias - (j & 3) * 1024;
+            } else { voff[j] = 0; isx[j] = false; }
+        }
+    }
+    // slab `ksrc` of the operands -> ring slot of slab-sequence position `kt`
+    __device__ __forceinline__ void issue(unsigned smem_base, int kt, int ksrc, const char* xbase, const char* wbase) const {
+        const unsigned long long sx = (unsigned long long)(xbase + (size_t)ksrc * 64 - kDmaBias);
+        const unsigned long long sw = (unsigned long long)(wbase + (size_t)ksrc * 64 - kDmaBias);
+        unsigned long long sb[5];
+#pragma unroll
+        for (int j = 0; j < 5; j++) sb[j] = isx[j] ? sx : sw;
+        const unsigned base = __builtin_amdgcn_readfirstlane(smem_base + (kt % TL::NSTAGE) * TL::STAGE + start * 1024);
+        if constexpr (TL::PER >= 4) glds_group<4>(voff, sb, 0, base);
+        else glds_group<TL::PER>(voff, sb, 0, base);
+        if constexpr (TL::PER == 5) glds_group<1>(voff, sb, 4, base + 4096);
+    }
+};
 
 // Row sources: which global row feeds tile row r of the activation operand.
 struct RowsDirect {                       // tile row r = matrix row tok0 + r
     const f16* X; int ld;
-    __device__ __forceinline__ const f16* row(int tok0, int r) const { return X + (size_t)(tok0 + r) * ld; }
+    __device__ __forceinline__ const char* base() const { return reinterpret_cast<const char*>(X); }
+    __device__ __forceinline__ unsigned rowbyte(int tok0, int r) const { return (unsigned)(tok0 + r) * (unsigned)ld * 2u; }
 };
 struct RowsFrames {                       // tile row r = frame (tok0 + r) of the token stream, conditioning token skipped;
     const f16* X; int ld; int T, S, total;   // rows >= BT (second group) come from the uncond half (+cfg_rows)
     int BT; size_t cfg_rows;
-    __device__ __forceinline__ const f16* row(int tok0, int r) const {
+    __device__ __forceinline__ const char* base() const { return reinterpret_cast<const char*>(X); }
+    __device__ __forceinline__ unsigned rowbyte(int tok0, int r) const {
         int half = r >= BT ? 1 : 0;
         int tok = tok0 + r - half * BT;
         if (tok >= total) tok = total - 1;
         int clip = tok / T, t = tok - clip * T;
-        return X + ((size_t)clip * S + 1 + t + half * cfg_rows) * ld;
+        return (unsigned)((size_t)clip * S + 1 + t + half * cfg_rows) * (unsigned)ld * 2u;
     }
 };
 
@@ -81,24 +134,17 @@ __device__ __forceinline__ void gemm_mainloop_dma(char* smem, const SRC& xs, con
     const int wt = wave / TL::WN, wn = wave % TL::WN;
     const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
-    // per-lane source pointers of this wave's PER pieces (advance 64 B per slab)
-    const char* src[TL::PER];
-    unsigned dst[TL::PER];
-#pragma unroll
-    for (int j = 0; j < TL::PER; j++) {
-        int i = wave + 8 * j;
-        if (i >= TL::INSTR) i -= 8 * (TL::PER - 1);          // duplicate piece: same bytes, same place
-        int row = i * 16 + (lane >> 2);
-        int c = (lane & 3) ^ ((row >> 2) & 3);
-        const f16* g = row < TL::XROWS ? xs.row(tok0, row) : W + (size_t)(f0 + row - TL::XROWS) * ldw;
-        src[j] = reinterpret_cast<const char*>(g + c * 8);
-        dst[j] = i * 1024;
-    }
+    DmaPlan<TL> plan;
+    plan.init(wave, lane, [&](int row) {
+        return row < TL::XROWS ? xs.rowbyte(tok0, row) : (unsigned)(f0 + row - TL::XROWS) * (unsigned)ldw * 2u;
+    });
+    const char* xb = xs.base();
+    const char* wb = reinterpret_cast<const char*>(W);
     const int KT = K >> 5;
     constexpr int AHEAD = TL::NSTAGE - 1;                    // slabs in flight
 #pragma unroll
     for (int s = 0; s < AHEAD; s++)
-        if (s < KT) dma_issue<TL>(src, dst, smem_base, s);
+        if (s < KT) plan.issue(smem_base, s, s, xb, wb);
 
     for (int kt = 0; kt < KT; kt++) {
         const int rem = KT - 1 - kt;                        // slabs already issued beyond kt: min(rem, AHEAD - 1)
@@ -106,7 +152,7 @@ __device__ __forceinline__ void gemm_mainloop_dma(char* smem, const SRC& xs, con
         else if (AHEAD >= 3 && rem == 1) wait_vmcnt<TL::PER>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();                       // slab kt landed for every wave; slot of slab kt-1 is free
-        if (kt + AHEAD < KT) dma_issue<TL>(src, dst, smem_base, kt + AHEAD);
+        if (kt + AHEAD < KT) plan.issue(smem_base, kt + AHEAD, kt + AHEAD, xb, wb);
         const char* st = smem + (kt % TL::NSTAGE) * TL::STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
