@@ -63,6 +63,8 @@ def lib():
     """The loaded library; raises RuntimeError (never falls back) when it cannot be loaded."""
     global _lib
     if _lib is None:
+        if not os.path.exists(LIB_PATH) and "MST_ENGINE_LIB" not in os.environ:
+            _build_in_place()
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`. "
@@ -74,6 +76,22 @@ def lib():
             fn.argtypes = args
         _lib = l
     return _lib
+
+
+def _build_in_place():
+    """Fresh checkout (the .so is git-ignored): compile the library with hipcc where it belongs.
+    Same command as __graft_entry__.build(); failures surface as the 'missing' error above."""
+    import shutil
+    import subprocess
+    hipcc = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        return
+    try:
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH,
+                        "mst_engine.hip"], cwd=os.path.join(_HERE, "csrc"), check=True)
+    except (subprocess.CalledProcessError, OSError):
+        if os.path.exists(LIB_PATH):
+            os.remove(LIB_PATH)
 
 
 def check(rc):
