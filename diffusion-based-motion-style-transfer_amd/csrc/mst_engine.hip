@@ -160,7 +160,9 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     e->cfg = *c;
     e->S_max = c->max_frames + 1;
     size_t M = (size_t)c->max_rows * e->S_max;
-    e->M_pad = (int)(((M + 255) / 256) * 256);
+    // rows of every token-row buffer: whole 256-row tiles plus one spare tile -- a slice starts at an arbitrary row and
+    // its last tile may over-READ up to a tile beyond the slice (never write)
+    e->M_pad = (int)(((M + 255) / 256) * 256) + 256;
     e->kin_pad = ((c->feats + 31) / 32) * 32;           // K of the pose-embedding GEMM: whole 32-deep slabs,
     if (e->kin_pad < 96) e->kin_pad = 96;               // and at least the 3 slabs the ring keeps in flight
     e->nt_out = (c->feats + 255) / 256;              // output-projection tile = 256 * nt_out features
@@ -493,12 +495,12 @@ static WS ws_slice(const mst_engine* e, int r0, int T) {
 
 // K3 .. K8: token stream through the encoder stack.  rows = clips through the transformer.
 static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, int rows, int T, int temb_uniform_row, int temb_mod,
-                     hipStream_t st) {
+                     hipStream_t st, int tp_uncond = 0) {
     const int S = T + 1, M = rows * S;
     {
         ProfScope ps(e, FAM_COND, st);
         hipLaunchKernelGGL(k_cond_token, dim3((rows * MST_D + 255) / 256), dim3(256), 0, st, e->temb, temb_uniform_row,
-                           temb_mod, ws.textproj, e->pe, S, rows, ws.hx, ws.hl);
+                           temb_mod, ws.textproj, rows > clips_x ? clips_x : 0, rows > clips_x ? tp_uncond : 0, e->pe, S, rows, ws.hx, ws.hl);
         HIPCHECK(hipGetLastError());
     }
     {
@@ -603,16 +605,16 @@ extern "C" int mst_forward(mst_engine* e, const float* x, const int64_t* t, cons
     CHECK(timestep_rows(e, (const long long*)t, batch, st));
     const int rows = cfg ? 2 * batch : batch;
     const WS ws = ws_slice(e, 0, frames);
-    CHECK(run_trunk(e, ws, x, batch, rows, frames, -1, batch, st));
+    CHECK(run_trunk(e, ws, x, batch, rows, frames, -1, batch, st, batch));
     StepArgs sa{};
     sa.scale = scale;
     return launch_out_nt<0>(e, ws, cfg, batch, frames, out, sa, st);
 }
 
 extern "C" int mst_loop_slices(const mst_engine* e, int32_t batch, int32_t cfg) {
-    if (!e || e->nsplit < 2 || cfg || e->dbg_stage >= 0) return 1;
+    if (!e || e->nsplit < 2 || e->dbg_stage >= 0) return 1;
     int n = e->nsplit;
-    while (n > 1 && batch / n < 8) n--;          // at least 8 clips per slice
+    while (n > 1 && (cfg ? 2 : 1) * batch / n < 8) n--;      // at least 8 rows through the transformer per slice
     return n;
 }
 
@@ -662,9 +664,12 @@ extern "C" int mst_sample_loop(mst_engine* e, const mst_schedule* s, const mst_l
             const int nb = (c0 + per <= a->batch) ? per : a->batch - c0;
             if (nb <= 0) continue;
             const size_t eo = (size_t)c0 * per_clip;
-            const WS ws = ws_slice(e, c0, a->frames);
+            // workspace rows of the slice: its clips (cond + uncond twins under CFG); text projections are indexed
+            // in the full-batch layout [cond 0..B | uncond 0..B]
+            WS ws = ws_slice(e, a->cfg ? 2 * c0 : c0, a->frames);
+            ws.textproj = e->textproj + (size_t)c0 * MST_D;
             hipStream_t ss = streams[sl];
-            CHECK(run_trunk(e, ws, a->x_dev + eo, nb, a->cfg ? 2 * nb : nb, a->frames, ti - a->t_end, 0, ss));
+            CHECK(run_trunk(e, ws, a->x_dev + eo, nb, a->cfg ? 2 * nb : nb, a->frames, ti - a->t_end, 0, ss, a->batch));
             StepArgs sa{};
             sa.tab = s->tab;
             sa.nsteps = s->n;
@@ -673,7 +678,7 @@ extern "C" int mst_sample_loop(mst_engine* e, const mst_schedule* s, const mst_l
             sa.mask = a->inpainting_mask_dev ? a->inpainting_mask_dev + eo : nullptr;
             sa.motion = a->inpainted_motion_dev ? a->inpainted_motion_dev + eo : nullptr;
             sa.noise = a->noise_mode == MST_NOISE_BUFFER ? a->noise_dev + (size_t)j * clip_elems + eo : nullptr;
-            sa.scale = a->scale_dev;
+            sa.scale = a->scale_dev ? a->scale_dev + c0 : nullptr;
             sa.x = a->x_dev + eo;
             sa.sample = a->x_dev + eo;
             sa.xstart = a->xstart_dump_dev ? a->xstart_dump_dev + (size_t)j * clip_elems + eo : nullptr;

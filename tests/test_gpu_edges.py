@@ -75,7 +75,7 @@ def test_odd_batch_across_the_two_slices_equals_single_slice():
     from oracle import schedule
     F, T, B = 181, 76, 17
     eng, w, pe = make(F, T, B)
-    assert eng.loop_slices(B) == 2 and eng.loop_slices(B, cfg=True) == 1 and eng.loop_slices(8) == 1 and eng.loop_slices(64) == 3
+    assert eng.loop_slices(B) == 2 and eng.loop_slices(8) == 1 and eng.loop_slices(64) == 3 and eng.loop_slices(64, cfg=True) == 3
     shape = (B, F, 1, T)
     tab, tmap = schedule.make("cosine", 1000, "")
     sch = Schedule(tab, tmap, dev())
@@ -136,3 +136,29 @@ def test_argument_errors_surface_as_exceptions():
     fresh.set_text(torch.zeros(2, 512, device=dev()))
     with pytest.raises(RuntimeError, match="tensors loaded"):
         fresh.forward(x[:2], torch.zeros(2, dtype=torch.long, device=dev()))
+
+
+def test_cfg_loop_in_slices_equals_clipwise_runs():
+    """CFG with the batch split over concurrent slices: every clip must come out as when run alone."""
+    from mst_amd.engine import Schedule, SAMPLER_DDPM
+    from oracle import schedule
+    F, T, B = 181, 76, 13
+    eng, w, pe = make(F, T, 2 * B)
+    assert eng.loop_slices(B, cfg=True) == 3
+    shape = (B, F, 1, T)
+    tab, tmap = schedule.make("cosine", 1000, "")
+    sch = Schedule(tab, tmap, dev())
+    txt = cu(syn.normal(SEED, "txtc", (B, 512)))
+    x0 = cu(syn.normal(SEED, "xc", shape))
+    mask = cu(syn.root_horizontal_mask(B, F, T))
+    motion = cu(syn.normal(SEED, "mc", shape))
+    scale = cu(np.linspace(1.0, 3.0, B).astype(np.float32))
+    nz = cu(np.stack([syn.normal(SEED, f"nzc/{k}", shape) for k in range(4)]))
+    eng.set_text(txt, cfg=True)
+    whole = eng.sample_loop(sch, x0.clone(), 3, 0, SAMPLER_DDPM, cfg=True, scale=scale, mask=mask, motion=motion, noise=nz)
+    parts = []
+    for i in (0, 6, 12):
+        eng.set_text(txt[i:i + 1], cfg=True)
+        parts.append(eng.sample_loop(sch, x0[i:i + 1].clone(), 3, 0, SAMPLER_DDPM, cfg=True, scale=scale[i:i + 1],
+                                     mask=mask[i:i + 1], motion=motion[i:i + 1], noise=nz[:, i:i + 1].contiguous()))
+    assert rel_l2(torch.cat(parts).cpu().numpy(), whole[[0, 6, 12]].cpu().numpy()) < 1e-6
