@@ -2,8 +2,8 @@
 import csv, glob, sys, collections, re
 def short(n):
     n = re.sub(r"^_ZN3mst\d+", "", n)
-    for a, b in (("k_gemm_dmaILi128ELi256ELi2ELi2ELi3ELi1ENS_10RowsDirectENS_11DEpiBiasF16ILb0E", "gemm_wide(qkv/ffn1)"), ("k_gemm_dmaILi64ELi512ELi2ELi2ELi4ELi1ENS_10RowsDirectENS_11DEpiResidLNE", "gemm_ln(outproj/ffn2)"),
-                 ("k_gemmILi64ELi4ELi1ENS_6XInputENS_10EpiEmbedInE", "embed_in"), ("k_attentionILi7E", "attention7"), ("k_gemmILi64ELi3ELi1ENS_7XFramesENS_11EpiEmbedOutILi1E", "embed_out_ddpm")):
+    for a, b in (("k_qkv_attentionILi7E", "qkv_attention_fused"), ("k_gemm_dmaILi64ELi512ELi2ELi2ELi4ELi1ENS_10RowsDirectENS_11DEpiResidLNE", "gemm_ln(outproj/ffn2)"), ("DEpiBiasF16ILb1E", "ffn1_gelu_gemm"),
+                 ("DEpiEmbedInE", "embed_in_gemm"), ("DEpiEmbedOutILi1E", "embed_out_ddpm_step")):
         if a in n: return b
     return n[:40]
 for d in sys.argv[1:]:
