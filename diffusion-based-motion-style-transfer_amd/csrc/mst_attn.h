@@ -165,14 +165,18 @@ __global__ __launch_bounds__(512) void k_attention(const f16* __restrict__ qkv, 
 //   * V is written in natural order into the transposed-read image.
 // The attention core that follows is k_attention's.  `qkv` is not materialised at all.
 // ------------------------------------------------------------------------------------------------------------
+#ifndef QA_BK
+#define QA_BK 64   // same-box A/B: 64-deep slabs (whole cache lines) 38.7 vs 39.6 us per launch
+#endif
 template <int NKT>
 struct QATile {
+    static constexpr int KDEPTH = QA_BK, RB = QA_BK * 2, RPP = 1024 / RB, CPR = RB / 16;   // slab depth (see DTile)
     static constexpr int XR = NKT * 32;                 // token rows staged per slab
     static constexpr int WR = 3 * MST_HD;               // 384 weight rows: q | k | v of this head
     static constexpr int ROWS = XR + WR;
-    static constexpr int STAGE = ROWS * 64;
-    static constexpr int NSTAGE = 3;
-    static constexpr int INSTR = ROWS / 16;
+    static constexpr int STAGE = ROWS * RB;
+    static constexpr int NSTAGE = QA_BK == 64 ? 2 : 3;
+    static constexpr int INSTR = ROWS / RPP;
     static constexpr int PER = (INSTR + 7) / 8;
     static constexpr int RING = NSTAGE * STAGE;
     static constexpr int XROWS = XR;
@@ -207,24 +211,24 @@ __global__ __launch_bounds__(512) void k_qkv_attention(const f16* __restrict__ h
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[n][r] = 0.f;
 
-    constexpr int KT = MST_D / 32, AHEAD = TL::NSTAGE - 1;
+    constexpr int KT = MST_D / TL::KDEPTH, AHEAD = TL::NSTAGE - 1;
 #pragma unroll
     for (int s = 0; s < AHEAD; s++) plan.issue(smem_base, s, s, xb, wb);
     const bool active = wave < NKT;
     for (int kt = 0; kt < KT; kt++) {
-        if (KT - 1 - kt >= AHEAD - 1) wait_vmcnt<(AHEAD - 1) * TL::PER>();
+        if (AHEAD >= 2 && KT - 1 - kt >= AHEAD - 1) wait_vmcnt<(AHEAD - 1) * TL::PER>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if (kt + AHEAD < KT) plan.issue(smem_base, kt + AHEAD, kt + AHEAD, xb, wb);
         if (active) {
             const char* st = smem + (kt % TL::NSTAGE) * TL::STAGE;
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++) {
+            for (int ks = 0; ks < TL::KDEPTH / 16; ks++) {
                 const int c = ks * 2 + hh;
-                const f16x8 xf = *reinterpret_cast<const f16x8*>(st + ring_off(wave * 32 + l31, c));
+                const f16x8 xf = *reinterpret_cast<const f16x8*>(st + ring_off_rb<TL::RB>(wave * 32 + l31, c));
 #pragma unroll
                 for (int n = 0; n < 12; n++) {
-                    const f16x8 wf = *reinterpret_cast<const f16x8*>(st + ring_off(TL::XR + n * 32 + l31, c));
+                    const f16x8 wf = *reinterpret_cast<const f16x8*>(st + ring_off_rb<TL::RB>(TL::XR + n * 32 + l31, c));
                     acc[n] = mfma_f16(wf, xf, acc[n]);
                 }
             }

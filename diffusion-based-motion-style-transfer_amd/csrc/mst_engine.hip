@@ -34,6 +34,12 @@ using namespace mst;
 #endif
 #ifndef WIDE_XCD
 #define WIDE_XCD 1
+// LayerNorm GEMMs (64 x 512 tiles, one block per CU): slab depth / ring slots.  64-deep slabs move whole
+// 128-B cache lines per DMA segment; 32-deep slabs fetch every line twice, one slab apart (gemm_bench: 24.3 -> 19.5 us at K=512).
+#ifndef LN_BK
+#define LN_BK 64
+#endif
+#define LN_NS (LN_BK == 64 ? 2 : 4)
 #endif
 // launch geometry of a wide GEMM over nx token tiles x ny feature tiles (1-D when XCD-aware)
 static dim3 wide_grid(int M, int ny) {
@@ -380,18 +386,18 @@ struct ProfScope {
 };
 
 // ------------------------------------------------------------------------------------------ launches
-template <int BT, int BF, int MT, int NT, int NS, int NX, class SRC, class EPI>
+template <int BT, int BF, int MT, int NT, int NS, int NX, int BK = 32, class SRC, class EPI>
 static int launch_gemm_dma(dim3 grid, const SRC& xs, const f16* W, int ldw, int K, const EPI& epi, hipStream_t st, int xcd_ny = 0) {
-    using TL = DTile<BT, BF, MT, NT, NS, NX>;
+    using TL = DTile<BT, BF, MT, NT, NS, NX, BK>;
     static_assert(EPI::template smem_bytes<BT, BF>() <= TL::SMEM, "epilogue tile must fit the ring");
     static_assert(TL::SMEM <= 163840, "ring exceeds the 160 KiB LDS");
-    auto kern = k_gemm_dma<BT, BF, MT, NT, NS, NX, SRC, EPI>;
+    auto kern = k_gemm_dma<BT, BF, MT, NT, NS, NX, SRC, EPI, BK>;
     static bool attr_set = false;
     if (!attr_set) {
         HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TL::SMEM));
         attr_set = true;
     }
-    if (K < 32 * (NS - 1) || (K & 31)) return fail("gemm: K=%d unsupported by the %d-slot ring", K, NS);
+    if (K < BK * (NS - 1) || (K % BK)) return fail("gemm: K=%d unsupported by the %d-slot ring", K, NS);
     hipLaunchKernelGGL(kern, grid, dim3(512), TL::SMEM, st, xs, W, ldw, K, xcd_ny, epi);
     HIPCHECK(hipGetLastError());
     return 0;
@@ -537,7 +543,7 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
         {
             ProfScope ps(e, FAM_OUTPROJ_LN, st);
             DEpiResidLN epi{w.b_out, w.g1, w.be1, ws.hx, ws.hl, M};
-            CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1>(dim3((M + 63) / 64, 1), RowsDirect{ws.att, MST_D}, w.w_out, MST_D, ABL_K(MST_D), epi, st)));
+            CHECK((launch_gemm_dma<64, 512, 2, 2, LN_NS, 1, LN_BK>(dim3((M + 63) / 64, 1), RowsDirect{ws.att, MST_D}, w.w_out, MST_D, ABL_K(MST_D), epi, st)));
         }
         DBG_STOP(3)
         {
@@ -554,7 +560,7 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
         {
             ProfScope ps(e, FAM_FFN2_LN, st);
             DEpiResidLN epi{w.b2, w.g2, w.be2, ws.hx, ws.hl, M};
-            CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1>(dim3((M + 63) / 64, 1), RowsDirect{ws.hid, MST_FF}, w.w2, MST_FF, ABL_K(MST_FF), epi, st)));
+            CHECK((launch_gemm_dma<64, 512, 2, 2, LN_NS, 1, LN_BK>(dim3((M + 63) / 64, 1), RowsDirect{ws.hid, MST_FF}, w.w2, MST_FF, ABL_K(MST_FF), epi, st)));
         }
         DBG_STOP(5)
     }

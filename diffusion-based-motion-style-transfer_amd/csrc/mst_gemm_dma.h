@@ -20,21 +20,30 @@
 
 namespace mst {
 
-template <int BT, int BF, int MT, int NT, int NS = 4, int NX = 1>
+template <int BT, int BF, int MT, int NT, int NS = 4, int NX = 1, int BK = 32>
 struct DTile {
+    static_assert(BK == 32 || BK == 64, "slab depth");
+    static constexpr int KDEPTH = BK;
+    static constexpr int RB = BK * 2;                 // bytes per slab row: 64 (half a cache line) or 128 (a full line)
+    static constexpr int RPP = 1024 / RB;             // tile rows per 1-KiB DMA piece
+    static constexpr int CPR = RB / 16;               // 16-B chunks per row
     static constexpr int WT = BT / (32 * MT);       // wave rows (token direction)
     static constexpr int WN = 8 / WT;               // wave columns (feature direction)
     static_assert(WT * WN == 8 && WN * NT * 32 == BF, "8 waves must tile BT x BF");
     static constexpr int XROWS = NX * BT;           // NX = 2: a second token group (CFG: the uncond half)
     static constexpr int ROWS = XROWS + BF;
-    static constexpr int STAGE = ROWS * 64;         // bytes per 32-deep slab
+    static constexpr int STAGE = ROWS * RB;         // bytes per slab
     static constexpr int NSTAGE = NS;               // ring slots: NS - 1 slabs in flight
     static constexpr int SMEM = NSTAGE * STAGE;
-    static constexpr int INSTR = ROWS / 16;         // 1-KiB DMA pieces per slab
+    static constexpr int INSTR = ROWS / RPP;        // 1-KiB DMA pieces per slab
     static constexpr int PER = (INSTR + 7) / 8;     // pieces per wave per slab (uniform; extras duplicate)
 };
 
 __device__ __forceinline__ int ring_off(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
+// 128-B rows (64-deep slabs): two rows per 256-B bank row, chunk c of row r at c ^ ((r >> 1) & 7)
+template <int RB> __device__ __forceinline__ int ring_off_rb(int row, int c) {
+    return RB == 64 ? ring_off(row, c) : row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
+}
 
 // LDS-DMA issue.  One `global_load_lds_dwordx4` moves 1 KiB (64 lanes x 16 B): LDS destination = M0 + imm + 16 * lane,
 // global source = SGPR base + per-lane 32-bit offset + imm -- the SAME immediate is added on both sides (verified with
@@ -42,8 +51,9 @@ __device__ __forceinline__ int ring_off(int row, int c) { return row * 64 + ((c 
 // with imm = 0 / 1024 / 2048 / 3072 and the per-lane offset pre-compensated by -imm; the slab-to-slab advance is a
 // scalar add on the two operand bases.  (First version: one piece per asm statement with M0 save/set/restore and a
 // 64-bit VALU address add each -- ~150 issue cycles per piece, which is what bounded the slab loop at ~0.6 us.)
+constexpr int kMaxPer = 12;             // most 1-KiB pieces one wave issues per slab
 template <int G>
-__device__ __forceinline__ void glds_group(const unsigned (&voff)[5], const unsigned long long (&sb)[5], int j0, unsigned lds_dst) {
+__device__ __forceinline__ void glds_group(const unsigned (&voff)[kMaxPer], const unsigned long long (&sb)[kMaxPer], int j0, unsigned lds_dst) {
     unsigned keep;
     if constexpr (G == 4)
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
@@ -74,9 +84,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 constexpr unsigned kDmaBias = 4096;      // keeps (offset - imm) non-negative; subtracted from the scalar bases
 template <class TL>
 struct DmaPlan {
-    static_assert(TL::PER <= 5 && TL::INSTR >= TL::PER, "piece plan");
-    unsigned voff[5];
-    bool isx[5];
+    static_assert(TL::PER <= kMaxPer && TL::INSTR >= TL::PER, "piece plan");
+    unsigned voff[kMaxPer];
+    bool isx[kMaxPer];
     int start;
     // rowbyte(r): byte offset of tile row r inside its operand (X rows for r < XROWS, else W rows)
     template <class F>
@@ -84,26 +94,29 @@ struct DmaPlan {
         start = wave * TL::PER;
         if (start > TL::INSTR - TL::PER) start = TL::INSTR - TL::PER;   // last wave re-issues a few of its neighbour's
 #pragma unroll
-        for (int j = 0; j < 5; j++) {
+        for (int j = 0; j < kMaxPer; j++) {
             if (j < TL::PER) {
-                const int row = (start + j) * 16 + (lane >> 2);
-                const int c = (lane & 3) ^ ((row >> 2) & 3);
-                isx[j] = (start + j) * 16 < TL::XROWS;               // wave-uniform
+                const int row = (start + j) * TL::RPP + lane / TL::CPR;
+                const int c = TL::RB == 64 ? ((lane & 3) ^ ((row >> 2) & 3)) : ((lane & 7) ^ ((row >> 1) & 7));
+                isx[j] = (start + j) * TL::RPP < TL::XROWS;           // wave-uniform
                 voff[j] = rowbyte(row) + c * 16 + kDmaBias - (j & 3) * 1024;
             } else { voff[j] = 0; isx[j] = false; }
         }
     }
     // slab `ksrc` of the operands -> ring slot of slab-sequence position `kt`
     __device__ __forceinline__ void issue(unsigned smem_base, int kt, int ksrc, const char* xbase, const char* wbase) const {
-        const unsigned long long sx = (unsigned long long)(xbase + (size_t)ksrc * 64 - kDmaBias);
-        const unsigned long long sw = (unsigned long long)(wbase + (size_t)ksrc * 64 - kDmaBias);
-        unsigned long long sb[5];
+        const unsigned long long sx = (unsigned long long)(xbase + (size_t)ksrc * TL::RB - kDmaBias);
+        const unsigned long long sw = (unsigned long long)(wbase + (size_t)ksrc * TL::RB - kDmaBias);
+        unsigned long long sb[kMaxPer];
 #pragma unroll
-        for (int j = 0; j < 5; j++) sb[j] = isx[j] ? sx : sw;
+        for (int j = 0; j < kMaxPer; j++) sb[j] = isx[j] ? sx : sw;
         const unsigned base = __builtin_amdgcn_readfirstlane(smem_base + (kt % TL::NSTAGE) * TL::STAGE + start * 1024);
         if constexpr (TL::PER >= 4) glds_group<4>(voff, sb, 0, base);
         else glds_group<TL::PER>(voff, sb, 0, base);
-        if constexpr (TL::PER == 5) glds_group<1>(voff, sb, 4, base + 4096);
+        if constexpr (TL::PER >= 8) glds_group<4>(voff, sb, 4, base + 4096);
+        else if constexpr (TL::PER > 4) glds_group<TL::PER - 4>(voff, sb, 4, base + 4096);
+        if constexpr (TL::PER >= 12) glds_group<4>(voff, sb, 8, base + 8192);
+        else if constexpr (TL::PER > 8) glds_group<TL::PER - 8>(voff, sb, 8, base + 8192);
     }
 };
 
@@ -140,7 +153,7 @@ __device__ __forceinline__ void gemm_mainloop_dma(char* smem, const SRC& xs, con
     });
     const char* xb = xs.base();
     const char* wb = reinterpret_cast<const char*>(W);
-    const int KT = K >> 5;
+    const int KT = K / TL::KDEPTH;
     constexpr int AHEAD = TL::NSTAGE - 1;                    // slabs in flight
 #pragma unroll
     for (int s = 0; s < AHEAD; s++)
@@ -148,23 +161,23 @@ __device__ __forceinline__ void gemm_mainloop_dma(char* smem, const SRC& xs, con
 
     for (int kt = 0; kt < KT; kt++) {
         const int rem = KT - 1 - kt;                        // slabs already issued beyond kt: min(rem, AHEAD - 1)
-        if (rem >= AHEAD - 1) wait_vmcnt<(AHEAD - 1) * TL::PER>();
+        if (AHEAD >= 2 && rem >= AHEAD - 1) wait_vmcnt<(AHEAD >= 2 ? AHEAD - 1 : 0) * TL::PER>();
         else if (AHEAD >= 3 && rem == 1) wait_vmcnt<TL::PER>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();                       // slab kt landed for every wave; slot of slab kt-1 is free
         if (kt + AHEAD < KT) plan.issue(smem_base, kt + AHEAD, kt + AHEAD, xb, wb);
         const char* st = smem + (kt % TL::NSTAGE) * TL::STAGE;
 #pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
+        for (int ks = 0; ks < TL::KDEPTH / 16; ks++) {
             const int c = ks * 2 + (lane >> 5);
             f16x8 xf[NX][MT], wf[NT];
 #pragma unroll
             for (int x = 0; x < NX; x++)
 #pragma unroll
                 for (int m = 0; m < MT; m++)
-                    xf[x][m] = *reinterpret_cast<const f16x8*>(st + ring_off(x * BT + (wt * MT + m) * 32 + (lane & 31), c));
+                    xf[x][m] = *reinterpret_cast<const f16x8*>(st + ring_off_rb<TL::RB>(x * BT + (wt * MT + m) * 32 + (lane & 31), c));
 #pragma unroll
-            for (int n = 0; n < NT; n++) wf[n] = *reinterpret_cast<const f16x8*>(st + ring_off(TL::XROWS + (wn * NT + n) * 32 + (lane & 31), c));
+            for (int n = 0; n < NT; n++) wf[n] = *reinterpret_cast<const f16x8*>(st + ring_off_rb<TL::RB>(TL::XROWS + (wn * NT + n) * 32 + (lane & 31), c));
 #pragma unroll
             for (int x = 0; x < NX; x++)
 #pragma unroll
@@ -518,10 +531,10 @@ struct DEpiEmbedOut {
     }
 };
 
-template <int BT, int BF, int MT, int NT, int NS, int NX, class SRC, class EPI>
+template <int BT, int BF, int MT, int NT, int NS, int NX, class SRC, class EPI, int BK = 32>
 __global__ __launch_bounds__(512) void k_gemm_dma(SRC xs, const f16* __restrict__ W, int ldw, int K, int xcd_ny, EPI epi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using TL = DTile<BT, BF, MT, NT, NS, NX>;
+    using TL = DTile<BT, BF, MT, NT, NS, NX, BK>;
     int bx = blockIdx.x, by = blockIdx.y;
     if (xcd_ny > 0) {
         // XCD-aware order (1-D launch over ceil(nx/8)*8*ny ids): workgroups are dealt round-robin over the

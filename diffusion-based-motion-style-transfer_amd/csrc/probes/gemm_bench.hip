@@ -18,10 +18,10 @@ struct DEpiNone {                       // keeps the accumulators alive, writes 
     }
 };
 
-template <int BT, int BF, int MT, int NT, int NS>
+template <int BT, int BF, int MT, int NT, int NS, int BK = 32>
 float run(const f16* X, const f16* W, float* sink, int M, int N, int K, int iters) {
-    using TL = DTile<BT, BF, MT, NT, NS, 1>;
-    auto kern = k_gemm_dma<BT, BF, MT, NT, NS, 1, RowsDirect, DEpiNone>;
+    using TL = DTile<BT, BF, MT, NT, NS, 1, BK>;
+    auto kern = k_gemm_dma<BT, BF, MT, NT, NS, 1, RowsDirect, DEpiNone, BK>;
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TL::SMEM);
     dim3 grid((M + BT - 1) / BT, N / BF);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -33,9 +33,11 @@ float run(const f16* X, const f16* W, float* sink, int M, int N, int K, int iter
     return ms * 1e3f / iters;
 }
 
-#define CASE(BT, BF, MT, NT, NS)                                                                                   \
+#define CASE(BT, BF, MT, NT, NS) CASEK(BT, BF, MT, NT, NS, 32)
+#define CASEK(BT, BF, MT, NT, NS, BK)                                                                              \
     {                                                                                                              \
-        float t1 = run<BT, BF, MT, NT, NS>(X, W, sink, M, N, 512, 50), t2 = run<BT, BF, MT, NT, NS>(X, W, sink, M, N, 2048, 50); \
+        printf("BK=%d ", BK);                                                                                      \
+        float t1 = run<BT, BF, MT, NT, NS, BK>(X, W, sink, M, N, 512, 50), t2 = run<BT, BF, MT, NT, NS, BK>(X, W, sink, M, N, 2048, 50); \
         int blocks = ((M + BT - 1) / BT) * (N / BF);                                                               \
         double fl = 2.0 * M * N * 2048;                                                                            \
         printf("tile %3dx%3d wave %dx%d ring %d: blocks %4d  K=512 %7.1f us  K=2048 %7.1f us  -> %.3f us/slab, fixed %.1f us, %.0f TFLOP/s at K=2048\n", \
@@ -59,5 +61,9 @@ int main() {
     CASE(256, 256, 4, 2, 4)
     CASE(256, 256, 2, 4, 4)
     CASE(128, 128, 2, 1, 4)
+    CASEK(64, 512, 2, 2, 2, 64)
+    CASEK(128, 256, 2, 2, 2, 64)
+    CASEK(128, 256, 2, 2, 3, 64)
+    CASEK(256, 256, 4, 2, 2, 64)
     return 0;
 }
