@@ -10,6 +10,7 @@
 
 #include "../../include/mst_engine.h"
 #include "mst_attn.h"
+#include "mst_train.h"
 #include "mst_common.h"
 #include "mst_elem.h"
 #include "mst_gemm_dma.h"
@@ -81,6 +82,21 @@ struct LayerW {
     f16 *w_in = nullptr, *w_out = nullptr, *w1 = nullptr, *w2 = nullptr;
     float *b_in = nullptr, *b_out = nullptr, *b1 = nullptr, *b2 = nullptr;
     float *g1 = nullptr, *be1 = nullptr, *g2 = nullptr, *be2 = nullptr;
+    // [in][out] f16 copies: the "weights" operand of the dgrad GEMMs (training path)
+    f16 *w_inT = nullptr, *w_outT = nullptr, *w1T = nullptr, *w2T = nullptr;
+};
+
+// engine-owned scratch of the backward pass, allocated on the first training call
+struct TrainWS {
+    bool ready = false;
+    float *g0 = nullptr, *g1 = nullptr;                 // fp32 gradient stream, ping-pong
+    f16 *dbr = nullptr, *dpre = nullptr, *datt = nullptr, *dqkv = nullptr;
+    f16 *aT = nullptr, *bT = nullptr;                   // token-contiguous operands of the wgrad GEMMs
+    float* part = nullptr;                              // split-K partial products
+    float* zeros = nullptr;                             // zero bias
+    float* gscale = nullptr;                            // [0] scale applied to the incoming gradient, [1] its inverse
+    unsigned* amax = nullptr;
+    size_t mk_cap = 0, split_cap = 0;
 };
 
 enum Family { FAM_COND = 0, FAM_EMBED_IN, FAM_QKV, FAM_ATTN, FAM_OUTPROJ_LN, FAM_FFN1, FAM_FFN2_LN, FAM_EMBED_OUT, FAM_QKV_ATTN, FAM_COUNT };
@@ -104,6 +120,7 @@ struct mst_engine {
     int temb_cap = 0;
     std::vector<std::string> loaded;
     int text_batch = 0, text_cfg = 0;
+    TrainWS tw;
     int dbg_layer = -1, dbg_stage = -1;   // stop the trunk after (layer, stage); -1 = run everything
     int fuse_qkv_attn = 1;                // K4 + K5 as one kernel per (clip, head); MST_FUSE_QKV_ATTN=0 keeps them apart
     int nsplit = 3;                       // sampling loops run the batch as this many independent slices on separate streams (same-box A/B: 2: 61.2, 3: 63.0, 4: 61.1 clips/s)
@@ -187,6 +204,10 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
         CHECK(dmalloc(&w.be1, MST_D));
         CHECK(dmalloc(&w.g2, MST_D));
         CHECK(dmalloc(&w.be2, MST_D));
+        CHECK(dmalloc(&w.w_inT, (size_t)3 * MST_D * MST_D));
+        CHECK(dmalloc(&w.w_outT, (size_t)MST_D * MST_D));
+        CHECK(dmalloc(&w.w1T, (size_t)MST_FF * MST_D));
+        CHECK(dmalloc(&w.w2T, (size_t)MST_D * MST_FF));
     }
     CHECK(dmalloc(&e->w_pose_in, (size_t)MST_D * e->kin_pad));
     CHECK(dmalloc(&e->b_pose_in, MST_D));
@@ -227,7 +248,13 @@ extern "C" void mst_engine_destroy(mst_engine* e) {
     if (!e) return;
     for (int l = 0; l < e->cfg.num_layers; l++) {
         LayerW& w = e->L[l];
-        void* p[] = {w.w_in, w.w_out, w.w1, w.w2, w.b_in, w.b_out, w.b1, w.b2, w.g1, w.be1, w.g2, w.be2};
+        void* p[] = {w.w_in, w.w_out, w.w1, w.w2, w.b_in, w.b_out, w.b1, w.b2, w.g1, w.be1, w.g2, w.be2,
+                     w.w_inT, w.w_outT, w.w1T, w.w2T};
+        for (void* q : p) (void)hipFree(q);
+    }
+    {
+        TrainWS& t = e->tw;
+        void* p[] = {t.g0, t.g1, t.dbr, t.dpre, t.datt, t.dqkv, t.aT, t.bT, t.part, t.zeros, t.gscale, t.amax};
         for (void* q : p) (void)hipFree(q);
     }
     void* p[] = {e->w_pose_in, e->b_pose_in, e->w_pose_out, e->b_pose_out, e->w_t0, e->b_t0, e->w_t2, e->b_t2,
@@ -248,6 +275,11 @@ extern "C" void mst_engine_destroy(mst_engine* e) {
 // ------------------------------------------------------------------------------------------ weights
 static int put_matrix(const float* src, int N, int K, f16* dst, int Npad, int Kpad, hipStream_t st) {
     hipLaunchKernelGGL(k_convert_pad, dim3(1024), dim3(256), 0, st, src, N, K, dst, Npad, Kpad);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+static int put_matrix_t(const float* src, int N, int K, f16* dst, hipStream_t st) {      // [N][K] f32 -> [K][N] f16
+    hipLaunchKernelGGL(k_convert_transpose, dim3((K + 31) / 32, (N + 31) / 32), dim3(256), 0, st, src, N, K, dst);
     HIPCHECK(hipGetLastError());
     return 0;
 }
@@ -275,7 +307,7 @@ extern "C" int mst_load_weight(mst_engine* e, const char* name, const float* src
         if (layer < 0 || layer >= e->cfg.num_layers) return fail("mst_load_weight: layer %d out of range", layer);
         LayerW& w = e->L[layer];
         std::string r(rest);
-#define MAT(key, N_, K_, dst) if (r == key) { if (!shape_is(shape, ndim, N_, K_)) return fail("mst_load_weight: %s: bad shape", name); rc = put_matrix(src, N_, K_, dst, N_, K_, st); }
+#define MAT(key, N_, K_, dst) if (r == key) { if (!shape_is(shape, ndim, N_, K_)) return fail("mst_load_weight: %s: bad shape", name); rc = put_matrix(src, N_, K_, dst, N_, K_, st); if (!rc) rc = put_matrix_t(src, N_, K_, dst##T, st); }
 #define VEC(key, N_, dst) if (r == key) { if (!shape_is(shape, ndim, N_)) return fail("mst_load_weight: %s: bad shape", name); rc = put_vector(src, N_, dst, N_, st); }
         MAT("self_attn.in_proj_weight", 3 * MST_D, MST_D, w.w_in)
         VEC("self_attn.in_proj_bias", 3 * MST_D, w.b_in)
@@ -747,6 +779,274 @@ extern "C" int mst_philox_normal(float* out, int32_t batch, int32_t feats, int32
     int n = feats * ((frames + 3) / 4);
     hipLaunchKernelGGL(k_philox_normal, dim3((n + 255) / 256, batch), dim3(256), 0, (hipStream_t)stream, out, feats, frames,
                        (unsigned long long)seed, (unsigned)step);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ training ABI
+// The trainable encoder stack (seqTransEncoder, mdm_forstyledataset.py:539-546) in training mode.
+// Tape: per layer the activations the backward pass needs, in caller-owned memory.
+struct TapeL { f16 *qkv, *att, *z1h, *z1l, *x1h, *x1l, *pre, *hid, *z2h, *z2l; };
+struct Tape { f16* sh[17]; f16* sl[17]; TapeL L[16]; };
+static size_t tape_rows(int M) { return ((size_t)(M + 255) / 256) * 256 + 256; }     // whole tiles + one spare (over-read)
+static size_t tape_layout(char* base, int nl, size_t Mp, Tape* t) {
+    size_t off = 0;
+    auto take = [&](size_t width) { f16* p = reinterpret_cast<f16*>(base + off); off += Mp * width * 2; return p; };
+    for (int l = 0; l <= nl; l++) { t->sh[l] = take(MST_D); t->sl[l] = take(MST_D); }
+    for (int l = 0; l < nl; l++) {
+        TapeL& a = t->L[l];
+        a.qkv = take(3 * MST_D); a.att = take(MST_D);
+        a.z1h = take(MST_D); a.z1l = take(MST_D); a.x1h = take(MST_D); a.x1l = take(MST_D);
+        a.pre = take(MST_FF); a.hid = take(MST_FF);
+        a.z2h = take(MST_D); a.z2l = take(MST_D);
+    }
+    return off;
+}
+
+static Drop make_drop(uint64_t seed, int layer, int site, float p) {
+    Drop d{0u, 0u, 1.0f};
+    if (p <= 0.f) return d;
+    d.key = mix32((uint32_t)seed ^ mix32((uint32_t)(seed >> 32) + 0x9E3779B9u * (uint32_t)(layer * 4 + site + 1)));
+    const double t = (double)p * 4294967296.0;
+    d.thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+    d.inv = 1.0f / (1.0f - p);
+    return d;
+}
+
+static int train_check(mst_engine* e, int rows, int S, float p) {
+    if (!e) return fail("null engine");
+    CHECK(mst_weights_complete(e));
+    if (S < 2 || S > e->S_max) return fail("train: S=%d outside 2..%d", S, e->S_max);
+    if (rows < 1 || (size_t)rows * S > (size_t)e->cfg.max_rows * e->S_max) return fail("train: %d rows x %d tokens exceed the engine capacity", rows, S);
+    if (!(p >= 0.f && p < 1.f)) return fail("train: dropout probability %g outside [0, 1)", (double)p);
+    if ((size_t)rows * S * MST_FF >= 0xFFFFFFFFull || (size_t)rows * MST_H * S * S >= 0xFFFFFFFFull)
+        return fail("train: batch too large for the 32-bit dropout counters");
+    return 0;
+}
+
+extern "C" int64_t mst_train_tape_bytes(const mst_engine* e, int32_t rows, int32_t S) {
+    if (!e || rows < 1 || S < 1) return -1;
+    Tape t;
+    return (int64_t)tape_layout(nullptr, e->cfg.num_layers, tape_rows(rows * S), &t);
+}
+
+template <int NKT>
+static int launch_attn_train_n(const f16* qkv, f16* out, int S, int rows, Drop d, hipStream_t st) {
+    auto kern = k_attention_train<NKT>;
+    static bool attr_set = false;
+    const int smem = NKT * 32 * 256 * 2;
+    if (!attr_set) {
+        HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(rows * MST_H), dim3(512), smem, st, qkv, out, S, d);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+template <int NKT>
+static int launch_attn_bwd_n(const f16* qkv, const f16* att, const f16* datt, f16* dqkv, int S, int rows, Drop d, hipStream_t st) {
+    auto kern = k_attention_bwd<NKT>;
+    static bool attr_set = false;
+    const int smem = NKT * 32 * 256 * 2 + NKT * 32 * 8;
+    if (!attr_set) {
+        HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(rows * MST_H), dim3(512), smem, st, qkv, att, datt, dqkv, S, d);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+#define NKT_SWITCH(fn, S, ...)                                    \
+    switch (((S) + 31) / 32) {                                    \
+        case 1: return fn<1>(__VA_ARGS__);                        \
+        case 2: return fn<2>(__VA_ARGS__);                        \
+        case 3: return fn<3>(__VA_ARGS__);                        \
+        case 4: return fn<4>(__VA_ARGS__);                        \
+        case 5: return fn<5>(__VA_ARGS__);                        \
+        case 6: return fn<6>(__VA_ARGS__);                        \
+        case 7: return fn<7>(__VA_ARGS__);                        \
+    }                                                             \
+    return fail("attention: S=%d unsupported", S);
+static int launch_attn_train(const f16* qkv, f16* out, int S, int rows, Drop d, hipStream_t st) {
+    NKT_SWITCH(launch_attn_train_n, S, qkv, out, S, rows, d, st)
+}
+static int launch_attn_bwd(const f16* qkv, const f16* att, const f16* datt, f16* dqkv, int S, int rows, Drop d, hipStream_t st) {
+    NKT_SWITCH(launch_attn_bwd_n, S, qkv, att, datt, dqkv, S, rows, d, st)
+}
+
+// h_in / h_out: [rows][S][512] float32 (clip-major token rows).  mdm_forstyledataset.py:622 `self.seqTransEncoder(xseq)`
+// with nn.TransformerEncoderLayer semantics (post-norm, erf GELU, dropout p at the four sites of the layer).
+extern "C" int mst_train_forward(mst_engine* e, const float* h_in, int32_t rows, int32_t S, float p_drop, uint64_t seed,
+                                 void* tape, float* h_out, void* stream) {
+    CHECK(train_check(e, rows, S, p_drop));
+    if (!h_in || !tape || !h_out) return fail("mst_train_forward: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHECK(hipSetDevice(e->cfg.device));
+    const int M = rows * S, nl = e->cfg.num_layers;
+    Tape t;
+    tape_layout((char*)tape, nl, tape_rows(M), &t);
+    const size_t n = (size_t)M * MST_D;
+    hipLaunchKernelGGL(k_split_stream, dim3(1024), dim3(256), 0, st, h_in, n, t.sh[0], t.sl[0]);
+    HIPCHECK(hipGetLastError());
+    e->prof_now = 0;
+    for (int l = 0; l < nl; l++) {
+        const LayerW& w = e->L[l];
+        const TapeL& a = t.L[l];
+        {
+            DEpiBiasF16<false> epi{w.b_in, a.qkv, 3 * MST_D, M};
+            CHECK((launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, 3 * MST_D / 256), RowsDirect{t.sh[l], MST_D}, w.w_in, MST_D, MST_D, epi, st, WIDE_XCD ? 3 * MST_D / 256 : 0)));
+        }
+        CHECK(launch_attn_train(a.qkv, a.att, S, rows, make_drop(seed, l, 0, p_drop), st));
+        {
+            DEpiResidLNTrain epi{w.b_out, w.g1, w.be1, t.sh[l], t.sl[l], a.z1h, a.z1l, a.x1h, a.x1l, M, make_drop(seed, l, 1, p_drop)};
+            CHECK((launch_gemm_dma<64, 512, 2, 2, LN_NS, 1, LN_BK>(dim3((M + 63) / 64, 1), RowsDirect{a.att, MST_D}, w.w_out, MST_D, MST_D, epi, st)));
+        }
+        {
+            DEpiRowOp<OpFfn1Train> epi{w.b1, M, OpFfn1Train{a.pre, a.hid, MST_FF, make_drop(seed, l, 2, p_drop)}};
+            CHECK((launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, MST_FF / 256), RowsDirect{a.x1h, MST_D}, w.w1, MST_D, MST_D, epi, st, WIDE_XCD ? MST_FF / 256 : 0)));
+        }
+        {
+            DEpiResidLNTrain epi{w.b2, w.g2, w.be2, a.x1h, a.x1l, a.z2h, a.z2l, t.sh[l + 1], t.sl[l + 1], M, make_drop(seed, l, 3, p_drop)};
+            CHECK((launch_gemm_dma<64, 512, 2, 2, LN_NS, 1, LN_BK>(dim3((M + 63) / 64, 1), RowsDirect{a.hid, MST_FF}, w.w2, MST_FF, MST_FF, epi, st)));
+        }
+    }
+    hipLaunchKernelGGL(k_join_stream, dim3(1024), dim3(256), 0, st, t.sh[nl], t.sl[nl], h_out, n);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+static int train_ws(mst_engine* e) {
+    TrainWS& t = e->tw;
+    if (t.ready) return 0;
+    const size_t Mp = (size_t)e->M_pad;
+    t.mk_cap = ((Mp + 511) / 512) * 512 + 512;
+    t.split_cap = t.mk_cap / 256;
+    if (t.split_cap > 64) t.split_cap = 64;
+    CHECK(dmalloc(&t.g0, Mp * MST_D));
+    CHECK(dmalloc(&t.g1, Mp * MST_D));
+    CHECK(dmalloc(&t.dbr, Mp * MST_D));
+    CHECK(dmalloc(&t.dpre, Mp * MST_FF));
+    CHECK(dmalloc(&t.datt, Mp * MST_D));
+    CHECK(dmalloc(&t.dqkv, Mp * 3 * MST_D));
+    CHECK(dmalloc(&t.aT, (size_t)3 * MST_D * t.mk_cap));
+    CHECK(dmalloc(&t.bT, (size_t)MST_FF * t.mk_cap));
+    CHECK(dmalloc(&t.part, t.split_cap * (size_t)3 * MST_D * MST_D));
+    CHECK(dmalloc(&t.zeros, 3 * MST_D));
+    CHECK(dmalloc(&t.gscale, 2));
+    CHECK(dmalloc(&t.amax, 1));
+    t.ready = true;
+    return 0;
+}
+
+// dW[n_out][k_in] += unscale * dY^T X   (dY: [M][n_out] f16, X: [M][k_in] f16), db += unscale * colsum(dY) if db
+static int wgrad(mst_engine* e, const f16* dY, int n_out, const f16* X, int k_in, int M, float* dW, float* db, hipStream_t st) {
+    TrainWS& t = e->tw;
+    const int kchunk = M >= 4096 ? 512 : 256;
+    int nsplit = (M + kchunk - 1) / kchunk;
+    const int Mk = nsplit * kchunk;
+    if ((size_t)Mk > t.mk_cap || (size_t)nsplit > t.split_cap) return fail("wgrad: %d tokens exceed the workspace", M);
+    hipLaunchKernelGGL(k_transpose_f16, dim3(Mk / 64, n_out / 64), dim3(256), 0, st, dY, n_out, M, t.aT, Mk, db, t.gscale);
+    hipLaunchKernelGGL(k_transpose_f16, dim3(Mk / 64, k_in / 64), dim3(256), 0, st, X, k_in, M, t.bT, Mk, (float*)nullptr, t.gscale);
+    HIPCHECK(hipGetLastError());
+    using TL = DTile<128, 256, 2, 2, 3, 1>;
+    auto kern = k_gemm_splitk<128, 256, 2, 2, 3>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TL::SMEM));
+        attr_set = true;
+    }
+    static_assert(DEpiF32::smem_bytes<128, 256>() <= TL::SMEM, "epilogue tile must fit the ring");
+    const size_t nelem = (size_t)n_out * k_in;
+    DEpiF32 epi{nullptr, t.part, k_in, n_out};
+    hipLaunchKernelGGL(kern, dim3(n_out / 128, k_in / 256, nsplit), dim3(512), TL::SMEM, st, t.aT, Mk, t.bT, Mk, kchunk, nelem, epi);
+    HIPCHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_splitk_reduce, dim3(256), dim3(256), 0, st, t.part, nsplit, nelem, t.gscale, dW);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+// grads: HOST array of num_layers * 12 device pointers in nn.TransformerEncoderLayer parameter order
+// (in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias, linear1.weight, linear1.bias, linear2.weight,
+//  linear2.bias, norm1.weight, norm1.bias, norm2.weight, norm2.bias); every buffer is ACCUMULATED into.
+extern "C" int mst_train_backward(mst_engine* e, const void* tape, const float* d_out, int32_t rows, int32_t S, float p_drop,
+                                  uint64_t seed, float* d_in, float* const* grads, void* stream) {
+    CHECK(train_check(e, rows, S, p_drop));
+    if (!tape || !d_out || !grads) return fail("mst_train_backward: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHECK(hipSetDevice(e->cfg.device));
+    CHECK(train_ws(e));
+    TrainWS& w_ = e->tw;
+    const int M = rows * S, nl = e->cfg.num_layers;
+    Tape t;
+    tape_layout((char*)const_cast<void*>(tape), nl, tape_rows(M), &t);
+    const size_t n = (size_t)M * MST_D;
+    // device-side gradient scaling: max |d_out| -> [16, 32)
+    HIPCHECK(hipMemsetAsync(w_.amax, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL(k_amax, dim3(512), dim3(256), 0, st, d_out, n, w_.amax);
+    hipLaunchKernelGGL(k_grad_scale, dim3(1), dim3(1), 0, st, w_.amax, w_.gscale);
+    hipLaunchKernelGGL(k_scale_f32, dim3(1024), dim3(256), 0, st, d_out, n, w_.gscale, 0, w_.g1);
+    HIPCHECK(hipGetLastError());
+    float* gA = w_.g0;      // dz buffers
+    float* gB = w_.g1;      // gradient wrt the current layer output
+    const int ln_blocks = (M + 3) / 4 < 512 ? (M + 3) / 4 : 512;
+    e->prof_now = 0;
+    for (int l = nl - 1; l >= 0; l--) {
+        const LayerW& w = e->L[l];
+        const TapeL& a = t.L[l];
+        float* const* G = grads + (size_t)l * 12;
+        for (int i = 0; i < 12; i++) if (!G[i]) return fail("mst_train_backward: null gradient buffer (layer %d, tensor %d)", l, i);
+        // LayerNorm2 backward: gB -> dz2 (gA, fp32) and the branch gradient dbr (f16); dgamma2, dbeta2, db2
+        hipLaunchKernelGGL(k_ln_bwd, dim3(ln_blocks), dim3(256), 0, st, gB, a.z2h, a.z2l, w.g2, M, make_drop(seed, l, 3, p_drop), w_.gscale,
+                           gA, w_.dbr, G[10], G[11], G[7]);
+        HIPCHECK(hipGetLastError());
+        // dW2 += dbr^T hid
+        CHECK(wgrad(e, w_.dbr, MST_D, a.hid, MST_FF, M, G[6], nullptr, st));
+        // d pre = (dbr W2) * mask * gelu'(pre)
+        {
+            DEpiRowOp<OpGeluBwd> epi{nullptr, M, OpGeluBwd{a.pre, w_.dpre, MST_FF, make_drop(seed, l, 2, p_drop)}};
+            CHECK((launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, MST_FF / 256), RowsDirect{w_.dbr, MST_D}, w.w2T, MST_D, MST_D, epi, st, WIDE_XCD ? MST_FF / 256 : 0)));
+        }
+        // dW1 += dpre^T x1, db1 += colsum(dpre)
+        CHECK(wgrad(e, w_.dpre, MST_FF, a.x1h, MST_D, M, G[4], G[5], st));
+        // g(x1) = dpre W1 + dz2  -> gB
+        {
+            DEpiF32 epi{gA, gB, MST_D, M};
+            CHECK((launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, MST_D / 256), RowsDirect{w_.dpre, MST_FF}, w.w1T, MST_FF, MST_FF, epi, st, WIDE_XCD ? MST_D / 256 : 0)));
+        }
+        // LayerNorm1 backward: gB -> dz1 (gA), dbr = d(out-proj output); dgamma1, dbeta1, db_out
+        hipLaunchKernelGGL(k_ln_bwd, dim3(ln_blocks), dim3(256), 0, st, gB, a.z1h, a.z1l, w.g1, M, make_drop(seed, l, 1, p_drop), w_.gscale,
+                           gA, w_.dbr, G[8], G[9], G[3]);
+        HIPCHECK(hipGetLastError());
+        // dW_out += dbr^T att
+        CHECK(wgrad(e, w_.dbr, MST_D, a.att, MST_D, M, G[2], nullptr, st));
+        // d att = dbr W_out
+        {
+            DEpiBiasF16<false> epi{w_.zeros, w_.datt, MST_D, M};
+            CHECK((launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, MST_D / 256), RowsDirect{w_.dbr, MST_D}, w.w_outT, MST_D, MST_D, epi, st, WIDE_XCD ? MST_D / 256 : 0)));
+        }
+        // attention backward -> d qkv
+        CHECK(launch_attn_bwd(a.qkv, a.att, w_.datt, w_.dqkv, S, rows, make_drop(seed, l, 0, p_drop), st));
+        // dW_in += dqkv^T x_in, db_in += colsum(dqkv)
+        CHECK(wgrad(e, w_.dqkv, 3 * MST_D, t.sh[l], MST_D, M, G[0], G[1], st));
+        // g(x_in) = dqkv W_in + dz1 -> gB
+        {
+            DEpiF32 epi{gA, gB, MST_D, M};
+            CHECK((launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, MST_D / 256), RowsDirect{w_.dqkv, 3 * MST_D}, w.w_inT, 3 * MST_D, 3 * MST_D, epi, st, WIDE_XCD ? MST_D / 256 : 0)));
+        }
+    }
+    if (d_in) {
+        hipLaunchKernelGGL(k_scale_f32, dim3(1024), dim3(256), 0, st, gB, n, w_.gscale, 1, d_in);
+        HIPCHECK(hipGetLastError());
+    }
+    return 0;
+}
+
+// keep-multipliers (0 or 1/(1-p)) of the first n elements of dropout site (layer, site) under `seed`:
+// site 0 attention probabilities [(clip*4+head)][q][key], 1 out-proj output [tok][512], 2 FFN hidden [tok][1024],
+// 3 FFN output [tok][512].  Lets a test rebuild the exact masked forward in PyTorch.
+extern "C" int mst_dropout_mask(uint64_t seed, int32_t layer, int32_t site, float p, uint64_t n, float* out, void* stream) {
+    if (!out || site < 0 || site > 3 || layer < 0 || !(p >= 0.f && p < 1.f) || n >= 0xFFFFFFFFull) return fail("mst_dropout_mask: bad arguments");
+    hipLaunchKernelGGL(k_dropout_mask, dim3(1024), dim3(256), 0, (hipStream_t)stream, make_drop(seed, layer, site, p), (size_t)n, out);
     HIPCHECK(hipGetLastError());
     return 0;
 }

@@ -1,0 +1,785 @@
+// The trainable encoder stack in TRAINING mode (few_shot_style_finetune_losses, gaussian_diffusion.py:1317-1399,
+// back-propagates through the 8 `seqTransEncoder` layers of StyleDiffusion, mdm_forstyledataset.py:539-546):
+//   * forward epilogues that also write the activation tape and apply dropout,
+//   * the backward pass: LayerNorm backward, GELU backward, attention backward, dgrad / wgrad GEMMs on the
+//     same LDS-DMA main loop as the inference kernels (wgrad = split-K over the token dimension).
+// Numerics: f16 MFMA operands, fp32 accumulation; incoming gradients are rescaled on the device to a fixed
+// f16-friendly magnitude (k_grad_scale) and every fp32 result is unscaled where it is written.
+#pragma once
+#include "mst_common.h"
+#include "mst_gemm_dma.h"
+#include "mst_attn.h"
+
+namespace mst {
+
+// ------------------------------------------------------------------------------------------------------------
+// Dropout: a counter-based keep mask, regenerated (never stored) by the backward kernels.
+// Element idx of a site is kept iff mix32(idx * phi + key) >= thr; kept values are multiplied by inv = 1/(1-p).
+// thr = 0 keeps everything (eval / p = 0).  `key` mixes the call's seed, the layer and the site on the host.
+// ------------------------------------------------------------------------------------------------------------
+struct Drop { uint32_t key, thr; float inv; };
+__host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float drop_mul(const Drop& d, uint32_t idx) {
+    return mix32(idx * 0x9E3779B9u + d.key) >= d.thr ? d.inv : 0.f;
+}
+
+// d/dx of the erf GELU:  Phi(x) + x phi(x)
+__device__ __forceinline__ float gelu_grad(float x) {
+    return 0.5f * (1.0f + erf_as(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Epilogue: accumulators (+ bias) -> f16 tile in LDS -> OP on whole 16-byte row chunks (8 consecutive
+// features of one token), fully coalesced.  Same pass structure as DEpiBiasF16.
+// ------------------------------------------------------------------------------------------------------------
+template <class OP>
+struct DEpiRowOp {
+    const float* bias; int M; OP op;              // bias may be null
+    __device__ __forceinline__ int rows() const { return M; }
+    template <int BT, int BF> static constexpr int pass_rows() { return (BT * (BF * 2 + 16) <= 69632) ? BT : (BF == 512 ? 64 : 128); }
+    template <int BT, int BF> static constexpr int smem_bytes() { return pass_rows<BT, BF>() * (BF * 2 + 16); }
+    template <int BT, int BF, int MT, int NT>
+    __device__ __forceinline__ void run(f32x16 (&acc)[1][MT][NT], int tok0, int f0, char* smem) const {
+        static_assert(BF == 256 || BF == 512, "copy-out assumes 512-byte or 1-KiB tile rows");
+        constexpr int LD = BF * 2 + 16;
+        constexpr int PR = pass_rows<BT, BF>();
+        constexpr int PASSES = BT / PR;
+        constexpr int RPA = 1024 / (BF * 2);
+        DLane<BT, BF, MT, NT> lc;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int sub = RPA == 2 ? lane >> 5 : 0, col = (RPA == 2 ? (lane & 31) : lane) * 16;
+#pragma unroll
+        for (int pass = 0; pass < PASSES; pass++) {
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                const int tl = lc.tok(m);
+                if (tl / PR != pass) continue;                // wave-uniform
+                char* trow = smem + (tl - pass * PR) * LD;
+#pragma unroll
+                for (int n = 0; n < NT; n++)
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const int f = lc.feat(n, g);
+                        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+                        if (bias) b = *reinterpret_cast<const f32x4*>(bias + f0 + f);
+                        *reinterpret_cast<uint2*>(trow + f * 2) =
+                            pack4_f16(acc[0][m][n][4 * g] + b[0], acc[0][m][n][4 * g + 1] + b[1],
+                                      acc[0][m][n][4 * g + 2] + b[2], acc[0][m][n][4 * g + 3] + b[3]);
+                    }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < PR / (8 * RPA); p++) {
+                const int row = p * 8 * RPA + wave * RPA + sub;
+                const int tok = tok0 + pass * PR + row;
+                const uint4 v = *reinterpret_cast<const uint4*>(smem + row * LD + col);
+                if (tok < M) op(tok, f0 + (col >> 1), v);
+            }
+            if (pass + 1 < PASSES) __syncthreads();
+        }
+    }
+};
+
+// FFN1 in training: tile = pre-activation (f16).  Writes `pre` and hid = dropout(gelu(pre)).
+struct OpFfn1Train {
+    f16* pre; f16* hid; int ld; Drop d;
+    __device__ __forceinline__ void operator()(int tok, int c, uint4 v) const {
+        const size_t o = (size_t)tok * ld + c;
+        *reinterpret_cast<uint4*>(pre + o) = v;
+        const f16x8 p = __builtin_bit_cast(f16x8, v);
+        f16x8 h;
+#pragma unroll
+        for (int j = 0; j < 8; j++) h[j] = (f16)(gelu_erf((float)p[j]) * drop_mul(d, (uint32_t)o + j));
+        *reinterpret_cast<uint4*>(hid + o) = __builtin_bit_cast(uint4, h);
+    }
+};
+// FFN2 dgrad: tile = d hid.  out = tile * dropout-mask * gelu'(pre).
+struct OpGeluBwd {
+    const f16* pre; f16* out; int ld; Drop d;
+    __device__ __forceinline__ void operator()(int tok, int c, uint4 v) const {
+        const size_t o = (size_t)tok * ld + c;
+        const f16x8 g = __builtin_bit_cast(f16x8, v);
+        const f16x8 p = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(pre + o));
+        f16x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; j++) r[j] = (f16)((float)g[j] * drop_mul(d, (uint32_t)o + j) * gelu_grad((float)p[j]));
+        *reinterpret_cast<uint4*>(out + o) = __builtin_bit_cast(uint4, r);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// Epilogue: fp32 out (+ optional fp32 residual), row-major, coalesced through LDS in passes of 64 rows.
+// dgrad GEMMs that end in the fp32 gradient stream, and the split-K partial products of the wgrad GEMMs.
+// ------------------------------------------------------------------------------------------------------------
+struct DEpiF32 {
+    const float* resid; float* out; int ldo; int M;
+    __device__ __forceinline__ int rows() const { return M; }
+    template <int BT, int BF> static constexpr int smem_bytes() { return 64 * (BF * 4 + 16); }
+    template <int BT, int BF, int MT, int NT>
+    __device__ __forceinline__ void run(f32x16 (&acc)[1][MT][NT], int tok0, int f0, char* smem) const {
+        static_assert(BF == 256, "one wave access = one 1-KiB row");
+        constexpr int LD = BF * 4 + 16, PR = 64, PASSES = BT / PR;
+        DLane<BT, BF, MT, NT> lc;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int pass = 0; pass < PASSES; pass++) {
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                const int tl = lc.tok(m);
+                if (tl / PR != pass) continue;                // wave-uniform
+                char* trow = smem + (tl - pass * PR) * LD;
+#pragma unroll
+                for (int n = 0; n < NT; n++)
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        f32x4 v = {acc[0][m][n][4 * g], acc[0][m][n][4 * g + 1], acc[0][m][n][4 * g + 2], acc[0][m][n][4 * g + 3]};
+                        *reinterpret_cast<f32x4*>(trow + lc.feat(n, g) * 4) = v;
+                    }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < PR / 8; p++) {
+                const int row = p * 8 + wave, tok = tok0 + pass * PR + row;
+                if (tok >= M) continue;
+                f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * LD + lane * 16);
+                const size_t o = (size_t)tok * ldo + f0 + lane * 4;
+                if (resid) {
+                    const f32x4 r = *reinterpret_cast<const f32x4*>(resid + o);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[i] += r[i];
+                }
+                *reinterpret_cast<f32x4*>(out + o) = v;
+            }
+            if (pass + 1 < PASSES) __syncthreads();
+        }
+    }
+};
+
+// split-K GEMM: grid (rows / BT, cols / BF, splits); split z contracts k in [z * kchunk, (z+1) * kchunk) and
+// writes its own partial product at out + z * out_stride.
+template <int BT, int BF, int MT, int NT, int NS>
+__global__ __launch_bounds__(512) void k_gemm_splitk(const f16* __restrict__ A, int lda, const f16* __restrict__ B, int ldb,
+                                                     int kchunk, size_t out_stride, DEpiF32 epi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using TL = DTile<BT, BF, MT, NT, NS, 1>;
+    const int tok0 = blockIdx.x * BT, f0 = blockIdx.y * BF, z = blockIdx.z;
+    f32x16 acc[1][MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int n = 0; n < NT; n++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[0][m][n][r] = 0.f;
+    RowsDirect xs{A + (size_t)z * kchunk, lda};
+    gemm_mainloop_dma<TL, BT, BF, MT, NT, 1, RowsDirect>(smem, xs, B + (size_t)z * kchunk, ldb, tok0, f0, kchunk, acc);
+    epi.out += (size_t)z * out_stride;
+    epi.template run<BT, BF, MT, NT>(acc, tok0, f0, smem);
+}
+
+// grad[i] += unscale * sum_z part[z][i]
+__global__ void k_splitk_reduce(const float* __restrict__ part, int nsplit, size_t n, const float* __restrict__ gscale,
+                                float* __restrict__ grad) {
+    const float inv = gscale[1];
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < nsplit; z++) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(part + (size_t)z * n + i);
+#pragma unroll
+            for (int j = 0; j < 4; j++) s[j] += v[j];
+        }
+        f32x4 g = *reinterpret_cast<const f32x4*>(grad + i);
+#pragma unroll
+        for (int j = 0; j < 4; j++) g[j] += inv * s[j];
+        *reinterpret_cast<f32x4*>(grad + i) = g;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Training variant of DEpiResidLN: y = LN(z), z = resid + dropout(acc + bias); residual read from (rin),
+// z and y written to their own tape slots (hi/lo pairs).
+// ------------------------------------------------------------------------------------------------------------
+struct DEpiResidLNTrain {
+    const float* bias; const float* gamma; const float* beta;
+    const f16* rin_hi; const f16* rin_lo; f16* z_hi; f16* z_lo; f16* y_hi; f16* y_lo; int M; Drop d;
+    __device__ __forceinline__ int rows() const { return M; }
+    template <int BT, int BF> static constexpr int smem_bytes() { return BT * (MST_D * 4 + 16); }
+    template <int BT, int BF, int MT, int NT>
+    __device__ __forceinline__ void run(f32x16 (&acc)[1][MT][NT], int tok0, int f0, char* smem) const {
+        static_assert(BF == MST_D, "LayerNorm needs the whole row in one block");
+        constexpr int LD = MST_D * 4 + 16;
+        DLane<BT, BF, MT, NT> lc;
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            char* trow = smem + lc.tok(m) * LD;
+#pragma unroll
+            for (int n = 0; n < NT; n++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    f32x4 v = {acc[0][m][n][4 * g], acc[0][m][n][4 * g + 1], acc[0][m][n][4 * g + 2], acc[0][m][n][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(trow + lc.feat(n, g) * 4) = v;
+                }
+        }
+        __syncthreads();
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int fa = lane * 4, fb = 256 + lane * 4;
+        const f32x4 ba = *reinterpret_cast<const f32x4*>(bias + fa), bb = *reinterpret_cast<const f32x4*>(bias + fb);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + fa), gb = *reinterpret_cast<const f32x4*>(gamma + fb);
+        const f32x4 ea = *reinterpret_cast<const f32x4*>(beta + fa), eb = *reinterpret_cast<const f32x4*>(beta + fb);
+        constexpr int RPW = BT / 8;
+        for (int r = 0; r < RPW; r++) {
+            const int row = wave * RPW + r, tok = tok0 + row;
+            if (tok >= M) continue;                            // wave-uniform
+            const size_t off = (size_t)tok * MST_D;
+            f32x4 xa = join4_f16(*reinterpret_cast<const uint2*>(rin_hi + off + fa), *reinterpret_cast<const uint2*>(rin_lo + off + fa));
+            f32x4 xb = join4_f16(*reinterpret_cast<const uint2*>(rin_hi + off + fb), *reinterpret_cast<const uint2*>(rin_lo + off + fb));
+            const f32x4 ta = *reinterpret_cast<const f32x4*>(smem + row * LD + fa * 4);
+            const f32x4 tb = *reinterpret_cast<const f32x4*>(smem + row * LD + fb * 4);
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                xa[i] += (ta[i] + ba[i]) * drop_mul(d, (uint32_t)(off + fa + i));
+                xb[i] += (tb[i] + bb[i]) * drop_mul(d, (uint32_t)(off + fb + i));
+                s += xa[i] + xb[i];
+            }
+            uint2 h, l;
+            split4_f16(xa, h, l);
+            *reinterpret_cast<uint2*>(z_hi + off + fa) = h;
+            *reinterpret_cast<uint2*>(z_lo + off + fa) = l;
+            split4_f16(xb, h, l);
+            *reinterpret_cast<uint2*>(z_hi + off + fb) = h;
+            *reinterpret_cast<uint2*>(z_lo + off + fb) = l;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            const float mean = s * (1.0f / MST_D);
+            float s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                xa[i] -= mean;
+                xb[i] -= mean;
+                s2 += xa[i] * xa[i] + xb[i] * xb[i];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
+            const float rstd = 1.0f / sqrtf(s2 * (1.0f / MST_D) + 1e-5f);
+            f32x4 ya, yb;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                ya[i] = xa[i] * rstd * ga[i] + ea[i];
+                yb[i] = xb[i] * rstd * gb[i] + eb[i];
+            }
+            split4_f16(ya, h, l);
+            *reinterpret_cast<uint2*>(y_hi + off + fa) = h;
+            *reinterpret_cast<uint2*>(y_lo + off + fa) = l;
+            split4_f16(yb, h, l);
+            *reinterpret_cast<uint2*>(y_hi + off + fb) = h;
+            *reinterpret_cast<uint2*>(y_lo + off + fb) = l;
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// Elementwise / row-wise helpers of the training path
+// ------------------------------------------------------------------------------------------------------------
+// fp32 rows -> hi/lo pair
+__global__ void k_split_stream(const float* __restrict__ in, size_t n, f16* __restrict__ hi, f16* __restrict__ lo) {
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(in + i);
+        uint2 h, l;
+        split4_f16(v, h, l);
+        *reinterpret_cast<uint2*>(hi + i) = h;
+        *reinterpret_cast<uint2*>(lo + i) = l;
+    }
+}
+
+// max |g| -> amax (float bits, non-negative -> unsigned order = float order)
+__global__ void k_amax(const float* __restrict__ g, size_t n, unsigned* __restrict__ amax) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float a = fabsf(g[i]);
+        m = a > m ? a : m;                               // NaN never wins: the scale stays finite
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(m));
+}
+// gscale[0] = power of two s with max|g| * s in [16, 32);  gscale[1] = 1 / s
+__global__ void k_grad_scale(const unsigned* __restrict__ amax, float* __restrict__ gscale) {
+    const float a = __uint_as_float(*amax);
+    float s = 1.0f;
+    if (a > 0.f && a < INFINITY) s = exp2f(floorf(log2f(32.0f / a)) - 0.0f);
+    if (!(s > 0.f) || s == INFINITY) s = 1.0f;
+    gscale[0] = s;
+    gscale[1] = 1.0f / s;
+}
+__global__ void k_scale_f32(const float* __restrict__ in, size_t n, const float* __restrict__ gscale, int which, float* __restrict__ out) {
+    const float s = gscale[which];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i] * s;
+}
+
+// LayerNorm backward for rows y = LN(z) * gamma + beta with z = resid + dropout(branch):
+//   dz  = rstd * (gamma g - mean(gamma g) - xhat mean(gamma g xhat))                 (fp32, the residual gradient)
+//   dbr = dz * dropout-mask                                                            (f16, the branch gradient = GEMM operand)
+//   dgamma += sum_rows g xhat,  dbeta += sum_rows g,  dbias += sum_rows dbr            (unscaled, atomics)
+// One wave per row; lane owns features [4 lane, +4) and [256 + 4 lane, +4).
+__global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ g, const f16* __restrict__ z_hi, const f16* __restrict__ z_lo,
+                                                const float* __restrict__ gamma, int M, Drop d, const float* __restrict__ gscale,
+                                                float* __restrict__ dz, f16* __restrict__ dbr,
+                                                float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias) {
+    __shared__ float red[3][4][MST_D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fa = lane * 4, fb = 256 + lane * 4;
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + fa), gb = *reinterpret_cast<const f32x4*>(gamma + fb);
+    f32x4 dga = {0.f, 0.f, 0.f, 0.f}, dgb = dga, dba = dga, dbb = dga, dca = dga, dcb = dga;
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        const size_t off = (size_t)row * MST_D;
+        f32x4 xa = join4_f16(*reinterpret_cast<const uint2*>(z_hi + off + fa), *reinterpret_cast<const uint2*>(z_lo + off + fa));
+        f32x4 xb = join4_f16(*reinterpret_cast<const uint2*>(z_hi + off + fb), *reinterpret_cast<const uint2*>(z_lo + off + fb));
+        const f32x4 ya = *reinterpret_cast<const f32x4*>(g + off + fa), yb = *reinterpret_cast<const f32x4*>(g + off + fb);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) s += xa[i] + xb[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s * (1.0f / MST_D);
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            xa[i] -= mean;
+            xb[i] -= mean;
+            s2 += xa[i] * xa[i] + xb[i] * xb[i];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
+        const float rstd = 1.0f / sqrtf(s2 * (1.0f / MST_D) + 1e-5f);
+        float c1 = 0.f, c2 = 0.f;
+        f32x4 aa, ab;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            xa[i] *= rstd;                                   // xhat
+            xb[i] *= rstd;
+            aa[i] = ga[i] * ya[i];
+            ab[i] = gb[i] * yb[i];
+            c1 += aa[i] + ab[i];
+            c2 += aa[i] * xa[i] + ab[i] * xb[i];
+            dga[i] += ya[i] * xa[i];
+            dgb[i] += yb[i] * xb[i];
+            dba[i] += ya[i];
+            dbb[i] += yb[i];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            c1 += __shfl_xor(c1, o);
+            c2 += __shfl_xor(c2, o);
+        }
+        c1 *= (1.0f / MST_D);
+        c2 *= (1.0f / MST_D);
+        f32x4 za, zb, ra, rb;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            za[i] = rstd * (aa[i] - c1 - xa[i] * c2);
+            zb[i] = rstd * (ab[i] - c1 - xb[i] * c2);
+            ra[i] = za[i] * drop_mul(d, (uint32_t)(off + fa + i));
+            rb[i] = zb[i] * drop_mul(d, (uint32_t)(off + fb + i));
+            dca[i] += ra[i];
+            dcb[i] += rb[i];
+        }
+        *reinterpret_cast<f32x4*>(dz + off + fa) = za;
+        *reinterpret_cast<f32x4*>(dz + off + fb) = zb;
+        *reinterpret_cast<uint2*>(dbr + off + fa) = pack4_f16(ra[0], ra[1], ra[2], ra[3]);
+        *reinterpret_cast<uint2*>(dbr + off + fb) = pack4_f16(rb[0], rb[1], rb[2], rb[3]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        red[0][wave][fa + i] = dga[i]; red[0][wave][fb + i] = dgb[i];
+        red[1][wave][fa + i] = dba[i]; red[1][wave][fb + i] = dbb[i];
+        red[2][wave][fa + i] = dca[i]; red[2][wave][fb + i] = dcb[i];
+    }
+    __syncthreads();
+    const float inv = gscale[1];
+    for (int i = threadIdx.x; i < 3 * MST_D; i += 256) {
+        const int a = i / MST_D, f = i - a * MST_D;
+        const float v = (red[a][0][f] + red[a][1][f] + red[a][2][f] + red[a][3][f]) * inv;
+        float* dst = a == 0 ? dgamma : (a == 1 ? dbeta : dbias);
+        atomicAdd(dst + f, v);
+    }
+}
+
+// in [M][N] (row stride ld_in) f16 -> out [N][ld_out] f16 (token-contiguous rows, zero for tokens in [M, ld_out)):
+// the K-contiguous operands of the wgrad GEMMs.  colsum != null: colsum[n] += unscale * sum_rows in[row][n]
+// (bias gradients).  Block = 64 tokens x 64 features.
+__global__ __launch_bounds__(256) void k_transpose_f16(const f16* __restrict__ in, int ld_in, int M, f16* __restrict__ out, int ld_out,
+                                                       float* __restrict__ colsum, const float* __restrict__ gscale) {
+    __shared__ f16 tile[64][72];
+    __shared__ float cs[4][64];
+    const int t0 = blockIdx.x * 64, n0 = blockIdx.y * 64, tid = threadIdx.x;
+#pragma unroll
+    for (int q = tid; q < 512; q += 256) {
+        const int r = q >> 3, ch = q & 7;
+        uint4 v = {0, 0, 0, 0};
+        if (t0 + r < M) v = *reinterpret_cast<const uint4*>(in + (size_t)(t0 + r) * ld_in + n0 + ch * 8);
+        *reinterpret_cast<uint4*>(&tile[r][ch * 8]) = v;
+    }
+    __syncthreads();
+    if (colsum) {
+        const int c = tid & 63, part = tid >> 6;
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) s += (float)tile[part * 16 + r][c];
+        cs[part][c] = s;
+    }
+#pragma unroll
+    for (int q = tid; q < 512; q += 256) {
+        const int n = q >> 3, ch = q & 7;                   // feature row n, tokens 8 ch .. 8 ch + 7
+        f16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = tile[ch * 8 + j][n];
+        *reinterpret_cast<uint4*>(out + (size_t)(n0 + n) * ld_out + t0 + ch * 8) = __builtin_bit_cast(uint4, v);
+    }
+    if (colsum) {
+        __syncthreads();
+        if (tid < 64) atomicAdd(colsum + n0 + tid, (cs[0][tid] + cs[1][tid] + cs[2][tid] + cs[3][tid]) * gscale[1]);
+    }
+}
+
+// [N][K] float32 -> [K][N] f16 (transposed weight copies: the "weights" operand of the dgrad GEMMs)
+__global__ void k_convert_transpose(const float* __restrict__ src, int N, int K, f16* __restrict__ dst) {
+    __shared__ float tile[32][33];
+    const int n0 = blockIdx.y * 32, k0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) tile[j][tx] = (n0 + j < N && k0 + tx < K) ? src[(size_t)(n0 + j) * K + k0 + tx] : 0.f;
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (k0 + j < K && n0 + tx < N) dst[(size_t)(k0 + j) * N + n0 + tx] = (f16)tile[tx][j];
+}
+
+// debug / tests: the keep-multiplier of `n` consecutive elements of a site
+__global__ void k_dropout_mask(Drop d, size_t n, float* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = drop_mul(d, (uint32_t)i);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Attention in training: forward with dropout on the probabilities, and the backward pass.
+// Dropout index of P[q][key] of (clip, head): ((clip * 4 + head) * S + q) * S + key.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t p_index(int ch, int S, int q, int key) { return ((uint32_t)ch * S + q) * S + key; }
+
+// forward: k_attention (mst_attn.h) + dropout on P.  Both K and V use the transposed-read image layout.
+template <int NKT>
+__global__ __launch_bounds__(512) void k_attention_train(const f16* __restrict__ qkv, f16* __restrict__ out, int S, Drop d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KEYS = NKT * 32;
+    char* ks = smem;
+    char* vs = smem + KEYS * 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int clip = blockIdx.x / MST_H, head = blockIdx.x % MST_H;
+    const f16* base = qkv + (size_t)clip * S * (3 * MST_D) + head * MST_HD;
+    for (int q = tid; q < KEYS * 16; q += 512) {
+        int row = q >> 4, ch = q & 15;
+        uint4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
+        if (row < S) {
+            const f16* p = base + (size_t)row * (3 * MST_D) + ch * 8;
+            kv = *reinterpret_cast<const uint4*>(p + MST_D);
+            vv = *reinterpret_cast<const uint4*>(p + 2 * MST_D);
+        }
+        *reinterpret_cast<uint4*>(ks + k_off(row, ch)) = kv;
+        *reinterpret_cast<uint4*>(vs + v_off(row, ch * 8)) = vv;
+    }
+    __syncthreads();
+    if (wave >= NKT) return;
+    const int hh = lane >> 5;
+    const int q_idx = wave * 32 + (lane & 31);
+    const int q_ld = q_idx < S ? q_idx : S - 1;
+    f16x8 qf[8];
+    {
+        const f16* qp = base + (size_t)q_ld * (3 * MST_D) + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 8; s++) qf[s] = *reinterpret_cast<const f16x8*>(qp + s * 16);
+    }
+    f32x16 sc[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; kt++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) sc[kt][r] = 0.f;
+        const int row = kt * 32 + (lane & 31);
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            f16x8 kf = *reinterpret_cast<const f16x8*>(ks + k_off(row, 2 * s + hh));
+            sc[kt] = mfma_f16(kf, qf[s], sc[kt]);
+        }
+    }
+    const float scale = 0.08838834764831845f;
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; kt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float v = sc[kt][r] * scale;
+            if (kt == NKT - 1) {
+                int key = kt * 32 + mfma_row(r, lane);
+                if (key >= S) v = -INFINITY;
+            }
+            sc[kt][r] = v;
+            m = fmaxf(m, v);
+        }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; kt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float p = __expf(sc[kt][r] - m);
+            sc[kt][r] = p;
+            l += p;
+        }
+    l += __shfl_xor(l, 32);
+    const float inv_l = 1.0f / l;
+    const int ch = clip * MST_H + head;
+    f16x8 pf[NKT][2];
+#pragma unroll
+    for (int kt = 0; kt < NKT; kt++)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int key = kt * 32 + mfma_row(8 * s2 + j, lane);
+                pf[kt][s2][j] = (f16)(sc[kt][8 * s2 + j] * inv_l * drop_mul(d, p_index(ch, S, q_idx, key)));
+            }
+    const int i16 = lane & 15, g = lane >> 4;
+    const int key_lane = 4 * hh + (i16 >> 2);
+    const int d_lane = 16 * (g & 1) + 4 * (i16 & 3);
+    f16* orow = out + ((size_t)clip * S + q_ld) * MST_D + head * MST_HD;
+#pragma unroll
+    for (int dt = 0; dt < 4; dt++) {
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; kt++)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) {
+                int key = kt * 32 + 16 * s2 + key_lane;
+                int dd = dt * 32 + d_lane;
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vs + v_off(key, dd)));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vs + v_off(key + 8, dd)));
+                const f16x4 lo_h = __builtin_bit_cast(f16x4, lo), hi_h = __builtin_bit_cast(f16x4, hi);
+                f16x8 vf = __builtin_shufflevector(lo_h, hi_h, 0, 1, 2, 3, 4, 5, 6, 7);
+                o = mfma_f16(vf, pf[kt][s2], o);
+            }
+        if (q_idx < S) {
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                int dd = dt * 32 + 8 * gq + 4 * hh;
+                *reinterpret_cast<uint2*>(orow + dd) = pack4_f16(o[4 * gq], o[4 * gq + 1], o[4 * gq + 2], o[4 * gq + 3]);
+            }
+        }
+    }
+}
+
+// image helpers: [row][128] f16 in the transposed-read layout (v_off); both access patterns work on it
+__device__ __forceinline__ f16x8 img_row_frag(const char* img, int row, int s, int hh) {       // d = 16 s + 8 hh .. + 8
+    return *reinterpret_cast<const f16x8*>(img + v_off(row, 16 * s + 8 * hh));
+}
+// A-operand fragment of img^T for MFMA k-step (tile t, half s2) and d tile dt: lane (d = dt*32 + l31) receives
+// rows t*32 + 16 s2 + 4 hh + {0..3} and + 8 + {0..3} -- the permuted k order the accumulator-as-operand trick needs.
+__device__ __forceinline__ f16x8 img_tr_frag(const char* img, int t, int s2, int dt, int lane) {
+    const int hh = lane >> 5, i16 = lane & 15, g = lane >> 4;
+    const int row = t * 32 + 16 * s2 + 4 * hh + (i16 >> 2);
+    const int dd = dt * 32 + 16 * (g & 1) + 4 * (i16 & 3);
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(img + v_off(row, dd)));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(img + v_off(row + 8, dd)));
+    const f16x4 lo_h = __builtin_bit_cast(f16x4, lo), hi_h = __builtin_bit_cast(f16x4, hi);
+    return __builtin_shufflevector(lo_h, hi_h, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ void stage_image(char* img, const f16* src, size_t row_stride, int S, int KEYS, int tid) {
+    for (int q = tid; q < KEYS * 16; q += 512) {
+        const int row = q >> 4, ch = q & 15;
+        uint4 v = {0, 0, 0, 0};
+        if (row < S) v = *reinterpret_cast<const uint4*>(src + (size_t)row * row_stride + ch * 8);
+        *reinterpret_cast<uint4*>(img + v_off(row, ch * 8)) = v;
+    }
+}
+
+// Backward of one (clip, head):  with P = softmax(Q K^T * scale), Pd = dropout(P), O = Pd V:
+//   dV = Pd^T dO,  dPd = dO V^T,  dP = dPd * mask,  dS = P (dP - D) * scale with D_q = sum_d dO[q][d] O[q][d],
+//   dQ = dS K,  dK = dS^T Q.
+// Pass 1 (wave = 32-query tile, lane = query; K, V images in LDS): row statistics, dQ.
+// Pass 2 (wave = 32-key tile, lane = key; Q, dO images in LDS): dK, dV.  P is recomputed in both passes.
+template <int NKT>
+__global__ __launch_bounds__(512) void k_attention_bwd(const f16* __restrict__ qkv, const f16* __restrict__ att,
+                                                       const f16* __restrict__ datt, f16* __restrict__ dqkv, int S, Drop d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KEYS = NKT * 32;
+    char* img0 = smem;
+    char* img1 = smem + KEYS * 256;
+    float* lse_s = reinterpret_cast<float*>(smem + 2 * KEYS * 256);
+    float* dq_s = lse_s + KEYS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hh = lane >> 5, l31 = lane & 31;
+    const int clip = blockIdx.x / MST_H, head = blockIdx.x % MST_H, ch = clip * MST_H + head;
+    const f16* base = qkv + (size_t)clip * S * (3 * MST_D) + head * MST_HD;
+    const f16* obase = att + (size_t)clip * S * MST_D + head * MST_HD;
+    const f16* dobase = datt + (size_t)clip * S * MST_D + head * MST_HD;
+    f16* dbase = dqkv + (size_t)clip * S * (3 * MST_D) + head * MST_HD;
+    const float scale = 0.08838834764831845f;
+
+    // ---------------- pass 1: K -> img0, V -> img1
+    stage_image(img0, base + MST_D, 3 * MST_D, S, KEYS, tid);
+    stage_image(img1, base + 2 * MST_D, 3 * MST_D, S, KEYS, tid);
+    __syncthreads();
+    if (wave < NKT) {
+        const int q_idx = wave * 32 + l31, q_ld = q_idx < S ? q_idx : S - 1;
+        f16x8 qf[8], dof[8];
+        float D = 0.f;
+        {
+            const f16* qp = base + (size_t)q_ld * (3 * MST_D) + 8 * hh;
+            const f16* dp = dobase + (size_t)q_ld * MST_D + 8 * hh;
+            const f16* op = obase + (size_t)q_ld * MST_D + 8 * hh;
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                qf[s] = *reinterpret_cast<const f16x8*>(qp + s * 16);
+                dof[s] = *reinterpret_cast<const f16x8*>(dp + s * 16);
+                const f16x8 of = *reinterpret_cast<const f16x8*>(op + s * 16);
+#pragma unroll
+                for (int j = 0; j < 8; j++) D += (float)dof[s][j] * (float)of[j];
+            }
+        }
+        D += __shfl_xor(D, 32);
+        f32x16 sc[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; kt++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) sc[kt][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 8; s++) sc[kt] = mfma_f16(img_row_frag(img0, kt * 32 + l31, s, hh), qf[s], sc[kt]);
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; kt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                float v = sc[kt][r] * scale;
+                if (kt == NKT - 1 && kt * 32 + mfma_row(r, lane) >= S) v = -INFINITY;
+                sc[kt][r] = v;
+                m = fmaxf(m, v);
+            }
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; kt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float p = __expf(sc[kt][r] - m);
+                sc[kt][r] = p;
+                l += p;
+            }
+        l += __shfl_xor(l, 32);
+        const float inv_l = 1.0f / l;
+        if (hh == 0) {
+            lse_s[q_idx] = q_idx < S ? m + __logf(l) : INFINITY;     // padded queries: P = exp(s - inf) = 0 in pass 2
+            dq_s[q_idx] = D;
+        }
+        f16x8 dsf[NKT][2];
+#pragma unroll
+        for (int kt = 0; kt < NKT; kt++) {
+            f32x16 dp;
+#pragma unroll
+            for (int r = 0; r < 16; r++) dp[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 8; s++) dp = mfma_f16(img_row_frag(img1, kt * 32 + l31, s, hh), dof[s], dp);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int key = kt * 32 + mfma_row(r, lane);
+                const float mul = drop_mul(d, p_index(ch, S, q_idx, key));
+                dsf[kt][r >> 3][r & 7] = (f16)(sc[kt][r] * inv_l * (dp[r] * mul - D) * scale);
+            }
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++) {
+            f32x16 o;
+#pragma unroll
+            for (int r = 0; r < 16; r++) o[r] = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NKT; kt++)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++) o = mfma_f16(img_tr_frag(img0, kt, s2, dt, lane), dsf[kt][s2], o);
+            if (q_idx < S) {
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++)
+                    *reinterpret_cast<uint2*>(dbase + (size_t)q_idx * (3 * MST_D) + dt * 32 + 8 * gq + 4 * hh) =
+                        pack4_f16(o[4 * gq], o[4 * gq + 1], o[4 * gq + 2], o[4 * gq + 3]);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------- pass 2: Q -> img0, dO -> img1
+    stage_image(img0, base, 3 * MST_D, S, KEYS, tid);
+    stage_image(img1, dobase, MST_D, S, KEYS, tid);
+    __syncthreads();
+    if (wave >= NKT) return;
+    {
+        const int key_idx = wave * 32 + l31, key_ld = key_idx < S ? key_idx : S - 1;
+        const bool key_ok = key_idx < S;
+        f16x8 kf[8], vf[8];
+        {
+            const f16* kp = base + (size_t)key_ld * (3 * MST_D) + MST_D + 8 * hh;
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                kf[s] = *reinterpret_cast<const f16x8*>(kp + s * 16);
+                vf[s] = *reinterpret_cast<const f16x8*>(kp + MST_D + s * 16);
+            }
+        }
+        f32x16 dk[4], dv[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+#pragma unroll 1
+        for (int qt = 0; qt < NKT; qt++) {
+            f32x16 s_, dp;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { s_[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                s_ = mfma_f16(img_row_frag(img0, qt * 32 + l31, s, hh), kf[s], s_);
+                dp = mfma_f16(img_row_frag(img1, qt * 32 + l31, s, hh), vf[s], dp);
+            }
+            f16x8 pdf[2], dsf[2];
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                const int q0 = qt * 32 + 8 * gq + 4 * hh;
+                const f32x4 ls = *reinterpret_cast<const f32x4*>(lse_s + q0), dd = *reinterpret_cast<const f32x4*>(dq_s + q0);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int r = 4 * gq + i;
+                    float p = key_ok ? __expf(s_[r] * scale - ls[i]) : 0.f;
+                    const float mul = drop_mul(d, p_index(ch, S, q0 + i, key_idx));
+                    pdf[r >> 3][r & 7] = (f16)(p * mul);
+                    dsf[r >> 3][r & 7] = (f16)(p * (dp[r] * mul - dd[i]) * scale);
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++) {
+                    dv[dt] = mfma_f16(img_tr_frag(img1, qt, s2, dt, lane), pdf[s2], dv[dt]);
+                    dk[dt] = mfma_f16(img_tr_frag(img0, qt, s2, dt, lane), dsf[s2], dk[dt]);
+                }
+        }
+        if (key_ok) {
+            f16* krow = dbase + (size_t)key_idx * (3 * MST_D) + MST_D;
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {
+                    const int dd = dt * 32 + 8 * gq + 4 * hh;
+                    *reinterpret_cast<uint2*>(krow + dd) = pack4_f16(dk[dt][4 * gq], dk[dt][4 * gq + 1], dk[dt][4 * gq + 2], dk[dt][4 * gq + 3]);
+                    *reinterpret_cast<uint2*>(krow + MST_D + dd) = pack4_f16(dv[dt][4 * gq], dv[dt][4 * gq + 1], dv[dt][4 * gq + 2], dv[dt][4 * gq + 3]);
+                }
+        }
+    }
+}
+
+}  // namespace mst

@@ -162,6 +162,46 @@ class DenoiserEngine:
                                     N.stream_ptr(self.device)))
         return out
 
+    # ------------------------------------------------------------------------------ training
+    def train_tape(self, rows, S):
+        """Uninitialised activation tape for one train_forward of `rows` clips x S tokens (caller-owned)."""
+        n = N.lib().mst_train_tape_bytes(self.handle, rows, S)
+        if n <= 0:
+            raise RuntimeError("mst_train_tape_bytes failed")
+        return torch.empty(n, dtype=torch.uint8, device=self.device)
+
+    def train_forward(self, h, p_drop, seed, tape=None):
+        """h: [rows, S, 512] float32 -> (encoder-stack output [rows, S, 512], tape)."""
+        h = _f32c(h, self.device, "h")
+        rows, S, d = h.shape
+        if tape is None:
+            tape = self.train_tape(rows, S)
+        out = torch.empty_like(h)
+        N.check(N.lib().mst_train_forward(self.handle, N.ptr(h), rows, S, float(p_drop), int(seed), N.ptr(tape), N.ptr(out),
+                                          N.stream_ptr(self.device)))
+        return out, tape
+
+    def train_backward(self, tape, d_out, p_drop, seed, grads, need_input_grad=True):
+        """grads: num_layers*12 float32 GPU tensors in LAYER_TENSORS order per layer, accumulated into.
+        Returns dL/dh [rows, S, 512] (or None)."""
+        d_out = _f32c(d_out, self.device, "d_out")
+        rows, S, d = d_out.shape
+        if len(grads) != self.num_layers * 12:
+            raise ValueError(f"expected {self.num_layers * 12} gradient buffers, got {len(grads)}")
+        for g in grads:
+            if g.dtype != torch.float32 or not g.is_contiguous() or g.device != d_out.device:
+                raise ValueError("gradient buffers must be contiguous float32 tensors on the engine's device")
+        arr = (C.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
+        d_in = torch.empty_like(d_out) if need_input_grad else None
+        N.check(N.lib().mst_train_backward(self.handle, N.ptr(tape), N.ptr(d_out), rows, S, float(p_drop), int(seed),
+                                           N.ptr(d_in), arr, N.stream_ptr(self.device)))
+        return d_in
+
+    def dropout_mask(self, seed, layer, site, p, n):
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        N.check(N.lib().mst_dropout_mask(int(seed), layer, site, float(p), n, N.ptr(out), N.stream_ptr(self.device)))
+        return out
+
     # ------------------------------------------------------------------------------ sampling
     def sample_loop(self, schedule, x, t_start, t_end=0, sampler=SAMPLER_DDPM, eta=0.0, cfg=False, scale=None,
                     mask=None, motion=None, mask_noise=True, clip_denoised=False, noise=None, seed=None,

@@ -182,6 +182,36 @@ int mst_step_epilogue(const mst_schedule* s, const float* model_out_dev, const f
 int mst_philox_normal(float* out_dev, int32_t batch, int32_t feats, int32_t frames, uint64_t seed,
                       uint32_t step, void* stream);
 
+/* -------------------------------------------------------------------------------------------
+ * Training path of the TRAINABLE encoder stack: StyleDiffusion.seqTransEncoder, 8 x
+ * nn.TransformerEncoderLayer(d_model=512, nhead=4, dim_feedforward=1024, dropout=0.1, gelu),
+ * model/mdm_forstyledataset.py:539-546, called at :622 inside the graph that
+ * few_shot_style_finetune_losses (diffusion/gaussian_diffusion.py:1317-1399) back-propagates
+ * through.  Replaces the torch autograd graph of that call:
+ *   mst_train_forward   forward in model.train() semantics: dropout p at the four sites of each
+ *                       layer (attention probabilities, out-proj output, FFN hidden, FFN output),
+ *                       masks drawn from a counter-based generator keyed by `seed`; writes the
+ *                       activation tape into caller-owned memory of mst_train_tape_bytes() bytes.
+ *   mst_train_backward  given dL/d(h_out): dL/d(h_in) and the 96 parameter gradients, ACCUMULATED
+ *                       (+=) into the caller's float32 buffers.  `grads` is a HOST array of
+ *                       num_layers*12 device pointers in nn.TransformerEncoderLayer parameter order:
+ *                       self_attn.in_proj_weight, .in_proj_bias, self_attn.out_proj.weight, .bias,
+ *                       linear1.weight, .bias, linear2.weight, .bias, norm1.weight, .bias,
+ *                       norm2.weight, .bias.  rows / S / p_drop / seed must repeat the forward's.
+ * h_in, h_out, d_out, d_in: float32 [rows][S][512] (clip-major; the reference's [S, B, 512] permuted).
+ * The engine's weights are the ones last uploaded with mst_load_weight.
+ * mst_dropout_mask: the keep-multipliers (0 or 1/(1-p)) of the first n elements of site
+ * (layer, site 0..3) -- lets a test rebuild the masked forward exactly in PyTorch.
+ * ----------------------------------------------------------------------------------------- */
+int64_t mst_train_tape_bytes(const mst_engine* e, int32_t rows, int32_t S);
+int mst_train_forward(mst_engine* e, const float* h_in_dev, int32_t rows, int32_t S, float p_drop,
+                      uint64_t seed, void* tape_dev, float* h_out_dev, void* stream);
+int mst_train_backward(mst_engine* e, const void* tape_dev, const float* d_out_dev, int32_t rows,
+                       int32_t S, float p_drop, uint64_t seed, float* d_in_dev,
+                       float* const* grads_host_array, void* stream);
+int mst_dropout_mask(uint64_t seed, int32_t layer, int32_t site, float p, uint64_t n, float* out_dev,
+                     void* stream);
+
 /* Per-kernel device timing of the most recent mst_sample_loop / mst_forward when profiling is
  * enabled: HIP events recorded around every launch on the caller's stream.  names/ms are arrays
  * of `cap` entries filled with per-kernel-family totals; returns the number of families. */

@@ -1,0 +1,187 @@
+"""GPU parity of the native TRAINING path of the trainable encoder stack (mst_train_forward /
+mst_train_backward, include/mst_engine.h) against a plain PyTorch fp32 implementation of the same
+eight post-norm layers (nn.TransformerEncoderLayer semantics, model/mdm_forstyledataset.py:539-546 of
+the reference) evaluated on the GPU with torch autograd.
+
+Dropout is checked EXACTLY: the engine's counter-based keep masks are read back through
+mst_dropout_mask and applied at the same four sites of the PyTorch layers, so forward and backward
+can be compared value by value at p = 0.1 (the reference's training setting).
+
+Tolerances: the engine multiplies with f16 MFMA operands (fp32 accumulation); the forward bar is the
+north_star's 1e-3 relative L2; gradients pass through ~2x as many rounded products (recomputed
+probabilities, dgrad and wgrad operands), bar 4e-3 relative L2 per tensor."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import mst_amd  # noqa: F401
+from mst_amd import synthetic as syn
+from mst_amd.engine import LAYER_TENSORS
+from conftest import SEED, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL_FWD = 1e-3
+TOL_GRAD = 4e-3
+SHAPES = {"xia": (181, 76), "hml": (263, 196)}
+L, D, H = 8, 512, 4
+
+
+def _dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch.device("cuda:0")
+
+
+_ENGINES = {}
+
+
+def engine_for(tag, max_rows=4):
+    from mst_amd.engine import DenoiserEngine
+    if tag not in _ENGINES:
+        Fe, T = SHAPES[tag]
+        eng = DenoiserEngine(Fe, T, max_rows, device=_dev())
+        w = syn.denoiser_state(SEED, Fe, layer_prefix="seqTransEncoder.layers.")
+        eng.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, layer_prefix="seqTransEncoder.layers.",
+                            pe=torch.from_numpy(syn.positional_table(5000, 512)))
+        _ENGINES[tag] = (eng, w)
+    return _ENGINES[tag]
+
+
+def layer_params(w, requires_grad):
+    out = []
+    for i in range(L):
+        for k in LAYER_TENSORS:
+            t = torch.from_numpy(w[f"seqTransEncoder.layers.{i}.{k}"]).to(_dev()).clone()
+            out.append(t.requires_grad_(requires_grad))
+    return out
+
+
+def torch_stack(h, params, masks=None):
+    """Eight post-norm encoder layers in fp32; h: [B, S, 512].  masks[l] = (m0 [B,4,S,S], m1 [B,S,512],
+    m2 [B,S,1024], m3 [B,S,512]) keep-multipliers or None."""
+    B, S, _ = h.shape
+    x = h
+    for l in range(L):
+        win, bin_, wout, bout, w1, b1, w2, b2, g1, be1, g2, be2 = params[12 * l:12 * l + 12]
+        m = masks[l] if masks is not None else (None,) * 4
+        qkv = x @ win.t() + bin_
+        q, k, v = qkv.view(B, S, 3, H, D // H).permute(2, 0, 3, 1, 4)          # [B, H, S, hd]
+        p = torch.softmax((q * (D // H) ** -0.5) @ k.transpose(-1, -2), dim=-1)
+        if m[0] is not None:
+            p = p * m[0]
+        att = (p @ v).permute(0, 2, 1, 3).reshape(B, S, D)
+        o = att @ wout.t() + bout
+        if m[1] is not None:
+            o = o * m[1]
+        x1 = F.layer_norm(x + o, (D,), g1, be1, 1e-5)
+        hid = F.gelu(x1 @ w1.t() + b1)
+        if m[2] is not None:
+            hid = hid * m[2]
+        f = hid @ w2.t() + b2
+        if m[3] is not None:
+            f = f * m[3]
+        x = F.layer_norm(x1 + f, (D,), g2, be2, 1e-5)
+    return x
+
+
+def stream_input(tag, rows):
+    Fe, T = SHAPES[tag]
+    S = T + 1
+    h = syn.normal(SEED, f"train/{tag}/h", (rows, S, D)).astype(np.float32)
+    r = syn.normal(SEED, f"train/{tag}/r", (rows, S, D)).astype(np.float32)
+    return S, torch.from_numpy(h).to(_dev()), torch.from_numpy(r).to(_dev())
+
+
+def engine_masks(eng, seed, p, rows, S):
+    out = []
+    for l in range(L):
+        out.append((eng.dropout_mask(seed, l, 0, p, rows * H * S * S).view(rows, H, S, S),
+                    eng.dropout_mask(seed, l, 1, p, rows * S * D).view(rows, S, D),
+                    eng.dropout_mask(seed, l, 2, p, rows * S * 1024).view(rows, S, 1024),
+                    eng.dropout_mask(seed, l, 3, p, rows * S * D).view(rows, S, D)))
+    return out
+
+
+def test_dropout_mask_statistics():
+    eng, _ = engine_for("xia")
+    p, n = 0.1, 1 << 20
+    m = eng.dropout_mask(1234, 0, 2, p, n)
+    vals = torch.unique(m).cpu().numpy()
+    assert len(vals) == 2 and vals[0] == 0.0 and abs(vals[1] - 1.0 / (1.0 - p)) < 1e-6
+    keep = float((m > 0).float().mean())
+    assert abs(keep - (1 - p)) < 4 * np.sqrt(p * (1 - p) / n), keep          # 4 sigma
+    assert torch.equal(m, eng.dropout_mask(1234, 0, 2, p, n))                  # a pure function of (seed, site, index)
+    for other in (eng.dropout_mask(1235, 0, 2, p, n), eng.dropout_mask(1234, 1, 2, p, n), eng.dropout_mask(1234, 0, 3, p, n)):
+        agree = float(((m > 0) == (other > 0)).float().mean())
+        assert abs(agree - (p * p + (1 - p) ** 2)) < 5e-3, agree              # independent streams
+    assert float(eng.dropout_mask(7, 3, 1, 0.0, 4096).min()) == 1.0            # p = 0 keeps everything
+
+
+@pytest.mark.parametrize("tag,rows", [("xia", 3), ("hml", 2)])
+def test_train_forward_p0(tag, rows):
+    eng, w = engine_for(tag)
+    S, h, _ = stream_input(tag, rows)
+    out, _ = eng.train_forward(h, 0.0, 0)
+    with torch.no_grad():
+        ref = torch_stack(h, layer_params(w, False))
+    err = rel_l2(out.cpu().numpy(), ref.cpu().numpy())
+    assert err <= TOL_FWD, err
+
+
+@pytest.mark.parametrize("tag,rows,p", [("xia", 3, 0.0), ("hml", 2, 0.0), ("xia", 3, 0.1), ("hml", 2, 0.1)])
+def test_train_backward_vs_autograd(tag, rows, p):
+    eng, w = engine_for(tag)
+    S, h, r = stream_input(tag, rows)
+    seed = 0x1234ABCD5678
+    # reference: autograd through the fp32 PyTorch layers with the engine's masks
+    params = layer_params(w, True)
+    href = h.clone().requires_grad_(True)
+    masks = engine_masks(eng, seed, p, rows, S) if p > 0 else None
+    ref = torch_stack(href, params, masks)
+    (ref * r).sum().backward()
+    # engine
+    out, tape = eng.train_forward(h, p, seed)
+    grads = [torch.zeros_like(q) for q in params]
+    d_in = eng.train_backward(tape, r, p, seed, grads)
+    errs = {"out": rel_l2(out.cpu().numpy(), ref.detach().cpu().numpy()),
+            "d_in": rel_l2(d_in.cpu().numpy(), href.grad.cpu().numpy())}
+    assert errs["out"] <= TOL_FWD, errs
+    for i, (g, q) in enumerate(zip(grads, params)):
+        errs[f"L{i // 12}.{LAYER_TENSORS[i % 12]}"] = rel_l2(g.cpu().numpy(), q.grad.cpu().numpy())
+    worst = max(errs, key=errs.get)
+    assert errs[worst] <= TOL_GRAD, (worst, errs[worst], {k: round(v, 5) for k, v in errs.items()})
+
+
+def test_train_backward_accumulates_and_rescales():
+    """Gradient buffers are accumulated into (+=), and the device-side rescaling makes tiny upstream
+    gradients (2^-30 ~ 1e-9) exactly as accurate as O(1) ones: f16 operands never see the raw magnitude
+    (a power-of-two factor changes no rounding, so the results agree to fp32 round-off)."""
+    eng, w = engine_for("xia")
+    S, h, r = stream_input("xia", 2)
+    out, tape = eng.train_forward(h, 0.0, 0)
+    params = layer_params(w, False)
+    g1 = [torch.zeros_like(q) for q in params]
+    d1 = eng.train_backward(tape, r, 0.0, 0, g1)
+    g2 = [g.clone() for g in g1]
+    tiny = 2.0 ** -30
+    d2 = eng.train_backward(tape, r * tiny, 0.0, 0, g2)
+    assert rel_l2((d2 / tiny).cpu().numpy(), d1.cpu().numpy()) < 1e-6
+    for a, b in zip(g1, g2):
+        assert rel_l2(b.cpu().numpy(), (a * (1 + tiny)).cpu().numpy()) < 1e-6
+    g3 = [g.clone() for g in g1]
+    eng.train_backward(tape, r, 0.0, 0, g3, need_input_grad=False)
+    for a, b in zip(g1, g3):
+        assert rel_l2(b.cpu().numpy(), (2 * a).cpu().numpy()) < 1e-5
+
+
+def test_train_argument_errors():
+    eng, _ = engine_for("xia")
+    S, h, r = stream_input("xia", 2)
+    with pytest.raises(RuntimeError, match="dropout probability"):
+        eng.train_forward(h, 1.0, 0)
+    with pytest.raises(RuntimeError, match="exceed the engine capacity"):
+        eng.train_forward(torch.zeros(64, S, D, device=_dev()), 0.0, 0)
+    out, tape = eng.train_forward(h, 0.0, 0)
+    with pytest.raises(ValueError, match="gradient buffers"):
+        eng.train_backward(tape, r, 0.0, 0, [torch.zeros(1, device=_dev())])
