@@ -7,8 +7,11 @@ Two execution paths per module:
   * inference (no autograd graph needed): `forward` hands x, t and the text embedding to the native
     engine (csrc/, one HIP launch sequence); sampling loops bypass even that and run whole loops
     natively (see diffusion/gaussian_diffusion.py).  Weights are re-uploaded when parameters change.
-  * autograd (fine-tuning, model.train()): the same parameters are evaluated with torch ops on the
-    GPU so gradients exist -- the native backward is later-round work.
+  * autograd (fine-tuning, model.train()): the trainable encoder stack is ONE autograd node backed by
+    the engine's training kernels (model/native_stack.py: activation tape + dropout forward, HIP
+    backward); the frozen projections around it are a handful of torch ops.  `train_backend = "torch"`
+    on an instance evaluates the stack with torch ops instead (the tests' fp32 reference, and the
+    CPU-only gloo tests of the gradient reducer).
 CLIP stays third-party: `encode_text` uses the `clip` package when it is installed, a callable set
 with `set_text_encoder`, or a precomputed `y['text_embed']` ([B, clip_dim]).
 """
@@ -143,6 +146,21 @@ class _EngineHost:
         self.mst_prepare(eng, y, False)
         return eng.forward(x, timesteps)
 
+    train_backend = "native"          # or "torch" (explicit opt-in; see the module docstring)
+
+    def _encoder_stack(self, seq):
+        """seqTransEncoder(seq) inside an autograd graph; seq: [S, B, d]."""
+        if self.train_backend == "torch":
+            return self.seqTransEncoder(seq)
+        if self.train_backend != "native":
+            raise ValueError(f"train_backend must be 'native' or 'torch', not {self.train_backend!r}")
+        if seq.device.type != "cuda":
+            raise RuntimeError("the native training path runs on the GPU only; call .to('cuda') "
+                               "(set train_backend = 'torch' explicitly to evaluate the stack with torch ops)")
+        from .native_stack import EncoderStackFn, stack_parameters
+        p = self.seqTransEncoder.layers[0].dropout.p if self.seqTransEncoder.training else 0.0
+        return EncoderStackFn.apply(seq, self, float(p), *stack_parameters(self.seqTransEncoder))
+
     def _wants_autograd(self, x):
         return torch.is_grad_enabled() and (self.training or x.requires_grad
                                             or any(p.requires_grad for p in self.parameters()))
@@ -238,7 +256,7 @@ class MDM(nn.Module, _EngineHost):
             return self._native_forward(x, timesteps, y)
         emb = self._condition(timesteps, y)
         seq = self.sequence_pos_encoder(torch.cat((emb, self.input_process(x)), axis=0))
-        return self.output_process(self.seqTransEncoder(seq)[1:])
+        return self.output_process(self._encoder_stack(seq)[1:])
 
     def train(self, mode=True):
         return super().train(mode)
@@ -379,4 +397,4 @@ class StyleDiffusion(nn.Module, _EngineHost):
         enc = y['text_embed'] if y.get('text_embed') is not None else prior.encode_text(y['text'])
         emb = emb + prior.embed_text(self.mask_cond(enc, force_mask=y.get('uncond', False)))
         seq = prior.sequence_pos_encoder(torch.cat((emb, prior.input_process(x)), axis=0))
-        return prior.output_process(self.seqTransEncoder(seq)[1:])
+        return prior.output_process(self._encoder_stack(seq)[1:])

@@ -25,6 +25,7 @@ def _model():
     sd = {k: torch.from_numpy(syn.tensor_for(3, k, tuple(v.shape)).copy()) for k, v in m.state_dict().items()
           if not k.endswith(".pe") and "clip_model" not in k}
     m.load_state_dict(sd, strict=False)
+    m.train_backend = "torch"      # CPU ranks: the subject here is the reducer, not the kernels
     return m.train()
 
 

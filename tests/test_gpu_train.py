@@ -9,7 +9,8 @@ can be compared value by value at p = 0.1 (the reference's training setting).
 
 Tolerances: the engine multiplies with f16 MFMA operands (fp32 accumulation); the forward bar is the
 north_star's 1e-3 relative L2; gradients pass through ~2x as many rounded products (recomputed
-probabilities, dgrad and wgrad operands), bar 4e-3 relative L2 per tensor."""
+probabilities, dgrad and wgrad operands): measured <= 7e-4 on every one of the 96 tensors and on dL/dh
+(tools/train_errs.py), bar 1.5e-3 relative L2 per tensor."""
 import numpy as np
 import pytest
 import torch
@@ -23,7 +24,7 @@ from conftest import SEED, rel_l2
 pytestmark = pytest.mark.gpu
 
 TOL_FWD = 1e-3
-TOL_GRAD = 4e-3
+TOL_GRAD = 1.5e-3
 SHAPES = {"xia": (181, 76), "hml": (263, 196)}
 L, D, H = 8, 512, 4
 
@@ -185,3 +186,71 @@ def test_train_argument_errors():
     out, tape = eng.train_forward(h, 0.0, 0)
     with pytest.raises(ValueError, match="gradient buffers"):
         eng.train_backward(tape, r, 0.0, 0, [torch.zeros(1, device=_dev())])
+
+
+# ------------------------------------------------------------------------------ through the model boundary
+def _style_model(dropout=0.1):
+    from mst_amd.model.mdm_forstyledataset import StyleDiffusion
+    m = StyleDiffusion("", 181, 1, 1, True, "rot6d", True, True, latent_dim=512, ff_size=1024, num_layers=8, num_heads=4,
+                       dropout=dropout, activation="gelu", data_rep="hml_vec", cond_mode="text", cond_mask_prob=0.0,
+                       arch="trans_enc", dataset="stylexia_posrot")
+    sd = {k: torch.from_numpy(syn.tensor_for(3, k, tuple(v.shape)).copy()) for k, v in m.state_dict().items()
+          if not k.endswith(".pe") and "clip_model" not in k}
+    m.load_state_dict(sd, strict=False)
+    return m.to(_dev())
+
+
+def _model_batch(B=3, T=76):
+    x = torch.from_numpy(syn.normal(3, "tr/x", (B, 181, 1, T))).to(_dev())
+    t = torch.tensor([5, 400, 900][:B], device=_dev())
+    y = {"text_embed": torch.from_numpy(syn.normal(3, "tr/emb", (B, 512))).to(_dev())}
+    tgt = torch.from_numpy(syn.normal(3, "tr/tgt", (B, 181, 1, T))).to(_dev())
+    return x, t, y, tgt
+
+
+def test_model_autograd_native_vs_torch_ops():
+    """StyleDiffusion.forward inside an autograd graph: the native stack node (default) against the same
+    module evaluated with torch ops (train_backend='torch'), eval mode (no dropout)."""
+    m = _style_model().eval()
+    x, t, y, tgt = _model_batch()
+    res = {}
+    for backend in ("native", "torch"):
+        m.train_backend = backend
+        m.zero_grad()
+        xin = x.clone().requires_grad_(True)
+        out = m(xin, t, y=y)
+        loss = ((out - tgt) ** 2).mean()
+        loss.backward()
+        res[backend] = (out.detach(), float(loss), xin.grad.clone(),
+                        {n: p.grad.clone() for n, p in m.named_parameters() if p.requires_grad})
+    m.train_backend = "native"
+    assert rel_l2(res["native"][0].cpu().numpy(), res["torch"][0].cpu().numpy()) <= TOL_FWD
+    assert abs(res["native"][1] - res["torch"][1]) <= 1e-3 * abs(res["torch"][1])
+    assert rel_l2(res["native"][2].cpu().numpy(), res["torch"][2].cpu().numpy()) <= TOL_GRAD
+    assert len(res["native"][3]) == 96
+    for n, g in res["torch"][3].items():
+        assert rel_l2(res["native"][3][n].cpu().numpy(), g.cpu().numpy()) <= TOL_GRAD, n
+
+
+def test_model_training_mode_dropout_is_seeded():
+    m = _style_model().train()
+    x, t, y, tgt = _model_batch()
+
+    def run(seed):
+        torch.manual_seed(seed)
+        m.zero_grad()
+        loss = ((m(x, t, y=y) - tgt) ** 2).mean()
+        loss.backward()
+        g = m.seqTransEncoder.layers[3].linear1.weight.grad.clone()
+        return float(loss), g
+
+    a, b, c = run(5), run(5), run(6)
+    assert a[0] == b[0] and torch.equal(a[1], b[1])                 # same torch seed -> same masks
+    assert a[0] != c[0]
+    assert torch.isfinite(a[1]).all() and float(a[1].abs().max()) > 0
+    m.eval()
+    with torch.no_grad():
+        e1, e2 = m(x, t, y=y), m(x, t, y=y)
+    assert torch.equal(e1, e2)                                       # inference path: no dropout
+    with pytest.raises(RuntimeError, match="GPU only"):
+        _style_model().cpu().train()(x.cpu(), t.cpu(), y={"text_embed": y["text_embed"].cpu()})
