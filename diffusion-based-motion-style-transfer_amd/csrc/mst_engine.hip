@@ -91,12 +91,11 @@ struct TrainWS {
     bool ready = false;
     float *g0 = nullptr, *g1 = nullptr;                 // fp32 gradient stream, ping-pong
     f16 *dbr = nullptr, *dpre = nullptr, *datt = nullptr, *dqkv = nullptr;
-    f16 *aT = nullptr, *bT = nullptr;                   // token-contiguous operands of the wgrad GEMMs
     float* part = nullptr;                              // split-K partial products
     float* zeros = nullptr;                             // zero bias
     float* gscale = nullptr;                            // [0] scale applied to the incoming gradient, [1] its inverse
     unsigned* amax = nullptr;
-    size_t mk_cap = 0, split_cap = 0;
+    size_t split_cap = 0;
 };
 
 enum Family { FAM_COND = 0, FAM_EMBED_IN, FAM_QKV, FAM_ATTN, FAM_OUTPROJ_LN, FAM_FFN1, FAM_FFN2_LN, FAM_EMBED_OUT, FAM_QKV_ATTN, FAM_COUNT };
@@ -254,7 +253,7 @@ extern "C" void mst_engine_destroy(mst_engine* e) {
     }
     {
         TrainWS& t = e->tw;
-        void* p[] = {t.g0, t.g1, t.dbr, t.dpre, t.datt, t.dqkv, t.aT, t.bT, t.part, t.zeros, t.gscale, t.amax};
+        void* p[] = {t.g0, t.g1, t.dbr, t.dpre, t.datt, t.dqkv, t.part, t.zeros, t.gscale, t.amax};
         for (void* q : p) (void)hipFree(q);
     }
     void* p[] = {e->w_pose_in, e->b_pose_in, e->w_pose_out, e->b_pose_out, e->w_t0, e->b_t0, e->w_t2, e->b_t2,
@@ -919,17 +918,13 @@ static int train_ws(mst_engine* e) {
     TrainWS& t = e->tw;
     if (t.ready) return 0;
     const size_t Mp = (size_t)e->M_pad;
-    t.mk_cap = ((Mp + 511) / 512) * 512 + 512;
-    t.split_cap = t.mk_cap / 256;
-    if (t.split_cap > 64) t.split_cap = 64;
+    t.split_cap = 64;
     CHECK(dmalloc(&t.g0, Mp * MST_D));
     CHECK(dmalloc(&t.g1, Mp * MST_D));
     CHECK(dmalloc(&t.dbr, Mp * MST_D));
     CHECK(dmalloc(&t.dpre, Mp * MST_FF));
     CHECK(dmalloc(&t.datt, Mp * MST_D));
     CHECK(dmalloc(&t.dqkv, Mp * 3 * MST_D));
-    CHECK(dmalloc(&t.aT, (size_t)3 * MST_D * t.mk_cap));
-    CHECK(dmalloc(&t.bT, (size_t)MST_FF * t.mk_cap));
     CHECK(dmalloc(&t.part, t.split_cap * (size_t)3 * MST_D * MST_D));
     CHECK(dmalloc(&t.zeros, 3 * MST_D));
     CHECK(dmalloc(&t.gscale, 2));
@@ -941,27 +936,32 @@ static int train_ws(mst_engine* e) {
 // dW[n_out][k_in] += unscale * dY^T X   (dY: [M][n_out] f16, X: [M][k_in] f16), db += unscale * colsum(dY) if db
 static int wgrad(mst_engine* e, const f16* dY, int n_out, const f16* X, int k_in, int M, float* dW, float* db, hipStream_t st) {
     TrainWS& t = e->tw;
-    const int kchunk = M >= 4096 ? 512 : 256;
-    int nsplit = (M + kchunk - 1) / kchunk;
-    const int Mk = nsplit * kchunk;
-    if ((size_t)Mk > t.mk_cap || (size_t)nsplit > t.split_cap) return fail("wgrad: %d tokens exceed the workspace", M);
-    hipLaunchKernelGGL(k_transpose_f16, dim3(Mk / 64, n_out / 64), dim3(256), 0, st, dY, n_out, M, t.aT, Mk, db, t.gscale);
-    hipLaunchKernelGGL(k_transpose_f16, dim3(Mk / 64, k_in / 64), dim3(256), 0, st, X, k_in, M, t.bT, Mk, (float*)nullptr, t.gscale);
-    HIPCHECK(hipGetLastError());
-    using TL = DTile<128, 256, 2, 2, 3, 1>;
-    auto kern = k_gemm_splitk<128, 256, 2, 2, 3>;
+    // ~one block per CU: tiles x splits ~ 256; every split contracts a whole number of 32-token slabs
+    const int tiles = (n_out / 128) * (k_in / 256);
+    int nsplit = (256 + tiles - 1) / tiles;
+    const int slabs = (M + 31) / 32;
+    if (nsplit > slabs) nsplit = slabs;
+    if ((size_t)nsplit > t.split_cap) nsplit = (int)t.split_cap;
+    const int kchunk = ((slabs + nsplit - 1) / nsplit) * 32;
+    nsplit = (M + kchunk - 1) / kchunk;
+    auto kern = k_wgrad_tr;
     static bool attr_set = false;
     if (!attr_set) {
-        HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TL::SMEM));
+        HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, WgTile::SMEM));
         attr_set = true;
     }
-    static_assert(DEpiF32::smem_bytes<128, 256>() <= TL::SMEM, "epilogue tile must fit the ring");
+    static_assert(DEpiF32::smem_bytes<128, 256>() <= WgTile::SMEM, "epilogue tile must fit the ring");
     const size_t nelem = (size_t)n_out * k_in;
     DEpiF32 epi{nullptr, t.part, k_in, n_out};
-    hipLaunchKernelGGL(kern, dim3(n_out / 128, k_in / 256, nsplit), dim3(512), TL::SMEM, st, t.aT, Mk, t.bT, Mk, kchunk, nelem, epi);
+    hipLaunchKernelGGL(kern, dim3(n_out / 128, k_in / 256, nsplit), dim3(512), WgTile::SMEM, st, dY, n_out, X, k_in, M, kchunk, nelem, epi);
     HIPCHECK(hipGetLastError());
     hipLaunchKernelGGL(k_splitk_reduce, dim3(256), dim3(256), 0, st, t.part, nsplit, nelem, t.gscale, dW);
     HIPCHECK(hipGetLastError());
+    if (db) {
+        const int rpb = 128;
+        hipLaunchKernelGGL(k_colsum_f16, dim3(n_out / 256, (M + rpb - 1) / rpb), dim3(256), 0, st, dY, n_out, M, rpb, t.gscale, db);
+        HIPCHECK(hipGetLastError());
+    }
     return 0;
 }
 

@@ -303,7 +303,10 @@ __global__ void k_amax(const float* __restrict__ g, size_t n, unsigned* __restri
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(m));
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(amax, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
 }
 // gscale[0] = power of two s with max|g| * s in [16, 32);  gscale[1] = 1 / s
 __global__ void k_grad_scale(const unsigned* __restrict__ amax, float* __restrict__ gscale) {
@@ -780,6 +783,141 @@ __global__ __launch_bounds__(512) void k_attention_bwd(const f16* __restrict__ q
                 }
         }
     }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// wgrad without transposed copies:  dW[r][c] = sum_tok dY[tok][r] * X[tok][c]  contracts over the ROW index of two
+// row-major activations.  32-token slabs of dY[:, r0:r0+128] and X[:, c0:c0+256] stream through the LDS-DMA ring as
+// three [32 tokens][128 features] images in the transposed-read layout (v_off); BOTH MFMA operands are then read with
+// ds_read_b64_tr_b16, which hands every lane 4 consecutive tokens of its feature -- the k order
+// slot(hh, j) <-> token 16 ks + 8 (j >> 2) + 4 hh + (j & 3) is the same on both sides, so any order is a valid
+// contraction.  (First version: k_transpose_f16 copies + the ordinary K-contiguous GEMM: 92 us of transposes per layer.)
+// Grid (n_out / 128, k_in / 256, splits): split z contracts tokens [z * kchunk, (z + 1) * kchunk) and writes its own
+// fp32 partial; rows past M in the last slab are zeroed in LDS (the tape's pad rows are uninitialised memory).
+// ------------------------------------------------------------------------------------------------------------
+struct WgTile {
+    static constexpr int BLK = 32 * 256;                 // one [32][128] f16 image
+    static constexpr int STAGE = 3 * BLK;                // dY block + two X blocks
+    static constexpr int NSTAGE = 3;
+    static constexpr int SMEM = NSTAGE * STAGE;
+    static constexpr int PER = 3;                        // 1-KiB pieces per wave per slab (24 / 8)
+};
+
+__global__ __launch_bounds__(512) void k_wgrad_tr(const f16* __restrict__ dY, int n_out, const f16* __restrict__ X, int k_in,
+                                                  int M, int kchunk, size_t out_stride, DEpiF32 epi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using TL = WgTile;
+    constexpr int BT = 128, BF = 256, MT = 2, NT = 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r0 = blockIdx.x * BT, c0 = blockIdx.y * BF, z = blockIdx.z;
+    const int k0 = z * kchunk;
+    int ntok = M - k0;
+    if (ntok > kchunk) ntok = kchunk;
+    const int KT = ntok > 0 ? (ntok + 31) >> 5 : 0;
+    const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    // DMA plan: piece pid = 3 wave + j covers tokens 4 q .. 4 q + 3 of image blk (pid = 8 blk + q)
+    unsigned voff[kMaxPer];
+    bool isy[kMaxPer];
+#pragma unroll
+    for (int j = 0; j < kMaxPer; j++) {
+        voff[j] = 0;
+        isy[j] = false;
+        if (j < TL::PER) {
+            const int pid = wave * TL::PER + j, blk = pid >> 3, q = pid & 7;
+            const int tok = 4 * q + (lane >> 4), c = lane & 15, piece = c >> 2, sub = c & 3;
+            const int feat = ((piece ^ (tok & 3)) << 5) + (sub << 3);          // swizzle applied on the SOURCE side
+            isy[j] = blk == 0;
+            const unsigned ld = blk == 0 ? (unsigned)n_out : (unsigned)k_in;
+            const unsigned fb = blk == 0 ? (unsigned)r0 : (unsigned)(c0 + 128 * (blk - 1));
+            voff[j] = ((unsigned)tok * ld + fb + feat) * 2u + kDmaBias - (unsigned)(j & 3) * 1024u;
+        }
+    }
+    const char* yb = reinterpret_cast<const char*>(dY) + (size_t)k0 * n_out * 2;
+    const char* xb = reinterpret_cast<const char*>(X) + (size_t)k0 * k_in * 2;
+    auto issue = [&](int kt) {
+        const unsigned long long sy = (unsigned long long)(yb + (size_t)kt * 32 * n_out * 2 - kDmaBias);
+        const unsigned long long sx = (unsigned long long)(xb + (size_t)kt * 32 * k_in * 2 - kDmaBias);
+        unsigned long long sb[kMaxPer];
+#pragma unroll
+        for (int j = 0; j < kMaxPer; j++) sb[j] = isy[j] ? sy : sx;
+        const unsigned base = __builtin_amdgcn_readfirstlane(smem_base + (kt % TL::NSTAGE) * TL::STAGE + wave * TL::PER * 1024);
+        glds_group<3>(voff, sb, 0, base);
+    };
+
+    f32x16 acc[1][MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int n = 0; n < NT; n++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[0][m][n][r] = 0.f;
+    const int wt = wave >> 2, wn = wave & 3;                  // 2 x 4 waves over the 128 x 256 tile
+    constexpr int AHEAD = TL::NSTAGE - 1;
+#pragma unroll
+    for (int s_ = 0; s_ < AHEAD; s_++)
+        if (s_ < KT) issue(s_);
+    for (int kt = 0; kt < KT; kt++) {
+        const int rem = KT - 1 - kt;
+        if (rem >= AHEAD - 1) wait_vmcnt<(AHEAD - 1) * TL::PER>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + AHEAD < KT) issue(kt + AHEAD);
+        char* st = smem + (kt % TL::NSTAGE) * TL::STAGE;
+        const int lim = ntok - kt * 32;                       // valid tokens in this slab
+        if (lim < 32) {                                       // block-uniform: last slab only
+            for (int q = tid; q < 3 * 32 * 16; q += 512) {
+                const int blk = q >> 9, rem_ = q & 511, row = rem_ >> 4;
+                if (row >= lim) *reinterpret_cast<uint4*>(st + blk * TL::BLK + row * 256 + (rem_ & 15) * 16) = uint4{0, 0, 0, 0};
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            f16x8 yf[MT], xf[NT];
+#pragma unroll
+            for (int m = 0; m < MT; m++) yf[m] = img_tr_frag(st, 0, ks, wt * MT + m, lane);
+#pragma unroll
+            for (int n = 0; n < NT; n++) {
+                const int ft = wn * NT + n;                   // 32-feature tile of the 256 X columns
+                xf[n] = img_tr_frag(st + (1 + (ft >> 2)) * TL::BLK, 0, ks, ft & 3, lane);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; m++)
+#pragma unroll
+                for (int n = 0; n < NT; n++) acc[0][m][n] = mfma_f16(xf[n], yf[m], acc[0][m][n]);
+        }
+    }
+    __builtin_amdgcn_s_barrier();
+    epi.out += (size_t)z * out_stride;
+    epi.template run<BT, BF, MT, NT>(acc, r0, c0, smem);
+}
+
+// colsum[n] += unscale * sum_rows in[row][n]   (bias gradients of linear1 / in_proj); in: [M][N] f16, N % 256 == 0.
+// Block = 256 columns x rows_per_block rows: thread (cg, rl) sums 8 columns (16-byte loads) of every 8th row.
+__global__ __launch_bounds__(256) void k_colsum_f16(const f16* __restrict__ in, int N, int M, int rows_per_block,
+                                                    const float* __restrict__ gscale, float* __restrict__ colsum) {
+    __shared__ float red[8][256];
+    const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c0 = blockIdx.x * 256 + cg * 8;
+    const int r_lo = blockIdx.y * rows_per_block;
+    int r_hi = r_lo + rows_per_block;
+    if (r_hi > M) r_hi = M;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int r = r_lo + rl; r < r_hi; r += 8) {
+        const f16x8 v = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(in + (size_t)r * N + c0));
+#pragma unroll
+        for (int j = 0; j < 8; j++) s[j] += (float)v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) red[rl][cg * 8 + j] = s[j];
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) t += red[i][threadIdx.x];
+    atomicAdd(colsum + blockIdx.x * 256 + threadIdx.x, t * gscale[1]);
 }
 
 }  // namespace mst
