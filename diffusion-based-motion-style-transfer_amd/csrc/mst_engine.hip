@@ -48,6 +48,15 @@ static dim3 wide_grid(int M, int ny) {
     return WIDE_XCD ? dim3(((nx + 7) / 8) * 8 * ny, 1, 1) : dim3(nx, ny, 1);
 }
 
+// dgrad GEMMs that end in the fp32 gradient stream (N = 512): token tile
+#ifndef DG_BT
+#define DG_BT 128     // same-box A/B of the backward pass at batch 64: 128 x 256 tiles 2.99 ms, 64 x 256 (394 blocks, two per CU) 3.10 ms
+#endif
+static dim3 dg_grid(int M, int ny) {
+    const int nx = (M + DG_BT - 1) / DG_BT;
+    return WIDE_XCD ? dim3(((nx + 7) / 8) * 8 * ny, 1, 1) : dim3(nx, ny, 1);
+}
+
 // ------------------------------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
 static int fail(const char* fmt, ...) {
@@ -90,7 +99,10 @@ struct LayerW {
 struct TrainWS {
     bool ready = false;
     float *g0 = nullptr, *g1 = nullptr;                 // fp32 gradient stream, ping-pong
-    f16 *dbr = nullptr, *dpre = nullptr, *datt = nullptr, *dqkv = nullptr;
+    // operands the wgrad stream reads while the dgrad chain moves on: double-buffered by layer parity
+    f16 *dbr2[2] = {nullptr, nullptr}, *dbr1[2] = {nullptr, nullptr}, *dpre[2] = {nullptr, nullptr}, *dqkv[2] = {nullptr, nullptr};
+    f16* datt = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_side[2] = {nullptr, nullptr};
     float* part = nullptr;                              // split-K partial products
     float* zeros = nullptr;                             // zero bias
     float* gscale = nullptr;                            // [0] scale applied to the incoming gradient, [1] its inverse
@@ -122,6 +134,7 @@ struct mst_engine {
     TrainWS tw;
     int dbg_layer = -1, dbg_stage = -1;   // stop the trunk after (layer, stage); -1 = run everything
     int fuse_qkv_attn = 1;                // K4 + K5 as one kernel per (clip, head); MST_FUSE_QKV_ATTN=0 keeps them apart
+    int wgrad_stream_on = 1;              // training: wgrads on a second stream beside the dgrad chain (MST_WGRAD_STREAM=0: one stream)
     int nsplit = 3;                       // sampling loops run the batch as this many independent slices on separate streams (same-box A/B: 2: 61.2, 3: 63.0, 4: 61.1 clips/s)
     static constexpr int MAX_SLICES = 4;
     hipStream_t aux_stream[MAX_SLICES - 1] = {nullptr, nullptr, nullptr};
@@ -239,6 +252,7 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
         e->nsplit = n < 1 ? 1 : (n > mst_engine::MAX_SLICES ? mst_engine::MAX_SLICES : n);
     }
     if (const char* v = getenv("MST_FUSE_QKV_ATTN")) e->fuse_qkv_attn = atoi(v) != 0;
+    if (const char* v = getenv("MST_WGRAD_STREAM")) e->wgrad_stream_on = atoi(v) != 0;
     *out = e;
     return 0;
 }
@@ -253,7 +267,10 @@ extern "C" void mst_engine_destroy(mst_engine* e) {
     }
     {
         TrainWS& t = e->tw;
-        void* p[] = {t.g0, t.g1, t.dbr, t.dpre, t.datt, t.dqkv, t.part, t.zeros, t.gscale, t.amax};
+        void* p[] = {t.g0, t.g1, t.dbr2[0], t.dbr2[1], t.dbr1[0], t.dbr1[1], t.dpre[0], t.dpre[1], t.dqkv[0], t.dqkv[1],
+                     t.datt, t.part, t.zeros, t.gscale, t.amax};
+        if (t.ev_ready) (void)hipEventDestroy(t.ev_ready);
+        for (int i = 0; i < 2; i++) if (t.ev_side[i]) (void)hipEventDestroy(t.ev_side[i]);
         for (void* q : p) (void)hipFree(q);
     }
     void* p[] = {e->w_pose_in, e->b_pose_in, e->w_pose_out, e->b_pose_out, e->w_t0, e->b_t0, e->w_t2, e->b_t2,
@@ -921,10 +938,15 @@ static int train_ws(mst_engine* e) {
     t.split_cap = 64;
     CHECK(dmalloc(&t.g0, Mp * MST_D));
     CHECK(dmalloc(&t.g1, Mp * MST_D));
-    CHECK(dmalloc(&t.dbr, Mp * MST_D));
-    CHECK(dmalloc(&t.dpre, Mp * MST_FF));
+    for (int i = 0; i < 2; i++) {
+        CHECK(dmalloc(&t.dbr2[i], Mp * MST_D));
+        CHECK(dmalloc(&t.dbr1[i], Mp * MST_D));
+        CHECK(dmalloc(&t.dpre[i], Mp * MST_FF));
+        CHECK(dmalloc(&t.dqkv[i], Mp * 3 * MST_D));
+        HIPCHECK(hipEventCreateWithFlags(&t.ev_side[i], hipEventDisableTiming));
+    }
+    HIPCHECK(hipEventCreateWithFlags(&t.ev_ready, hipEventDisableTiming));
     CHECK(dmalloc(&t.datt, Mp * MST_D));
-    CHECK(dmalloc(&t.dqkv, Mp * 3 * MST_D));
     CHECK(dmalloc(&t.part, t.split_cap * (size_t)3 * MST_D * MST_D));
     CHECK(dmalloc(&t.zeros, 3 * MST_D));
     CHECK(dmalloc(&t.gscale, 2));
@@ -990,50 +1012,72 @@ extern "C" int mst_train_backward(mst_engine* e, const void* tape, const float* 
     float* gB = w_.g1;      // gradient wrt the current layer output
     const int ln_blocks = (M + 3) / 4 < 512 ? (M + 3) / 4 : 512;
     e->prof_now = 0;
+    // The dgrad chain (LayerNorm / GELU / attention backward and the four dgrad GEMMs) is serial; the four wgrads of a
+    // layer only consume its by-products, so they run on a second stream beside it.  Their f16 operands are
+    // double-buffered by layer parity: the chain of layer l waits for the wgrads of layer l + 2, not l + 1.
+    hipStream_t sw = e->wgrad_stream_on ? e->aux_stream[0] : st;
+    const bool two = sw != st;
+    bool side_used[2] = {false, false};
+#define TO_SIDE()                                                   \
+    if (two) {                                                      \
+        HIPCHECK(hipEventRecord(w_.ev_ready, st));                  \
+        HIPCHECK(hipStreamWaitEvent(sw, w_.ev_ready, 0));           \
+    }
     for (int l = nl - 1; l >= 0; l--) {
         const LayerW& w = e->L[l];
         const TapeL& a = t.L[l];
+        const int par = l & 1;
+        f16 *dbr2 = w_.dbr2[par], *dbr1 = w_.dbr1[par], *dpre = w_.dpre[par], *dqkv = w_.dqkv[par];
         float* const* G = grads + (size_t)l * 12;
         for (int i = 0; i < 12; i++) if (!G[i]) return fail("mst_train_backward: null gradient buffer (layer %d, tensor %d)", l, i);
-        // LayerNorm2 backward: gB -> dz2 (gA, fp32) and the branch gradient dbr (f16); dgamma2, dbeta2, db2
+        if (two && side_used[par]) HIPCHECK(hipStreamWaitEvent(st, w_.ev_side[par], 0));
+        // LayerNorm2 backward: gB -> dz2 (gA, fp32) and the branch gradient dbr2 (f16); dgamma2, dbeta2, db2
         hipLaunchKernelGGL(k_ln_bwd, dim3(ln_blocks), dim3(256), 0, st, gB, a.z2h, a.z2l, w.g2, M, make_drop(seed, l, 3, p_drop), w_.gscale,
-                           gA, w_.dbr, G[10], G[11], G[7]);
+                           gA, dbr2, G[10], G[11], G[7]);
         HIPCHECK(hipGetLastError());
-        // dW2 += dbr^T hid
-        CHECK(wgrad(e, w_.dbr, MST_D, a.hid, MST_FF, M, G[6], nullptr, st));
-        // d pre = (dbr W2) * mask * gelu'(pre)
+        TO_SIDE()
+        CHECK(wgrad(e, dbr2, MST_D, a.hid, MST_FF, M, G[6], nullptr, sw));                 // dW2 += dbr2^T hid
+        // d pre = (dbr2 W2) * mask * gelu'(pre)
         {
-            DEpiRowOp<OpGeluBwd> epi{nullptr, M, OpGeluBwd{a.pre, w_.dpre, MST_FF, make_drop(seed, l, 2, p_drop)}};
-            CHECK((launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, MST_FF / 256), RowsDirect{w_.dbr, MST_D}, w.w2T, MST_D, MST_D, epi, st, WIDE_XCD ? MST_FF / 256 : 0)));
+            DEpiRowOp<OpGeluBwd> epi{nullptr, M, OpGeluBwd{a.pre, dpre, MST_FF, make_drop(seed, l, 2, p_drop)}};
+            CHECK((launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, MST_FF / 256), RowsDirect{dbr2, MST_D}, w.w2T, MST_D, MST_D, epi, st, WIDE_XCD ? MST_FF / 256 : 0)));
         }
-        // dW1 += dpre^T x1, db1 += colsum(dpre)
-        CHECK(wgrad(e, w_.dpre, MST_FF, a.x1h, MST_D, M, G[4], G[5], st));
+        TO_SIDE()
+        CHECK(wgrad(e, dpre, MST_FF, a.x1h, MST_D, M, G[4], G[5], sw));                    // dW1 += dpre^T x1, db1
         // g(x1) = dpre W1 + dz2  -> gB
         {
             DEpiF32 epi{gA, gB, MST_D, M};
-            CHECK((launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, MST_D / 256), RowsDirect{w_.dpre, MST_FF}, w.w1T, MST_FF, MST_FF, epi, st, WIDE_XCD ? MST_D / 256 : 0)));
+            CHECK((launch_gemm_dma<DG_BT, 256, DG_BT / 64, 2, WIDE_NS, 1>(dg_grid(M, MST_D / 256), RowsDirect{dpre, MST_FF}, w.w1T, MST_FF, MST_FF, epi, st, WIDE_XCD ? MST_D / 256 : 0)));
         }
-        // LayerNorm1 backward: gB -> dz1 (gA), dbr = d(out-proj output); dgamma1, dbeta1, db_out
+        // LayerNorm1 backward: gB -> dz1 (gA), dbr1 = d(out-proj output); dgamma1, dbeta1, db_out
         hipLaunchKernelGGL(k_ln_bwd, dim3(ln_blocks), dim3(256), 0, st, gB, a.z1h, a.z1l, w.g1, M, make_drop(seed, l, 1, p_drop), w_.gscale,
-                           gA, w_.dbr, G[8], G[9], G[3]);
+                           gA, dbr1, G[8], G[9], G[3]);
         HIPCHECK(hipGetLastError());
-        // dW_out += dbr^T att
-        CHECK(wgrad(e, w_.dbr, MST_D, a.att, MST_D, M, G[2], nullptr, st));
-        // d att = dbr W_out
+        TO_SIDE()
+        CHECK(wgrad(e, dbr1, MST_D, a.att, MST_D, M, G[2], nullptr, sw));                  // dW_out += dbr1^T att
+        // d att = dbr1 W_out
         {
             DEpiBiasF16<false> epi{w_.zeros, w_.datt, MST_D, M};
-            CHECK((launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, MST_D / 256), RowsDirect{w_.dbr, MST_D}, w.w_outT, MST_D, MST_D, epi, st, WIDE_XCD ? MST_D / 256 : 0)));
+            CHECK((launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, MST_D / 256), RowsDirect{dbr1, MST_D}, w.w_outT, MST_D, MST_D, epi, st, WIDE_XCD ? MST_D / 256 : 0)));
         }
         // attention backward -> d qkv
-        CHECK(launch_attn_bwd(a.qkv, a.att, w_.datt, w_.dqkv, S, rows, make_drop(seed, l, 0, p_drop), st));
-        // dW_in += dqkv^T x_in, db_in += colsum(dqkv)
-        CHECK(wgrad(e, w_.dqkv, 3 * MST_D, t.sh[l], MST_D, M, G[0], G[1], st));
+        CHECK(launch_attn_bwd(a.qkv, a.att, w_.datt, dqkv, S, rows, make_drop(seed, l, 0, p_drop), st));
+        TO_SIDE()
+        CHECK(wgrad(e, dqkv, 3 * MST_D, t.sh[l], MST_D, M, G[0], G[1], sw));               // dW_in += dqkv^T x_in, db_in
+        if (two) {
+            HIPCHECK(hipEventRecord(w_.ev_side[par], sw));
+            side_used[par] = true;
+        }
         // g(x_in) = dqkv W_in + dz1 -> gB
         {
             DEpiF32 epi{gA, gB, MST_D, M};
-            CHECK((launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, MST_D / 256), RowsDirect{w_.dqkv, 3 * MST_D}, w.w_inT, 3 * MST_D, 3 * MST_D, epi, st, WIDE_XCD ? MST_D / 256 : 0)));
+            CHECK((launch_gemm_dma<DG_BT, 256, DG_BT / 64, 2, WIDE_NS, 1>(dg_grid(M, MST_D / 256), RowsDirect{dqkv, 3 * MST_D}, w.w_inT, 3 * MST_D, 3 * MST_D, epi, st, WIDE_XCD ? MST_D / 256 : 0)));
         }
     }
+#undef TO_SIDE
+    if (two)
+        for (int i = 0; i < 2; i++)
+            if (side_used[i]) HIPCHECK(hipStreamWaitEvent(st, w_.ev_side[i], 0));
     if (d_in) {
         hipLaunchKernelGGL(k_scale_f32, dim3(1024), dim3(256), 0, st, gB, n, w_.gscale, 1, d_in);
         HIPCHECK(hipGetLastError());

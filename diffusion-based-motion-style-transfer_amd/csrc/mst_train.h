@@ -117,11 +117,12 @@ struct OpGeluBwd {
 struct DEpiF32 {
     const float* resid; float* out; int ldo; int M;
     __device__ __forceinline__ int rows() const { return M; }
-    template <int BT, int BF> static constexpr int smem_bytes() { return 64 * (BF * 4 + 16); }
+    template <int BT> static constexpr int pass_rows() { return BT >= 128 ? 64 : 32; }       // tile rows staged per pass
+    template <int BT, int BF> static constexpr int smem_bytes() { return pass_rows<BT>() * (BF * 4 + 16); }
     template <int BT, int BF, int MT, int NT>
     __device__ __forceinline__ void run(f32x16 (&acc)[1][MT][NT], int tok0, int f0, char* smem) const {
         static_assert(BF == 256, "one wave access = one 1-KiB row");
-        constexpr int LD = BF * 4 + 16, PR = 64, PASSES = BT / PR;
+        constexpr int LD = BF * 4 + 16, PR = pass_rows<BT>(), PASSES = BT / PR;
         DLane<BT, BF, MT, NT> lc;
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
