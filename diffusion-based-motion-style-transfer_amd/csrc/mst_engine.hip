@@ -948,7 +948,7 @@ static int train_ws(mst_engine* e) {
     HIPCHECK(hipEventCreateWithFlags(&t.ev_ready, hipEventDisableTiming));
     CHECK(dmalloc(&t.datt, Mp * MST_D));
     CHECK(dmalloc(&t.part, t.split_cap * (size_t)3 * MST_D * MST_D));
-    CHECK(dmalloc(&t.zeros, 3 * MST_D));
+    CHECK(dmalloc(&t.zeros, 3 * MST_D + MST_D));          // zero bias [1536] + a 512-float dump for unwanted reductions
     CHECK(dmalloc(&t.gscale, 2));
     CHECK(dmalloc(&t.amax, 1));
     t.ready = true;
@@ -993,7 +993,8 @@ static int wgrad(mst_engine* e, const f16* dY, int n_out, const f16* X, int k_in
 extern "C" int mst_train_backward(mst_engine* e, const void* tape, const float* d_out, int32_t rows, int32_t S, float p_drop,
                                   uint64_t seed, float* d_in, float* const* grads, void* stream) {
     CHECK(train_check(e, rows, S, p_drop));
-    if (!tape || !d_out || !grads) return fail("mst_train_backward: null argument");
+    if (!tape || !d_out) return fail("mst_train_backward: null argument");
+    if (!grads && !d_in) return 0;                       // nothing asked for
     hipStream_t st = (hipStream_t)stream;
     HIPCHECK(hipSetDevice(e->cfg.device));
     CHECK(train_ws(e));
@@ -1019,7 +1020,7 @@ extern "C" int mst_train_backward(mst_engine* e, const void* tape, const float* 
     const bool two = sw != st;
     bool side_used[2] = {false, false};
 #define TO_SIDE()                                                   \
-    if (two) {                                                      \
+    if (two && grads) {                                                \
         HIPCHECK(hipEventRecord(w_.ev_ready, st));                  \
         HIPCHECK(hipStreamWaitEvent(sw, w_.ev_ready, 0));           \
     }
@@ -1028,7 +1029,11 @@ extern "C" int mst_train_backward(mst_engine* e, const void* tape, const float* 
         const TapeL& a = t.L[l];
         const int par = l & 1;
         f16 *dbr2 = w_.dbr2[par], *dbr1 = w_.dbr1[par], *dpre = w_.dpre[par], *dqkv = w_.dqkv[par];
-        float* const* G = grads + (size_t)l * 12;
+        // grads == NULL (frozen stack): no wgrads; the LayerNorm kernel's small reductions land in a scratch vector
+        float* dump[12];
+        for (int i = 0; i < 12; i++) dump[i] = w_.zeros + 3 * MST_D;
+        float* const* G = grads ? grads + (size_t)l * 12 : dump;
+        const bool wg = grads != nullptr;
         for (int i = 0; i < 12; i++) if (!G[i]) return fail("mst_train_backward: null gradient buffer (layer %d, tensor %d)", l, i);
         if (two && side_used[par]) HIPCHECK(hipStreamWaitEvent(st, w_.ev_side[par], 0));
         // LayerNorm2 backward: gB -> dz2 (gA, fp32) and the branch gradient dbr2 (f16); dgamma2, dbeta2, db2
@@ -1036,14 +1041,14 @@ extern "C" int mst_train_backward(mst_engine* e, const void* tape, const float* 
                            gA, dbr2, G[10], G[11], G[7]);
         HIPCHECK(hipGetLastError());
         TO_SIDE()
-        CHECK(wgrad(e, dbr2, MST_D, a.hid, MST_FF, M, G[6], nullptr, sw));                 // dW2 += dbr2^T hid
+        if (wg) CHECK(wgrad(e, dbr2, MST_D, a.hid, MST_FF, M, G[6], nullptr, sw));                 // dW2 += dbr2^T hid
         // d pre = (dbr2 W2) * mask * gelu'(pre)
         {
             DEpiRowOp<OpGeluBwd> epi{nullptr, M, OpGeluBwd{a.pre, dpre, MST_FF, make_drop(seed, l, 2, p_drop)}};
             CHECK((launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, MST_FF / 256), RowsDirect{dbr2, MST_D}, w.w2T, MST_D, MST_D, epi, st, WIDE_XCD ? MST_FF / 256 : 0)));
         }
         TO_SIDE()
-        CHECK(wgrad(e, dpre, MST_FF, a.x1h, MST_D, M, G[4], G[5], sw));                    // dW1 += dpre^T x1, db1
+        if (wg) CHECK(wgrad(e, dpre, MST_FF, a.x1h, MST_D, M, G[4], G[5], sw));                    // dW1 += dpre^T x1, db1
         // g(x1) = dpre W1 + dz2  -> gB
         {
             DEpiF32 epi{gA, gB, MST_D, M};
@@ -1054,7 +1059,7 @@ extern "C" int mst_train_backward(mst_engine* e, const void* tape, const float* 
                            gA, dbr1, G[8], G[9], G[3]);
         HIPCHECK(hipGetLastError());
         TO_SIDE()
-        CHECK(wgrad(e, dbr1, MST_D, a.att, MST_D, M, G[2], nullptr, sw));                  // dW_out += dbr1^T att
+        if (wg) CHECK(wgrad(e, dbr1, MST_D, a.att, MST_D, M, G[2], nullptr, sw));                  // dW_out += dbr1^T att
         // d att = dbr1 W_out
         {
             DEpiBiasF16<false> epi{w_.zeros, w_.datt, MST_D, M};
@@ -1063,8 +1068,8 @@ extern "C" int mst_train_backward(mst_engine* e, const void* tape, const float* 
         // attention backward -> d qkv
         CHECK(launch_attn_bwd(a.qkv, a.att, w_.datt, dqkv, S, rows, make_drop(seed, l, 0, p_drop), st));
         TO_SIDE()
-        CHECK(wgrad(e, dqkv, 3 * MST_D, t.sh[l], MST_D, M, G[0], G[1], sw));               // dW_in += dqkv^T x_in, db_in
-        if (two) {
+        if (wg) CHECK(wgrad(e, dqkv, 3 * MST_D, t.sh[l], MST_D, M, G[0], G[1], sw));               // dW_in += dqkv^T x_in, db_in
+        if (two && wg) {
             HIPCHECK(hipEventRecord(w_.ev_side[par], sw));
             side_used[par] = true;
         }

@@ -182,16 +182,19 @@ class DenoiserEngine:
         return out, tape
 
     def train_backward(self, tape, d_out, p_drop, seed, grads, need_input_grad=True):
-        """grads: num_layers*12 float32 GPU tensors in LAYER_TENSORS order per layer, accumulated into.
+        """grads: num_layers*12 float32 GPU tensors in LAYER_TENSORS order per layer, accumulated into;
+        None skips every parameter gradient (frozen stack: input gradient only).
         Returns dL/dh [rows, S, 512] (or None)."""
         d_out = _f32c(d_out, self.device, "d_out")
         rows, S, d = d_out.shape
-        if len(grads) != self.num_layers * 12:
-            raise ValueError(f"expected {self.num_layers * 12} gradient buffers, got {len(grads)}")
-        for g in grads:
-            if g.dtype != torch.float32 or not g.is_contiguous() or g.device != d_out.device:
-                raise ValueError("gradient buffers must be contiguous float32 tensors on the engine's device")
-        arr = (C.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
+        arr = None
+        if grads is not None:
+            if len(grads) != self.num_layers * 12:
+                raise ValueError(f"expected {self.num_layers * 12} gradient buffers, got {len(grads)}")
+            for g in grads:
+                if g.dtype != torch.float32 or not g.is_contiguous() or g.device != d_out.device:
+                    raise ValueError("gradient buffers must be contiguous float32 tensors on the engine's device")
+            arr = (C.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
         d_in = torch.empty_like(d_out) if need_input_grad else None
         N.check(N.lib().mst_train_backward(self.handle, N.ptr(tape), N.ptr(d_out), rows, S, float(p_drop), int(seed),
                                            N.ptr(d_in), arr, N.stream_ptr(self.device)))

@@ -4,10 +4,18 @@
 (model/mdm_forstyledataset.py:622 of the reference) inside the graph that
 few_shot_style_finetune_losses (diffusion/gaussian_diffusion.py:1317-1399) back-propagates through:
 forward = mst_train_forward (activation tape + dropout), backward = mst_train_backward (dgrad / wgrad
-GEMMs, attention / LayerNorm / GELU backward).  The 96 parameters are passed as inputs so autograd
-routes their gradients; the arithmetic uses the engine's f16 copies of them (re-uploaded by
-`_EngineHost.mst_engine` whenever a parameter's version changes)."""
+GEMMs, attention / LayerNorm / GELU backward).  The arithmetic uses the engine's f16 copies of the
+parameters (re-uploaded by `_EngineHost.mst_engine` whenever a parameter's version changes).
+
+Parameter gradients.  One fine-tune iteration passes through the stack 7 times (one 64-clip call, six
+chained single-clip steps); handing 96 fresh gradient tensors per pass to autograd would cost 96 fills +
+96 adds per pass (~1300 tiny launches per iteration, more host time than the kernels).  Instead every
+node of one backward pass accumulates -- inside the kernels, which add into their output -- into ONE flat
+buffer owned by the module (`GradSink`), and a callback queued on the autograd engine adds that buffer
+into `p.grad` once, when the backward pass ends (the mechanism DDP-style reducers use).  The parameters
+are still inputs of the node, so autograd knows the node needs to run; it receives None for them."""
 import torch
+from torch.autograd import Variable
 
 from ..engine import LAYER_TENSORS
 
@@ -21,27 +29,70 @@ def stack_parameters(encoder):
     return out
 
 
+class GradSink:
+    """Per-module accumulator of the stack's parameter gradients over one backward pass."""
+
+    def __init__(self, host, params):
+        self.host, self.params = host, params
+        self.ids = tuple(id(p) for p in params)
+        self.flat, self.views, self.active = None, None, False
+
+    def begin(self, device):
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=device)      # fresh: views may become p.grad
+        self.views, off = [], 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+        self.active = True
+        Variable._execution_engine.queue_callback(self.flush)
+
+    def flush(self):
+        """End of the backward pass: p.grad (+)= accumulated gradient, then tell a gradient reducer."""
+        self.active = False
+        have, add = [], []
+        for p, v in zip(self.params, self.views):
+            if not p.requires_grad:
+                continue
+            if p.grad is None:
+                p.grad = v
+            else:
+                have.append(p.grad)
+                add.append(v)
+        if have:
+            torch._foreach_add_(have, add)
+        self.flat = self.views = None
+        ready = getattr(self.host, "_native_grads_ready", None)
+        if ready is not None:
+            ready()
+
+
 class EncoderStackFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, seq, host, p_drop, *params):
         S, B, d = seq.shape
         eng = host.mst_engine(B, S - 1)
-        # one 63-bit seed per call from torch's generator: torch.manual_seed reproduces the masks
+        # one 62-bit seed per call from torch's generator: torch.manual_seed reproduces the masks
         seed = int(torch.randint(0, 2 ** 62, (1,), device="cpu").item()) if p_drop > 0 else 0
         h = seq.detach().permute(1, 0, 2).contiguous()
         out, tape = eng.train_forward(h, p_drop, seed)
-        ctx.eng, ctx.tape, ctx.p_drop, ctx.seed = eng, tape, p_drop, seed
-        ctx.shapes = [tuple(p.shape) for p in params]
-        ctx.host = host
+        ctx.eng, ctx.tape, ctx.p_drop, ctx.seed, ctx.host = eng, tape, p_drop, seed, host
+        ctx.params = params
         return out.permute(1, 0, 2).contiguous()
 
     @staticmethod
     def backward(ctx, grad_out):
         need_in = ctx.needs_input_grad[0]
-        need_p = [ctx.needs_input_grad[3 + i] for i in range(len(ctx.shapes))]
-        grads = [torch.zeros(s, dtype=torch.float32, device=grad_out.device) for s in ctx.shapes]
+        views = None
+        if any(ctx.needs_input_grad[3:]):
+            sink = ctx.host.__dict__.get("_mst_grad_sink")
+            if sink is None or sink.ids != tuple(id(p) for p in ctx.params):
+                sink = ctx.host.__dict__["_mst_grad_sink"] = GradSink(ctx.host, list(ctx.params))
+            if not sink.active:
+                sink.begin(grad_out.device)
+            views = sink.views
         d_out = grad_out.permute(1, 0, 2).contiguous()
-        d_in = ctx.eng.train_backward(ctx.tape, d_out, ctx.p_drop, ctx.seed, grads, need_input_grad=need_in)
+        d_in = ctx.eng.train_backward(ctx.tape, d_out, ctx.p_drop, ctx.seed, views, need_input_grad=need_in)
         ctx.tape = None
         gi = d_in.permute(1, 0, 2).contiguous() if need_in else None
-        return (gi, None, None) + tuple(g if n else None for g, n in zip(grads, need_p))
+        return (gi, None, None) + (None,) * len(ctx.params)

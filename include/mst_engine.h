@@ -197,7 +197,8 @@ int mst_philox_normal(float* out_dev, int32_t batch, int32_t feats, int32_t fram
  *                       num_layers*12 device pointers in nn.TransformerEncoderLayer parameter order:
  *                       self_attn.in_proj_weight, .in_proj_bias, self_attn.out_proj.weight, .bias,
  *                       linear1.weight, .bias, linear2.weight, .bias, norm1.weight, .bias,
- *                       norm2.weight, .bias.  rows / S / p_drop / seed must repeat the forward's.
+ *                       norm2.weight, .bias.  grads == NULL: no parameter gradients (frozen stack, input
+ *                       gradient only).  rows / S / p_drop / seed must repeat the forward's.
  * h_in, h_out, d_out, d_in: float32 [rows][S][512] (clip-major; the reference's [S, B, 512] permuted).
  * The engine's weights are the ones last uploaded with mst_load_weight.
  * mst_dropout_mask: the keep-multipliers (0 or 1/(1-p)) of the first n elements of site

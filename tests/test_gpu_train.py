@@ -254,3 +254,31 @@ def test_model_training_mode_dropout_is_seeded():
     assert torch.equal(e1, e2)                                       # inference path: no dropout
     with pytest.raises(RuntimeError, match="GPU only"):
         _style_model().cpu().train()(x.cpu(), t.cpu(), y={"text_embed": y["text_embed"].cpu()})
+
+
+def test_native_gradients_reach_a_bucket_reducer():
+    """GradSink adds the accumulated gradients into existing p.grad tensors (here: views of the reducer's per-layer
+    buckets) at the end of backward and notifies the reducer, which fires its buckets last layer first."""
+    from mst_amd.finetune_dp import LayerBucketReducer
+    m = _style_model().eval()
+    x, t, y, tgt = _model_batch()
+
+    def step():
+        loss = ((m(x, t, y=y) - tgt) ** 2).mean() + ((m(x * 0.5, t, y=y) - tgt) ** 2).mean()     # two passes, one backward
+        loss.backward()
+
+    m.zero_grad()
+    step()
+    plain = {n: p.grad.clone() for n, p in m.named_parameters() if p.requires_grad}
+    red = LayerBucketReducer(m)
+    red.zero_grad()
+    step()
+    red.finish()
+    assert red.launch_order == list(range(7, -1, -1))
+    for n, p in m.named_parameters():
+        if p.requires_grad:
+            assert rel_l2(p.grad.cpu().numpy(), plain[n].cpu().numpy()) < 1e-6, n
+    # a second backward without zeroing accumulates (torch semantics)
+    step()
+    g = m.seqTransEncoder.layers[5].linear2.weight.grad
+    assert rel_l2(g.cpu().numpy(), (2 * plain["seqTransEncoder.layers.5.linear2.weight"]).cpu().numpy()) < 1e-6
