@@ -53,9 +53,9 @@ SIGNATURES = {
     "mst_philox_normal": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_uint32, C.c_void_p]),
     "mst_train_tape_bytes": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32]),
     "mst_train_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_uint64, C.c_void_p,
-                                    C.c_void_p, C.c_void_p]),
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     "mst_train_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_uint64,
-                                     C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
+                                     C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
     "mst_dropout_mask": (C.c_int, [C.c_uint64, C.c_int32, C.c_int32, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p]),
     "mst_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "mst_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int32),

@@ -847,28 +847,29 @@ extern "C" int64_t mst_train_tape_bytes(const mst_engine* e, int32_t rows, int32
 }
 
 template <int NKT>
-static int launch_attn_train_n(const f16* qkv, f16* out, int S, int rows, Drop d, hipStream_t st) {
+static int launch_attn_train_n(const f16* qkv, f16* out, int S, int rows, Drop d, const unsigned char* keep, hipStream_t st) {
     auto kern = k_attention_train<NKT>;
     static bool attr_set = false;
-    const int smem = NKT * 32 * 256 * 2;
+    const int smem = NKT * 32 * 256 * 2 + NKT * 32 * 4;
     if (!attr_set) {
         HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(rows * MST_H), dim3(512), smem, st, qkv, out, S, d);
+    hipLaunchKernelGGL(kern, dim3(rows * MST_H), dim3(512), smem, st, qkv, out, S, d, keep);
     HIPCHECK(hipGetLastError());
     return 0;
 }
 template <int NKT>
-static int launch_attn_bwd_n(const f16* qkv, const f16* att, const f16* datt, f16* dqkv, int S, int rows, Drop d, hipStream_t st) {
+static int launch_attn_bwd_n(const f16* qkv, const f16* att, const f16* datt, f16* dqkv, int S, int rows, Drop d,
+                             const unsigned char* keep, hipStream_t st) {
     auto kern = k_attention_bwd<NKT>;
     static bool attr_set = false;
-    const int smem = NKT * 32 * 256 * 2 + NKT * 32 * 8;
+    const int smem = NKT * 32 * 256 * 2 + NKT * 32 * 12;
     if (!attr_set) {
         HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(rows * MST_H), dim3(512), smem, st, qkv, att, datt, dqkv, S, d);
+    hipLaunchKernelGGL(kern, dim3(rows * MST_H), dim3(512), smem, st, qkv, att, datt, dqkv, S, d, keep);
     HIPCHECK(hipGetLastError());
     return 0;
 }
@@ -883,17 +884,18 @@ static int launch_attn_bwd_n(const f16* qkv, const f16* att, const f16* datt, f1
         case 7: return fn<7>(__VA_ARGS__);                        \
     }                                                             \
     return fail("attention: S=%d unsupported", S);
-static int launch_attn_train(const f16* qkv, f16* out, int S, int rows, Drop d, hipStream_t st) {
-    NKT_SWITCH(launch_attn_train_n, S, qkv, out, S, rows, d, st)
+static int launch_attn_train(const f16* qkv, f16* out, int S, int rows, Drop d, const unsigned char* keep, hipStream_t st) {
+    NKT_SWITCH(launch_attn_train_n, S, qkv, out, S, rows, d, keep, st)
 }
-static int launch_attn_bwd(const f16* qkv, const f16* att, const f16* datt, f16* dqkv, int S, int rows, Drop d, hipStream_t st) {
-    NKT_SWITCH(launch_attn_bwd_n, S, qkv, att, datt, dqkv, S, rows, d, st)
+static int launch_attn_bwd(const f16* qkv, const f16* att, const f16* datt, f16* dqkv, int S, int rows, Drop d,
+                           const unsigned char* keep, hipStream_t st) {
+    NKT_SWITCH(launch_attn_bwd_n, S, qkv, att, datt, dqkv, S, rows, d, keep, st)
 }
 
 // h_in / h_out: [rows][S][512] float32 (clip-major token rows).  mdm_forstyledataset.py:622 `self.seqTransEncoder(xseq)`
 // with nn.TransformerEncoderLayer semantics (post-norm, erf GELU, dropout p at the four sites of the layer).
 extern "C" int mst_train_forward(mst_engine* e, const float* h_in, int32_t rows, int32_t S, float p_drop, uint64_t seed,
-                                 void* tape, float* h_out, void* stream) {
+                                 const uint8_t* key_keep, void* tape, float* h_out, void* stream) {
     CHECK(train_check(e, rows, S, p_drop));
     if (!h_in || !tape || !h_out) return fail("mst_train_forward: null argument");
     hipStream_t st = (hipStream_t)stream;
@@ -912,7 +914,7 @@ extern "C" int mst_train_forward(mst_engine* e, const float* h_in, int32_t rows,
             DEpiBiasF16<false> epi{w.b_in, a.qkv, 3 * MST_D, M};
             CHECK((launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, 3 * MST_D / 256), RowsDirect{t.sh[l], MST_D}, w.w_in, MST_D, MST_D, epi, st, WIDE_XCD ? 3 * MST_D / 256 : 0)));
         }
-        CHECK(launch_attn_train(a.qkv, a.att, S, rows, make_drop(seed, l, 0, p_drop), st));
+        CHECK(launch_attn_train(a.qkv, a.att, S, rows, make_drop(seed, l, 0, p_drop), key_keep, st));
         {
             DEpiResidLNTrain epi{w.b_out, w.g1, w.be1, t.sh[l], t.sl[l], a.z1h, a.z1l, a.x1h, a.x1l, M, make_drop(seed, l, 1, p_drop)};
             CHECK((launch_gemm_dma<64, 512, 2, 2, LN_NS, 1, LN_BK>(dim3((M + 63) / 64, 1), RowsDirect{a.att, MST_D}, w.w_out, MST_D, MST_D, epi, st)));
@@ -991,7 +993,7 @@ static int wgrad(mst_engine* e, const f16* dY, int n_out, const f16* X, int k_in
 // (in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias, linear1.weight, linear1.bias, linear2.weight,
 //  linear2.bias, norm1.weight, norm1.bias, norm2.weight, norm2.bias); every buffer is ACCUMULATED into.
 extern "C" int mst_train_backward(mst_engine* e, const void* tape, const float* d_out, int32_t rows, int32_t S, float p_drop,
-                                  uint64_t seed, float* d_in, float* const* grads, void* stream) {
+                                  uint64_t seed, const uint8_t* key_keep, float* d_in, float* const* grads, void* stream) {
     CHECK(train_check(e, rows, S, p_drop));
     if (!tape || !d_out) return fail("mst_train_backward: null argument");
     if (!grads && !d_in) return 0;                       // nothing asked for
@@ -1066,7 +1068,7 @@ extern "C" int mst_train_backward(mst_engine* e, const void* tape, const float* 
             CHECK((launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, MST_D / 256), RowsDirect{dbr1, MST_D}, w.w_outT, MST_D, MST_D, epi, st, WIDE_XCD ? MST_D / 256 : 0)));
         }
         // attention backward -> d qkv
-        CHECK(launch_attn_bwd(a.qkv, a.att, w_.datt, dqkv, S, rows, make_drop(seed, l, 0, p_drop), st));
+        CHECK(launch_attn_bwd(a.qkv, a.att, w_.datt, dqkv, S, rows, make_drop(seed, l, 0, p_drop), key_keep, st));
         TO_SIDE()
         if (wg) CHECK(wgrad(e, dqkv, 3 * MST_D, t.sh[l], MST_D, M, G[0], G[1], sw));               // dW_in += dqkv^T x_in, db_in
         if (two && wg) {

@@ -470,15 +470,23 @@ __global__ void k_dropout_mask(Drop d, size_t n, float* __restrict__ out) {
 __device__ __forceinline__ uint32_t p_index(int ch, int S, int q, int key) { return ((uint32_t)ch * S + q) * S + key; }
 
 // forward: k_attention (mst_attn.h) + dropout on P.  Both K and V use the transposed-read image layout.
+// keep: optional [clips][S] bytes, 0 = key is padding (src_key_padding_mask of the motion encoder, mdm_forstyledataset.py:117-121)
+__device__ __forceinline__ void stage_key_bias(float* kbias, const unsigned char* keep, int clip, int S, int KEYS, int tid) {
+    for (int k = tid; k < KEYS; k += 512) kbias[k] = (k < S && (!keep || keep[(size_t)clip * S + k])) ? 0.f : -INFINITY;
+}
+
 template <int NKT>
-__global__ __launch_bounds__(512) void k_attention_train(const f16* __restrict__ qkv, f16* __restrict__ out, int S, Drop d) {
+__global__ __launch_bounds__(512) void k_attention_train(const f16* __restrict__ qkv, f16* __restrict__ out, int S, Drop d,
+                                                         const unsigned char* __restrict__ keep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KEYS = NKT * 32;
     char* ks = smem;
     char* vs = smem + KEYS * 256;
+    float* kbias = reinterpret_cast<float*>(smem + 2 * KEYS * 256);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int clip = blockIdx.x / MST_H, head = blockIdx.x % MST_H;
     const f16* base = qkv + (size_t)clip * S * (3 * MST_D) + head * MST_HD;
+    stage_key_bias(kbias, keep, clip, S, KEYS, tid);
     for (int q = tid; q < KEYS * 16; q += 512) {
         int row = q >> 4, ch = q & 15;
         uint4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
@@ -519,11 +527,7 @@ __global__ __launch_bounds__(512) void k_attention_train(const f16* __restrict__
     for (int kt = 0; kt < NKT; kt++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            float v = sc[kt][r] * scale;
-            if (kt == NKT - 1) {
-                int key = kt * 32 + mfma_row(r, lane);
-                if (key >= S) v = -INFINITY;
-            }
+            const float v = sc[kt][r] * scale + kbias[kt * 32 + mfma_row(r, lane)];
             sc[kt][r] = v;
             m = fmaxf(m, v);
         }
@@ -612,13 +616,15 @@ __device__ __forceinline__ void stage_image(char* img, const f16* src, size_t ro
 // Pass 2 (wave = 32-key tile, lane = key; Q, dO images in LDS): dK, dV.  P is recomputed in both passes.
 template <int NKT>
 __global__ __launch_bounds__(512) void k_attention_bwd(const f16* __restrict__ qkv, const f16* __restrict__ att,
-                                                       const f16* __restrict__ datt, f16* __restrict__ dqkv, int S, Drop d) {
+                                                       const f16* __restrict__ datt, f16* __restrict__ dqkv, int S, Drop d,
+                                                       const unsigned char* __restrict__ keep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KEYS = NKT * 32;
     char* img0 = smem;
     char* img1 = smem + KEYS * 256;
     float* lse_s = reinterpret_cast<float*>(smem + 2 * KEYS * 256);
     float* dq_s = lse_s + KEYS;
+    float* kbias = dq_s + KEYS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hh = lane >> 5, l31 = lane & 31;
     const int clip = blockIdx.x / MST_H, head = blockIdx.x % MST_H, ch = clip * MST_H + head;
@@ -629,6 +635,7 @@ __global__ __launch_bounds__(512) void k_attention_bwd(const f16* __restrict__ q
     const float scale = 0.08838834764831845f;
 
     // ---------------- pass 1: K -> img0, V -> img1
+    stage_key_bias(kbias, keep, clip, S, KEYS, tid);
     stage_image(img0, base + MST_D, 3 * MST_D, S, KEYS, tid);
     stage_image(img1, base + 2 * MST_D, 3 * MST_D, S, KEYS, tid);
     __syncthreads();
@@ -663,8 +670,7 @@ __global__ __launch_bounds__(512) void k_attention_bwd(const f16* __restrict__ q
         for (int kt = 0; kt < NKT; kt++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                float v = sc[kt][r] * scale;
-                if (kt == NKT - 1 && kt * 32 + mfma_row(r, lane) >= S) v = -INFINITY;
+                const float v = sc[kt][r] * scale + kbias[kt * 32 + mfma_row(r, lane)];
                 sc[kt][r] = v;
                 m = fmaxf(m, v);
             }
@@ -725,7 +731,7 @@ __global__ __launch_bounds__(512) void k_attention_bwd(const f16* __restrict__ q
     if (wave >= NKT) return;
     {
         const int key_idx = wave * 32 + l31, key_ld = key_idx < S ? key_idx : S - 1;
-        const bool key_ok = key_idx < S;
+        const bool key_ok = kbias[key_idx] == 0.f;            // real, un-padded key
         f16x8 kf[8], vf[8];
         {
             const f16* kp = base + (size_t)key_ld * (3 * MST_D) + MST_D + 8 * hh;
@@ -772,7 +778,7 @@ __global__ __launch_bounds__(512) void k_attention_bwd(const f16* __restrict__ q
                     dk[dt] = mfma_f16(img_tr_frag(img0, qt, s2, dt, lane), dsf[s2], dk[dt]);
                 }
         }
-        if (key_ok) {
+        if (key_idx < S) {
             f16* krow = dbase + (size_t)key_idx * (3 * MST_D) + MST_D;
 #pragma unroll
             for (int dt = 0; dt < 4; dt++)

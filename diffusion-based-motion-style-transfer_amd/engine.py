@@ -170,18 +170,28 @@ class DenoiserEngine:
             raise RuntimeError("mst_train_tape_bytes failed")
         return torch.empty(n, dtype=torch.uint8, device=self.device)
 
-    def train_forward(self, h, p_drop, seed, tape=None):
-        """h: [rows, S, 512] float32 -> (encoder-stack output [rows, S, 512], tape)."""
+    def _key_keep(self, keep, rows, S):
+        if keep is None:
+            return None
+        k = keep.to(device=self.device, dtype=torch.uint8).contiguous()
+        if tuple(k.shape) != (rows, S):
+            raise ValueError(f"key_keep must be [{rows}, {S}], got {tuple(k.shape)}")
+        return k
+
+    def train_forward(self, h, p_drop, seed, tape=None, key_keep=None):
+        """h: [rows, S, 512] float32 -> (encoder-stack output [rows, S, 512], tape).
+        key_keep: optional [rows, S] bool, False = padding key (src_key_padding_mask inverted)."""
         h = _f32c(h, self.device, "h")
         rows, S, d = h.shape
         if tape is None:
             tape = self.train_tape(rows, S)
         out = torch.empty_like(h)
-        N.check(N.lib().mst_train_forward(self.handle, N.ptr(h), rows, S, float(p_drop), int(seed), N.ptr(tape), N.ptr(out),
-                                          N.stream_ptr(self.device)))
+        kk = self._key_keep(key_keep, rows, S)
+        N.check(N.lib().mst_train_forward(self.handle, N.ptr(h), rows, S, float(p_drop), int(seed), N.ptr(kk), N.ptr(tape),
+                                          N.ptr(out), N.stream_ptr(self.device)))
         return out, tape
 
-    def train_backward(self, tape, d_out, p_drop, seed, grads, need_input_grad=True):
+    def train_backward(self, tape, d_out, p_drop, seed, grads, need_input_grad=True, key_keep=None):
         """grads: num_layers*12 float32 GPU tensors in LAYER_TENSORS order per layer, accumulated into;
         None skips every parameter gradient (frozen stack: input gradient only).
         Returns dL/dh [rows, S, 512] (or None)."""
@@ -196,8 +206,9 @@ class DenoiserEngine:
                     raise ValueError("gradient buffers must be contiguous float32 tensors on the engine's device")
             arr = (C.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
         d_in = torch.empty_like(d_out) if need_input_grad else None
+        kk = self._key_keep(key_keep, rows, S)
         N.check(N.lib().mst_train_backward(self.handle, N.ptr(tape), N.ptr(d_out), rows, S, float(p_drop), int(seed),
-                                           N.ptr(d_in), arr, N.stream_ptr(self.device)))
+                                           N.ptr(kk), N.ptr(d_in), arr, N.stream_ptr(self.device)))
         return d_in
 
     def dropout_mask(self, seed, layer, site, p, n):

@@ -148,10 +148,19 @@ class _EngineHost:
 
     train_backend = "native"          # or "torch" (explicit opt-in; see the module docstring)
 
-    def _encoder_stack(self, seq):
-        """seqTransEncoder(seq) inside an autograd graph; seq: [S, B, d]."""
+    def __setattr__(self, name, value):
+        super().__setattr__(name, value)
+        if name == "train_backend":               # one switch for the module and the engine hosts inside it
+            for child in self.modules():
+                if child is not self and isinstance(child, _EngineHost):
+                    nn.Module.__setattr__(child, name, value)
+
+    def _encoder_stack(self, seq, key_keep=None):
+        """seqTransEncoder(seq) inside an autograd graph; seq: [S, B, d]; key_keep: None or bool [B, S]."""
         if self.train_backend == "torch":
-            return self.seqTransEncoder(seq)
+            if key_keep is None:
+                return self.seqTransEncoder(seq)
+            return self.seqTransEncoder(seq, src_key_padding_mask=~key_keep)
         if self.train_backend != "native":
             raise ValueError(f"train_backend must be 'native' or 'torch', not {self.train_backend!r}")
         if seq.device.type != "cuda":
@@ -159,7 +168,7 @@ class _EngineHost:
                                "(set train_backend = 'torch' explicitly to evaluate the stack with torch ops)")
         from .native_stack import EncoderStackFn, stack_parameters
         p = self.seqTransEncoder.layers[0].dropout.p if self.seqTransEncoder.training else 0.0
-        return EncoderStackFn.apply(seq, self, float(p), *stack_parameters(self.seqTransEncoder))
+        return EncoderStackFn.apply(seq, self, float(p), key_keep, *stack_parameters(self.seqTransEncoder))
 
     def _wants_autograd(self, x):
         return torch.is_grad_enabled() and (self.training or x.requires_grad
@@ -262,9 +271,11 @@ class MDM(nn.Module, _EngineHost):
         return super().train(mode)
 
 
-class MotionEncoder(nn.Module):
+class MotionEncoder(nn.Module, _EngineHost):
     """The frozen 'semantic discriminator' (:11-124): mu/sigma query tokens + frames through 8 masked
-    encoder layers; borrows the prior's input projection and positional table."""
+    encoder layers; borrows the prior's input projection and positional table.  Inside an autograd graph
+    (the fine-tune objective needs its INPUT gradient) the masked stack runs as the native training node with a
+    key-padding mask and no parameter gradients; without a graph it is plain torch ops (not on the sampling path)."""
 
     def __init__(self, modeltype, njoints, nfeats, num_actions, translation, pose_rep, glob, glob_rot,
                  latent_dim=256, ff_size=1024, num_layers=8, num_heads=4, dropout=0.1,
@@ -274,7 +285,7 @@ class MotionEncoder(nn.Module):
         self.modeltype, self.njoints, self.nfeats, self.num_actions = modeltype, njoints, nfeats, num_actions
         self.pose_rep, self.glob, self.glob_rot, self.translation = pose_rep, glob, glob_rot, translation
         self.latent_dim, self.ff_size, self.num_layers, self.num_heads = latent_dim, ff_size, num_layers, num_heads
-        self.dropout, self.ablation, self.activation = dropout, ablation, activation
+        self.dropout, self.ablation, self.activation, self.clip_dim = dropout, ablation, activation, clip_dim
         self.input_feats = njoints * nfeats
         self.cond_mask_prob = kargs.get('cond_mask_prob', 0.)
         self.muQuery = nn.Parameter(torch.randn(1, latent_dim))
@@ -324,8 +335,20 @@ class MotionEncoder(nn.Module):
         queries = torch.cat((self.muQuery[:1][None].repeat(1, bs, 1), self.sigmaQuery[:1][None].repeat(1, bs, 1)), axis=0)
         seq = self.mdm_model.sequence_pos_encoder(torch.cat((queries, frames), axis=0))
         keep = torch.cat((torch.ones((bs, 2), dtype=bool, device=x.device), keep), axis=1)
-        final = self.seqTransEncoder(seq, src_key_padding_mask=~keep)
+        if torch.is_grad_enabled() and seq.requires_grad and seq.is_cuda and self.train_backend == "native":
+            final = self._encoder_stack(seq, key_keep=keep)
+        else:
+            final = self.seqTransEncoder(seq, src_key_padding_mask=~keep)
         return final[0], enc_text
+
+    # ---- engine plumbing: own (frozen) encoder layers + the prior's projections
+    def _prior(self):
+        return self.mdm_model
+
+    def _engine_sources(self):
+        params = list(self.seqTransEncoder.parameters()) + [p for n, p in self.mdm_model.named_parameters()
+                                                             if not n.startswith(('clip_model.', 'seqTransEncoder.'))]
+        return "seqTransEncoder.layers.", "mdm_model.", params
 
     def mask_cond(self, cond, force_mask=False):
         return _mask_cond(self, cond, force_mask)

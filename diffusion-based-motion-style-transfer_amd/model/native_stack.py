@@ -1,6 +1,6 @@
 """The trainable encoder stack as ONE autograd node backed by the native engine.
 
-`EncoderStackFn.apply(seq, host, p_drop, *params)` replaces `self.seqTransEncoder(seq)`
+`EncoderStackFn.apply(seq, host, p_drop, key_keep, *params)` replaces `self.seqTransEncoder(seq)`
 (model/mdm_forstyledataset.py:622 of the reference) inside the graph that
 few_shot_style_finetune_losses (diffusion/gaussian_diffusion.py:1317-1399) back-propagates through:
 forward = mst_train_forward (activation tape + dropout), backward = mst_train_backward (dgrad / wgrad
@@ -69,14 +69,17 @@ class GradSink:
 
 class EncoderStackFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, seq, host, p_drop, *params):
+    def forward(ctx, seq, host, p_drop, key_keep, *params):
+        """key_keep: None or bool [B, S], False = padding key (the motion encoder's ~src_key_padding_mask)."""
         S, B, d = seq.shape
         eng = host.mst_engine(B, S - 1)
         # one 62-bit seed per call from torch's generator: torch.manual_seed reproduces the masks
         seed = int(torch.randint(0, 2 ** 62, (1,), device="cpu").item()) if p_drop > 0 else 0
         h = seq.detach().permute(1, 0, 2).contiguous()
-        out, tape = eng.train_forward(h, p_drop, seed)
-        ctx.eng, ctx.tape, ctx.p_drop, ctx.seed, ctx.host = eng, tape, p_drop, seed, host
+        if key_keep is not None:
+            key_keep = key_keep.to(torch.uint8).contiguous()
+        out, tape = eng.train_forward(h, p_drop, seed, key_keep=key_keep)
+        ctx.eng, ctx.tape, ctx.p_drop, ctx.seed, ctx.host, ctx.keep = eng, tape, p_drop, seed, host, key_keep
         ctx.params = params
         return out.permute(1, 0, 2).contiguous()
 
@@ -84,7 +87,7 @@ class EncoderStackFn(torch.autograd.Function):
     def backward(ctx, grad_out):
         need_in = ctx.needs_input_grad[0]
         views = None
-        if any(ctx.needs_input_grad[3:]):
+        if any(ctx.needs_input_grad[4:]):
             sink = ctx.host.__dict__.get("_mst_grad_sink")
             if sink is None or sink.ids != tuple(id(p) for p in ctx.params):
                 sink = ctx.host.__dict__["_mst_grad_sink"] = GradSink(ctx.host, list(ctx.params))
@@ -92,7 +95,7 @@ class EncoderStackFn(torch.autograd.Function):
                 sink.begin(grad_out.device)
             views = sink.views
         d_out = grad_out.permute(1, 0, 2).contiguous()
-        d_in = ctx.eng.train_backward(ctx.tape, d_out, ctx.p_drop, ctx.seed, views, need_input_grad=need_in)
+        d_in = ctx.eng.train_backward(ctx.tape, d_out, ctx.p_drop, ctx.seed, views, need_input_grad=need_in, key_keep=ctx.keep)
         ctx.tape = None
         gi = d_in.permute(1, 0, 2).contiguous() if need_in else None
-        return (gi, None, None) + (None,) * len(ctx.params)
+        return (gi, None, None, None) + (None,) * len(ctx.params)

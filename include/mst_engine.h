@@ -200,16 +200,20 @@ int mst_philox_normal(float* out_dev, int32_t batch, int32_t feats, int32_t fram
  *                       norm2.weight, .bias.  grads == NULL: no parameter gradients (frozen stack, input
  *                       gradient only).  rows / S / p_drop / seed must repeat the forward's.
  * h_in, h_out, d_out, d_in: float32 [rows][S][512] (clip-major; the reference's [S, B, 512] permuted).
+ * key_keep: NULL, or uint8 [rows][S] with 0 marking padding keys -- the inverse of the `src_key_padding_mask`
+ * the frozen MotionEncoder passes to its own 8-layer stack (model/mdm_forstyledataset.py:90-124); every clip
+ * must keep at least one key.
  * The engine's weights are the ones last uploaded with mst_load_weight.
  * mst_dropout_mask: the keep-multipliers (0 or 1/(1-p)) of the first n elements of site
  * (layer, site 0..3) -- lets a test rebuild the masked forward exactly in PyTorch.
  * ----------------------------------------------------------------------------------------- */
 int64_t mst_train_tape_bytes(const mst_engine* e, int32_t rows, int32_t S);
 int mst_train_forward(mst_engine* e, const float* h_in_dev, int32_t rows, int32_t S, float p_drop,
-                      uint64_t seed, void* tape_dev, float* h_out_dev, void* stream);
+                      uint64_t seed, const uint8_t* key_keep_dev, void* tape_dev, float* h_out_dev,
+                      void* stream);
 int mst_train_backward(mst_engine* e, const void* tape_dev, const float* d_out_dev, int32_t rows,
-                       int32_t S, float p_drop, uint64_t seed, float* d_in_dev,
-                       float* const* grads_host_array, void* stream);
+                       int32_t S, float p_drop, uint64_t seed, const uint8_t* key_keep_dev,
+                       float* d_in_dev, float* const* grads_host_array, void* stream);
 int mst_dropout_mask(uint64_t seed, int32_t layer, int32_t site, float p, uint64_t n, float* out_dev,
                      void* stream);
 

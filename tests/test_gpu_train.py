@@ -282,3 +282,32 @@ def test_native_gradients_reach_a_bucket_reducer():
     step()
     g = m.seqTransEncoder.layers[5].linear2.weight.grad
     assert rel_l2(g.cpu().numpy(), (2 * plain["seqTransEncoder.layers.5.linear2.weight"]).cpu().numpy()) < 1e-6
+
+
+def test_motion_encoder_masked_stack_native_vs_torch_ops():
+    """The frozen MotionEncoder (mdm_forstyledataset.py:90-124) inside an autograd graph: key-padding-masked stack
+    through the native node (input gradient only) against torch ops with src_key_padding_mask."""
+    m = _style_model().eval()
+    enc = m.motion_enc
+    x, t, y, tgt = _model_batch()
+    T_ = x.shape[-1]
+    fm = torch.ones(3, 1, 1, T_, device=_dev())
+    fm[1, ..., T_ - 9:] = 0                                   # ragged lengths
+    fm[2, ..., 40:] = 0
+    yy = {"mask": fm, "text_embed": y["text_embed"]}
+    w = torch.from_numpy(syn.normal(3, "tr/w", (3, 512))).to(_dev())
+    res = {}
+    for backend in ("native", "torch"):
+        m.train_backend = backend
+        assert enc.train_backend == backend                   # one switch for the hosts inside
+        xin = x.clone().requires_grad_(True)
+        mu, _ = enc(xin, y=yy)
+        (mu * w).sum().backward()
+        res[backend] = (mu.detach(), xin.grad.clone())
+    m.train_backend = "native"
+    assert rel_l2(res["native"][0].cpu().numpy(), res["torch"][0].cpu().numpy()) <= TOL_FWD
+    assert rel_l2(res["native"][1].cpu().numpy(), res["torch"][1].cpu().numpy()) <= TOL_GRAD
+    assert all(p.grad is None for p in enc.parameters())      # frozen: no parameter gradient is produced
+    # frames behind the padding never influence mu: their input gradient is exactly zero on both paths
+    assert float(res["native"][1][1, :, :, T_ - 9:].abs().max()) == 0.0
+    assert float(res["native"][1][2, :, :, 40:].abs().max()) == 0.0
