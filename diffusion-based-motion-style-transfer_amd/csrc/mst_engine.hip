@@ -451,6 +451,19 @@ static int launch_gemm_dma(dim3 grid, const SRC& xs, const f16* W, int ldw, int 
     return 0;
 }
 
+// Wide (128 x 256) GEMM launch.  Few token rows = few workgroups, each walking the whole K loop alone: the loop is then
+// bound by the DMA round trip per slab, not by bandwidth, so small launches use 64-deep slabs (half as many round trips,
+// one workgroup per CU is plenty); large launches keep 32-deep slabs and two co-resident workgroups per CU.
+#ifndef SMALL_M
+#define SMALL_M 2048
+#endif
+template <class SRC, class EPI>
+static int launch_wide(int M, int ny, const SRC& xs, const f16* W, int ldw, int K, const EPI& epi, hipStream_t st) {
+    if (M <= SMALL_M && (K % 64) == 0 && K >= 128)
+        return launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, 3, 1, 64>(wide_grid(M, ny), xs, W, ldw, K, epi, st, WIDE_XCD ? ny : 0);
+    return launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, ny), xs, W, ldw, K, epi, st, WIDE_XCD ? ny : 0);
+}
+
 template <int NKT>
 static int launch_attn_n(const f16* qkv, f16* out, int S, int rows, hipStream_t st) {
     auto kern = k_attention<NKT>;
@@ -579,7 +592,7 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
             {
                 ProfScope ps(e, FAM_QKV, st);
                 DEpiBiasF16<false> epi{w.b_in, ws.qkv, 3 * MST_D, M};
-                CHECK((launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, 3 * MST_D / 256), RowsDirect{ws.hx, MST_D}, w.w_in, MST_D, MST_D, epi, st, WIDE_XCD ? 3 * MST_D / 256 : 0)));
+                CHECK((launch_wide(M, 3 * MST_D / 256, RowsDirect{ws.hx, MST_D}, w.w_in, MST_D, MST_D, epi, st)));
             }
             DBG_STOP(1)
             {
@@ -601,7 +614,7 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
             const int nx = (M + 127) / 128;
             CHECK((launch_gemm_dma<128, 512, 2, 4, 3, 1>(dim3(((nx + 7) / 8) * 8 * 2, 1, 1), RowsDirect{ws.hx, MST_D}, w.w1, MST_D, MST_D, epi, st, 2)));
 #else
-            CHECK((launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, MST_FF / 256), RowsDirect{ws.hx, MST_D}, w.w1, MST_D, MST_D, epi, st, WIDE_XCD ? MST_FF / 256 : 0)));
+            CHECK((launch_wide(M, MST_FF / 256, RowsDirect{ws.hx, MST_D}, w.w1, MST_D, MST_D, epi, st)));
 #endif
         }
         DBG_STOP(4)
@@ -912,7 +925,7 @@ extern "C" int mst_train_forward(mst_engine* e, const float* h_in, int32_t rows,
         const TapeL& a = t.L[l];
         {
             DEpiBiasF16<false> epi{w.b_in, a.qkv, 3 * MST_D, M};
-            CHECK((launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, 3 * MST_D / 256), RowsDirect{t.sh[l], MST_D}, w.w_in, MST_D, MST_D, epi, st, WIDE_XCD ? 3 * MST_D / 256 : 0)));
+            CHECK((launch_wide(M, 3 * MST_D / 256, RowsDirect{t.sh[l], MST_D}, w.w_in, MST_D, MST_D, epi, st)));
         }
         CHECK(launch_attn_train(a.qkv, a.att, S, rows, make_drop(seed, l, 0, p_drop), key_keep, st));
         {
@@ -921,7 +934,7 @@ extern "C" int mst_train_forward(mst_engine* e, const float* h_in, int32_t rows,
         }
         {
             DEpiRowOp<OpFfn1Train> epi{w.b1, M, OpFfn1Train{a.pre, a.hid, MST_FF, make_drop(seed, l, 2, p_drop)}};
-            CHECK((launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, MST_FF / 256), RowsDirect{a.x1h, MST_D}, w.w1, MST_D, MST_D, epi, st, WIDE_XCD ? MST_FF / 256 : 0)));
+            CHECK((launch_wide(M, MST_FF / 256, RowsDirect{a.x1h, MST_D}, w.w1, MST_D, MST_D, epi, st)));
         }
         {
             DEpiResidLNTrain epi{w.b2, w.g2, w.be2, a.x1h, a.x1l, a.z2h, a.z2l, t.sh[l + 1], t.sl[l + 1], M, make_drop(seed, l, 3, p_drop)};
@@ -966,6 +979,7 @@ static int wgrad(mst_engine* e, const f16* dY, int n_out, const f16* X, int k_in
     const int slabs = (M + 31) / 32;
     if (nsplit > slabs) nsplit = slabs;
     if ((size_t)nsplit > t.split_cap) nsplit = (int)t.split_cap;
+    if (M <= SMALL_M) nsplit = 1;        // few tokens: one workgroup per tile adds its product straight into dW (no partials, no reduce launch)
     const int kchunk = ((slabs + nsplit - 1) / nsplit) * 32;
     nsplit = (M + kchunk - 1) / kchunk;
     auto kern = k_wgrad_tr;
@@ -976,11 +990,17 @@ static int wgrad(mst_engine* e, const f16* dY, int n_out, const f16* X, int k_in
     }
     static_assert(DEpiF32::smem_bytes<128, 256>() <= WgTile::SMEM, "epilogue tile must fit the ring");
     const size_t nelem = (size_t)n_out * k_in;
-    DEpiF32 epi{nullptr, t.part, k_in, n_out};
-    hipLaunchKernelGGL(kern, dim3(n_out / 128, k_in / 256, nsplit), dim3(512), WgTile::SMEM, st, dY, n_out, X, k_in, M, kchunk, nelem, epi);
-    HIPCHECK(hipGetLastError());
-    hipLaunchKernelGGL(k_splitk_reduce, dim3(256), dim3(256), 0, st, t.part, nsplit, nelem, t.gscale, dW);
-    HIPCHECK(hipGetLastError());
+    if (nsplit == 1) {
+        DEpiF32 epi{dW, dW, k_in, n_out, t.gscale};
+        hipLaunchKernelGGL(kern, dim3(n_out / 128, k_in / 256, 1), dim3(512), WgTile::SMEM, st, dY, n_out, X, k_in, M, kchunk, nelem, epi);
+        HIPCHECK(hipGetLastError());
+    } else {
+        DEpiF32 epi{nullptr, t.part, k_in, n_out};
+        hipLaunchKernelGGL(kern, dim3(n_out / 128, k_in / 256, nsplit), dim3(512), WgTile::SMEM, st, dY, n_out, X, k_in, M, kchunk, nelem, epi);
+        HIPCHECK(hipGetLastError());
+        hipLaunchKernelGGL(k_splitk_reduce, dim3(256), dim3(256), 0, st, t.part, nsplit, nelem, t.gscale, dW);
+        HIPCHECK(hipGetLastError());
+    }
     if (db) {
         const int rpb = 128;
         hipLaunchKernelGGL(k_colsum_f16, dim3(n_out / 256, (M + rpb - 1) / rpb), dim3(256), 0, st, dY, n_out, M, rpb, t.gscale, db);
@@ -1047,14 +1067,14 @@ extern "C" int mst_train_backward(mst_engine* e, const void* tape, const float* 
         // d pre = (dbr2 W2) * mask * gelu'(pre)
         {
             DEpiRowOp<OpGeluBwd> epi{nullptr, M, OpGeluBwd{a.pre, dpre, MST_FF, make_drop(seed, l, 2, p_drop)}};
-            CHECK((launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, MST_FF / 256), RowsDirect{dbr2, MST_D}, w.w2T, MST_D, MST_D, epi, st, WIDE_XCD ? MST_FF / 256 : 0)));
+            CHECK((launch_wide(M, MST_FF / 256, RowsDirect{dbr2, MST_D}, w.w2T, MST_D, MST_D, epi, st)));
         }
         TO_SIDE()
         if (wg) CHECK(wgrad(e, dpre, MST_FF, a.x1h, MST_D, M, G[4], G[5], sw));                    // dW1 += dpre^T x1, db1
         // g(x1) = dpre W1 + dz2  -> gB
         {
             DEpiF32 epi{gA, gB, MST_D, M};
-            CHECK((launch_gemm_dma<DG_BT, 256, DG_BT / 64, 2, WIDE_NS, 1>(dg_grid(M, MST_D / 256), RowsDirect{dpre, MST_FF}, w.w1T, MST_FF, MST_FF, epi, st, WIDE_XCD ? MST_D / 256 : 0)));
+            CHECK((launch_wide(M, MST_D / 256, RowsDirect{dpre, MST_FF}, w.w1T, MST_FF, MST_FF, epi, st)));
         }
         // LayerNorm1 backward: gB -> dz1 (gA), dbr1 = d(out-proj output); dgamma1, dbeta1, db_out
         hipLaunchKernelGGL(k_ln_bwd, dim3(ln_blocks), dim3(256), 0, st, gB, a.z1h, a.z1l, w.g1, M, make_drop(seed, l, 1, p_drop), w_.gscale,
@@ -1065,7 +1085,7 @@ extern "C" int mst_train_backward(mst_engine* e, const void* tape, const float* 
         // d att = dbr1 W_out
         {
             DEpiBiasF16<false> epi{w_.zeros, w_.datt, MST_D, M};
-            CHECK((launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, MST_D / 256), RowsDirect{dbr1, MST_D}, w.w_outT, MST_D, MST_D, epi, st, WIDE_XCD ? MST_D / 256 : 0)));
+            CHECK((launch_wide(M, MST_D / 256, RowsDirect{dbr1, MST_D}, w.w_outT, MST_D, MST_D, epi, st)));
         }
         // attention backward -> d qkv
         CHECK(launch_attn_bwd(a.qkv, a.att, w_.datt, dqkv, S, rows, make_drop(seed, l, 0, p_drop), key_keep, st));
@@ -1078,7 +1098,7 @@ extern "C" int mst_train_backward(mst_engine* e, const void* tape, const float* 
         // g(x_in) = dqkv W_in + dz1 -> gB
         {
             DEpiF32 epi{gA, gB, MST_D, M};
-            CHECK((launch_gemm_dma<DG_BT, 256, DG_BT / 64, 2, WIDE_NS, 1>(dg_grid(M, MST_D / 256), RowsDirect{dqkv, 3 * MST_D}, w.w_inT, 3 * MST_D, 3 * MST_D, epi, st, WIDE_XCD ? MST_D / 256 : 0)));
+            CHECK((launch_wide(M, MST_D / 256, RowsDirect{dqkv, 3 * MST_D}, w.w_inT, 3 * MST_D, 3 * MST_D, epi, st)));
         }
     }
 #undef TO_SIDE

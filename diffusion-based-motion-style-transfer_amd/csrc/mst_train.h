@@ -116,6 +116,7 @@ struct OpGeluBwd {
 // ------------------------------------------------------------------------------------------------------------
 struct DEpiF32 {
     const float* resid; float* out; int ldo; int M;
+    const float* gscale = nullptr;                    // non-null: accumulators are multiplied by gscale[1] (the unscale factor) first
     __device__ __forceinline__ int rows() const { return M; }
     template <int BT> static constexpr int pass_rows() { return BT >= 128 ? 64 : 32; }       // tile rows staged per pass
     template <int BT, int BF> static constexpr int smem_bytes() { return pass_rows<BT>() * (BF * 4 + 16); }
@@ -147,6 +148,11 @@ struct DEpiF32 {
                 if (tok >= M) continue;
                 f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * LD + lane * 16);
                 const size_t o = (size_t)tok * ldo + f0 + lane * 4;
+                if (gscale) {
+                    const float us = gscale[1];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[i] *= us;
+                }
                 if (resid) {
                     const f32x4 r = *reinterpret_cast<const f32x4*>(resid + o);
 #pragma unroll

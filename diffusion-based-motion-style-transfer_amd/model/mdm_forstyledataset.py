@@ -122,7 +122,10 @@ class _EngineHost:
                                       latent_dim=self.latent_dim, num_heads=self.num_heads, ff_size=self.ff_size,
                                       clip_dim=self.clip_dim)
             ent = cache[dev] = {"eng": eng, "rows": rows_cap, "frames": frames_cap, "version": None}
-        lp, pp, params = self._engine_sources()
+        src = self.__dict__.get("_mst_sources")          # (layer prefix, prior prefix, parameters to watch): built once;
+        if src is None:                                  # Parameter objects survive .to() / load_state_dict / optimizer steps
+            src = self.__dict__["_mst_sources"] = self._engine_sources()
+        lp, pp, params = src
         version = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params)
         if ent["version"] != version:        # first use, optimizer step, load_state_dict, .to()
             sd = {k: v for k, v in self.state_dict().items() if 'clip_model.' not in k}

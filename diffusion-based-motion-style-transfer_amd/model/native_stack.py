@@ -21,11 +21,15 @@ from ..engine import LAYER_TENSORS
 
 
 def stack_parameters(encoder):
-    """The 12 tensors of every layer in LAYER_TENSORS order."""
+    """The 12 tensors of every layer in LAYER_TENSORS order (cached on the encoder: the Parameter objects are stable)."""
+    cached = encoder.__dict__.get("_mst_stack_params")
+    if cached is not None:
+        return cached
     out = []
     for layer in encoder.layers:
         named = dict(layer.named_parameters())
         out.extend(named[k] for k in LAYER_TENSORS)
+    encoder.__dict__["_mst_stack_params"] = out
     return out
 
 

@@ -36,8 +36,9 @@ content = to(syn.normal(7, "content", (1, F, 1, T)))
 style = to(syn.normal(7, "style", (1, F, 1, T)))
 mask1 = to(syn.root_horizontal_mask(1, F, T))
 maskB = to(syn.root_horizontal_mask(B, F, T))
-y1 = {"y": {"text": ["a person walks"], "mask": torch.ones(1, 1, 1, T, device=dev), "inpainting_mask": mask1, "inpainted_motion": content}}
-yB = {"y": {"text": ["a person walks"] * B, "mask": torch.ones(B, 1, 1, T, device=dev), "inpainting_mask": maskB, "inpainted_motion": t2m}}
+emb1 = to(syn.normal(7, "text/a person walks", (1, 512)))          # post-CLIP embeddings (CLIP is outside the engine and absent here)
+y1 = {"y": {"text": ["a person walks"], "text_embed": emb1, "mask": torch.ones(1, 1, 1, T, device=dev), "inpainting_mask": mask1, "inpainted_motion": content}}
+yB = {"y": {"text": ["a person walks"] * B, "text_embed": emb1.expand(B, -1).contiguous(), "mask": torch.ones(B, 1, 1, T, device=dev), "inpainting_mask": maskB, "inpainted_motion": t2m}}
 tt = torch.randint(0, 20, (B,), device=dev)
 opt = torch.optim.AdamW(model.parameters_wo_enc(), lr=1e-5)
 
