@@ -57,6 +57,10 @@ SIGNATURES = {
     "mst_train_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_uint64,
                                      C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
     "mst_dropout_mask": (C.c_int, [C.c_uint64, C.c_int32, C.c_int32, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "mst_adamw_workspace_bytes": (C.c_int64, [C.c_int32, C.POINTER(C.c_int64)]),
+    "mst_adamw_step": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                 C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_float, C.c_float, C.c_float, C.c_float,
+                                 C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mst_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "mst_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int32),
                                    C.c_int32]),

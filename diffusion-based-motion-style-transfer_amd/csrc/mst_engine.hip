@@ -1,10 +1,12 @@
 // libmst_engine.so -- host side: engine state, launch sequence, C ABI (include/mst_engine.h).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -1118,6 +1120,50 @@ extern "C" int mst_train_backward(mst_engine* e, const void* tape, const float* 
 extern "C" int mst_dropout_mask(uint64_t seed, int32_t layer, int32_t site, float p, uint64_t n, float* out, void* stream) {
     if (!out || site < 0 || site > 3 || layer < 0 || !(p >= 0.f && p < 1.f) || n >= 0xFFFFFFFFull) return fail("mst_dropout_mask: bad arguments");
     hipLaunchKernelGGL(k_dropout_mask, dim3(1024), dim3(256), 0, (hipStream_t)stream, make_drop(seed, layer, site, p), (size_t)n, out);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ optimizer ABI
+extern "C" int64_t mst_adamw_workspace_bytes(int32_t n_tensors, const int64_t* numel) {
+    if (n_tensors < 1 || !numel) return -1;
+    int64_t chunks = 0;
+    for (int i = 0; i < n_tensors; i++) chunks += (numel[i] + kAdamChunk - 1) / kAdamChunk;
+    return (int64_t)n_tensors * (int64_t)sizeof(AdamTensor) + chunks * (int64_t)sizeof(AdamChunk) + 256;
+}
+
+extern "C" int mst_adamw_step(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                              float* const* exp_avg_sq, const int64_t* numel, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, int32_t step, float* norms_dev, void* workspace_dev, int64_t workspace_bytes,
+                              void* stream) {
+    if (n_tensors < 1 || !params || !grads || !exp_avg || !exp_avg_sq || !numel || !workspace_dev || step < 1)
+        return fail("mst_adamw_step: bad arguments");
+    if (workspace_bytes < mst_adamw_workspace_bytes(n_tensors, numel)) return fail("mst_adamw_step: workspace too small");
+    std::vector<AdamTensor> tt(n_tensors);
+    std::vector<AdamChunk> cc;
+    for (int i = 0; i < n_tensors; i++) {
+        if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i] || numel[i] < 1) return fail("mst_adamw_step: null tensor %d", i);
+        tt[i] = AdamTensor{params[i], grads[i], exp_avg[i], exp_avg_sq[i], (long long)numel[i]};
+        for (long long s0 = 0; s0 < numel[i]; s0 += kAdamChunk) cc.push_back(AdamChunk{i, 0, s0});
+    }
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace_dev;
+    const size_t tb = sizeof(AdamTensor) * tt.size();
+    const size_t tb_al = (tb + 255) / 256 * 256;
+    // The tables change only when a tensor moves (a new gradient buffer): upload them synchronously then, and not at all
+    // when the same pointers come back (the usual case: torch's caching allocator returns the same blocks every iteration)
+    static std::map<void*, std::vector<AdamTensor>> uploaded;
+    std::vector<AdamTensor>& last = uploaded[workspace_dev];
+    if (last.size() != tt.size() || memcmp(last.data(), tt.data(), tb) != 0) {
+        HIPCHECK(hipStreamSynchronize(st));                 // a previous step may still be reading the old tables
+        HIPCHECK(hipMemcpy(ws, tt.data(), tb, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(ws + tb_al, cc.data(), sizeof(AdamChunk) * cc.size(), hipMemcpyHostToDevice));
+        last = tt;
+    }
+    const float bias1 = 1.0f - (float)pow((double)beta1, (double)step);
+    const float bias2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    hipLaunchKernelGGL(k_adamw_multi, dim3((unsigned)cc.size()), dim3(256), 0, st, (const AdamTensor*)ws, (const AdamChunk*)(ws + tb_al),
+                       lr, beta1, beta2, eps, weight_decay, bias1, bias2_sqrt, norms_dev);
     HIPCHECK(hipGetLastError());
     return 0;
 }

@@ -933,4 +933,54 @@ __global__ __launch_bounds__(256) void k_colsum_f16(const f16* __restrict__ in, 
     atomicAdd(colsum + blockIdx.x * 256 + threadIdx.x, t * gscale[1]);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Fused multi-tensor AdamW + the trainer's norms (train/training_loop.py:196-200 `mp_trainer.optimize(opt)` of the
+// reference = fp16_util.py:208-223: 192 per-tensor `.item()` syncs for grad/param norms, then torch AdamW's
+// per-tensor kernels).  One launch walks every (tensor, 64 K-element chunk) pair of a device-side table: updates
+// p, exp_avg, exp_avg_sq in place with torch.optim.AdamW's arithmetic (decoupled decay first, bias corrections as
+// step_size = lr / (1 - b1^t) and denom = sqrt(v) / sqrt(1 - b2^t) + eps) and accumulates sum g^2 and sum p^2
+// (parameters BEFORE the update, as the reference logs them) into norms[0..1].  HBM-bound: 28 bytes per parameter.
+// ------------------------------------------------------------------------------------------------------------
+struct AdamTensor { float* p; const float* g; float* m; float* v; long long numel; };
+struct AdamChunk { int tensor; int pad; long long start; };
+constexpr int kAdamChunk = 65536;
+
+__global__ __launch_bounds__(256) void k_adamw_multi(const AdamTensor* __restrict__ tensors, const AdamChunk* __restrict__ chunks,
+                                                     float lr, float beta1, float beta2, float eps, float wd,
+                                                     float bias1, float bias2_sqrt, float* __restrict__ norms) {
+    const AdamChunk ck = chunks[blockIdx.x];
+    const AdamTensor t = tensors[ck.tensor];
+    long long end = ck.start + kAdamChunk;
+    if (end > t.numel) end = t.numel;
+    const float step_size = lr / bias1, decay = 1.0f - lr * wd;
+    float sg = 0.f, sp = 0.f;
+    for (long long i = ck.start + threadIdx.x; i < end; i += 256) {
+        const float g = t.g[i];
+        float p = t.p[i];
+        sg += g * g;
+        sp += p * p;
+        p *= decay;
+        const float m0 = t.m[i];
+        const float m = m0 + (1.0f - beta1) * (g - m0);       // torch: exp_avg.lerp_(grad, 1 - beta1)
+        const float v = beta2 * t.v[i] + (1.0f - beta2) * g * g;
+        const float denom = sqrtf(v) / bias2_sqrt + eps;
+        t.m[i] = m;
+        t.v[i] = v;
+        t.p[i] = p - step_size * (m / denom);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sg += __shfl_xor(sg, o);
+        sp += __shfl_xor(sp, o);
+    }
+    __shared__ float red[2][4];
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sg; red[1][threadIdx.x >> 6] = sp; }
+    __syncthreads();
+    if (threadIdx.x == 0 && norms) {
+        atomicAdd(norms + 0, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(norms + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+
 }  // namespace mst

@@ -217,6 +217,22 @@ int mst_train_backward(mst_engine* e, const void* tape_dev, const float* d_out_d
 int mst_dropout_mask(uint64_t seed, int32_t layer, int32_t site, float p, uint64_t n, float* out_dev,
                      void* stream);
 
+/* -------------------------------------------------------------------------------------------
+ * Optimizer step of the fine-tune loop: `self.mp_trainer.optimize(self.opt)`,
+ * train/training_loop.py:196-200 -> diffusion/fp16_util.py:208-223 (`_compute_norms`: one
+ * `.item()` sync per tensor for grad and param norms) + torch.optim.AdamW.step (training_loop.py:96).
+ * ONE launch over all tensors: AdamW update in place (torch's arithmetic: decoupled weight decay,
+ * step_size = lr/(1-b1^t), denom = sqrt(v)/sqrt(1-b2^t) + eps) and norms_dev[0] += sum g^2,
+ * norms_dev[1] += sum p^2 of the parameters BEFORE the update (what the reference logs).
+ * All pointer arrays are HOST arrays of device pointers; workspace_dev holds the device-side tables
+ * (mst_adamw_workspace_bytes).  `step` is the 1-based step count of these tensors.
+ * ----------------------------------------------------------------------------------------- */
+int64_t mst_adamw_workspace_bytes(int32_t n_tensors, const int64_t* numel_host);
+int mst_adamw_step(int32_t n_tensors, float* const* params, const float* const* grads,
+                   float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel_host, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                   float* norms_dev, void* workspace_dev, int64_t workspace_bytes, void* stream);
+
 /* Per-kernel device timing of the most recent mst_sample_loop / mst_forward when profiling is
  * enabled: HIP events recorded around every launch on the caller's stream.  names/ms are arrays
  * of `cap` entries filled with per-kernel-family totals; returns the number of families. */

@@ -40,10 +40,12 @@ emb1 = to(syn.normal(7, "text/a person walks", (1, 512)))          # post-CLIP e
 y1 = {"y": {"text": ["a person walks"], "text_embed": emb1, "mask": torch.ones(1, 1, 1, T, device=dev), "inpainting_mask": mask1, "inpainted_motion": content}}
 yB = {"y": {"text": ["a person walks"] * B, "text_embed": emb1.expand(B, -1).contiguous(), "mask": torch.ones(B, 1, 1, T, device=dev), "inpainting_mask": maskB, "inpainted_motion": t2m}}
 tt = torch.randint(0, 20, (B,), device=dev)
-opt = torch.optim.AdamW(model.parameters_wo_enc(), lr=1e-5)
+from mst_amd.optim import FusedAdamW
+opts = {"native": FusedAdamW(model.parameters_wo_enc(), lr=1e-5), "torch": torch.optim.AdamW(model.parameters_wo_enc(), lr=1e-5)}
 
 
 def iteration(autocast=False):
+    opt = opts[model.train_backend]
     opt.zero_grad(set_to_none=True)
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
         terms = d_ddim.few_shot_style_finetune_losses(model, t2m, tt, content, style, skip_steps=700, model_kwargs=y1,
