@@ -61,6 +61,8 @@ SIGNATURES = {
     "mst_adamw_step": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                  C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_float, C.c_float, C.c_float, C.c_float,
                                  C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "mst_recover_from_ric": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_void_p, C.c_void_p]),
     "mst_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "mst_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int32),
                                    C.c_int32]),

@@ -152,4 +152,78 @@ __global__ void k_philox_normal(float* __restrict__ out, int F, int T, unsigned 
     }
 }
 
+
+// Post-sampling: normalised hml_vec clip [B][F][T] -> joint positions [B][T][J][3] in one launch
+// (sample.permute(0,2,3,1) * std + mean, then recover_from_ric: root yaw = running sum of the yaw velocities, root
+// XZ = running sum of the yaw-rotated XZ velocities, local joints rotated by the same yaw and moved to the root;
+// data_loaders/humanml/scripts/motion_process.py:389-410, :444-461, quaternion.py:88-99).  One workgroup per clip:
+// the two running sums over <= 224 frames are done sequentially by one lane in torch.cumsum's order (microseconds),
+// everything else is one thread per (frame, joint).  The quaternion is (cos a, 0, sin a, 0) with the FULL angle, as
+// the reference has it.
+__device__ __forceinline__ void yaw_rot(float c, float sn, float vx, float vy, float vz, float& ox, float& oy, float& oz) {
+    // qrot with s = c, u = (0, sn, 0):  uv = u x v,  uuv = u x uv,  out = v + 2 (s uv + uuv)
+    const float uvx = sn * vz, uvz = -sn * vx;                 // uv = (sn vz, 0, -sn vx)
+    const float uuvx = sn * uvz, uuvz = -sn * uvx;             // uuv = (sn uvz, 0, -sn uvx)
+    ox = vx + 2.0f * (c * uvx + uuvx);
+    oy = vy;
+    oz = vz + 2.0f * (c * uvz + uuvz);
+}
+
+__global__ __launch_bounds__(256) void k_recover_from_ric(const float* __restrict__ x, const float* __restrict__ mean,
+                                                          const float* __restrict__ stdv, int F, int T, int J,
+                                                          float* __restrict__ out) {
+    extern __shared__ float sm[];            // ang[T], px[T], pz[T], cs[T], sn[T]
+    float* ang = sm; float* px = sm + T; float* pz = sm + 2 * T; float* cs = sm + 3 * T; float* sn = sm + 4 * T;
+    const int b = blockIdx.x;
+    const float* xb = x + (size_t)b * F * T;
+    auto den = [&](int f, int t) { return xb[(size_t)f * T + t] * stdv[f] + mean[f]; };
+    if (threadIdx.x == 0) {
+        float a = 0.f;
+        for (int t = 0; t < T; t++) {        // exclusive running sum of the yaw velocity
+            ang[t] = a;
+            a += den(0, t);
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += 256) {
+        float s_, c_;
+        sincosf(ang[t], &s_, &c_);
+        cs[t] = c_;
+        sn[t] = s_;
+        float ox = 0.f, oy, oz = 0.f;
+        if (t > 0) yaw_rot(c_, s_, den(1, t - 1), 0.f, den(2, t - 1), ox, oy, oz);
+        px[t] = ox;
+        pz[t] = oz;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float ax = 0.f, az = 0.f;
+        for (int t = 0; t < T; t++) {        // inclusive running sums of the rotated root velocity
+            ax += px[t];
+            az += pz[t];
+            px[t] = ax;
+            pz[t] = az;
+        }
+    }
+    __syncthreads();
+    float* ob = out + (size_t)b * T * J * 3;
+    for (int i = threadIdx.x; i < T * J; i += 256) {
+        const int t = i / J, j = i - t * J;
+        float ox, oy, oz;
+        if (j == 0) {
+            ox = px[t];
+            oy = den(3, t);
+            oz = pz[t];
+        } else {
+            const int f = 4 + 3 * (j - 1);
+            yaw_rot(cs[t], sn[t], den(f, t), den(f + 1, t), den(f + 2, t), ox, oy, oz);
+            ox += px[t];
+            oz += pz[t];
+        }
+        ob[(size_t)i * 3 + 0] = ox;
+        ob[(size_t)i * 3 + 1] = oy;
+        ob[(size_t)i * 3 + 2] = oz;
+    }
+}
+
 }  // namespace mst

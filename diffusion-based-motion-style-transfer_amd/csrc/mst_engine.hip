@@ -1168,6 +1168,18 @@ extern "C" int mst_adamw_step(int32_t n_tensors, float* const* params, const flo
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------ post-sampling ABI
+extern "C" int mst_recover_from_ric(const float* sample, const float* mean, const float* stdv, int32_t batch, int32_t feats,
+                                    int32_t frames, int32_t joints, float* out, void* stream) {
+    if (!sample || !mean || !stdv || !out || batch < 1 || frames < 1 || joints < 1) return fail("mst_recover_from_ric: bad arguments");
+    if (feats < 4 + 3 * (joints - 1)) return fail("mst_recover_from_ric: %d features cannot hold %d joints", feats, joints);
+    if (frames > 4096) return fail("mst_recover_from_ric: frames %d > 4096", frames);
+    hipLaunchKernelGGL(k_recover_from_ric, dim3(batch), dim3(256), sizeof(float) * 5 * frames, (hipStream_t)stream, sample, mean, stdv,
+                       feats, frames, joints, out);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------ debug ABI
 extern "C" int mst_debug_stop_after(mst_engine* e, int32_t layer, int32_t stage) {
     if (!e) return fail("mst_debug_stop_after: null engine");

@@ -233,6 +233,17 @@ int mst_adamw_step(int32_t n_tensors, float* const* params, const float* const* 
                    float beta1, float beta2, float eps, float weight_decay, int32_t step,
                    float* norms_dev, void* workspace_dev, int64_t workspace_bytes, void* stream);
 
+/* -------------------------------------------------------------------------------------------
+ * Post-sampling tensor ops, one launch (sample/demo_style_transfer.py:265-267,
+ * train/finetune_style_diffusion.py:331-332):
+ *     sample = dataset.inv_transform(sample.cpu().permute(0, 2, 3, 1)).float()   dataset.py:478-479
+ *     joints = recover_from_ric(sample, n_joints)                                 motion_process.py:444-461
+ * sample_dev: [batch][feats][1][frames] float32 normalised hml_vec (the samplers' output layout),
+ * mean_dev / std_dev: [feats]; out_dev: [batch][1][frames][joints][3].  The clip never leaves the GPU.
+ * ----------------------------------------------------------------------------------------- */
+int mst_recover_from_ric(const float* sample_dev, const float* mean_dev, const float* std_dev, int32_t batch,
+                         int32_t feats, int32_t frames, int32_t joints, float* out_dev, void* stream);
+
 /* Per-kernel device timing of the most recent mst_sample_loop / mst_forward when profiling is
  * enabled: HIP events recorded around every launch on the caller's stream.  names/ms are arrays
  * of `cap` entries filled with per-kernel-family totals; returns the number of families. */

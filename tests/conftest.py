@@ -25,4 +25,4 @@ def rel_l2(a, b):
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np
-    return {n: np.load(os.path.join(GOLDEN, n + ".npz")) for n in ("schedules", "masks", "denoise", "train_loop")}
+    return {n: np.load(os.path.join(GOLDEN, n + ".npz")) for n in ("schedules", "masks", "denoise", "train_loop", "post")}
