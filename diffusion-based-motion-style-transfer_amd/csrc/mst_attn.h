@@ -235,6 +235,9 @@ __global__ __launch_bounds__(512) void k_qkv_attention(const f16* __restrict__ h
         }
     }
     __builtin_amdgcn_s_barrier();                       // ring dead: reuse it for the K / V images
+#if defined(QA_STOP) && QA_STOP == 1                    // timing ablation: projection main loop only
+    { float keep = 0.f; for (int n = 0; n < 12; n++) for (int r = 0; r < 16; r++) keep += acc[n][r]; if (keep == 123.456f) out[0] = (f16)keep; return; }
+#endif
 
     char* ks_img = smem;
     char* vs_img = smem + NKT * 32 * 256;
@@ -268,6 +271,9 @@ __global__ __launch_bounds__(512) void k_qkv_attention(const f16* __restrict__ h
     }
     __syncthreads();
     if (!active) return;
+#if defined(QA_STOP) && QA_STOP == 2                    // + bias / Q fragments / K, V images
+    { float keep = 0.f; for (int s_ = 0; s_ < 8; s_++) for (int j = 0; j < 8; j++) keep += (float)qf[s_][j]; if (keep == 123.456f) out[0] = (f16)keep; return; }
+#endif
 
     // ---- attention core (as k_attention, Q already in registers)
     f32x16 sc[NKT];
@@ -307,6 +313,9 @@ __global__ __launch_bounds__(512) void k_qkv_attention(const f16* __restrict__ h
         }
     l += __shfl_xor(l, 32);
     const float inv_l = 1.0f / l;
+#if defined(QA_STOP) && QA_STOP == 3                    // + scores and softmax
+    { if (l == 123.456f) out[0] = (f16)l; return; }
+#endif
     f16x8 pf[NKT][2];
 #pragma unroll
     for (int kt = 0; kt < NKT; kt++)
