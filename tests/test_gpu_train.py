@@ -311,3 +311,58 @@ def test_motion_encoder_masked_stack_native_vs_torch_ops():
     # frames behind the padding never influence mu: their input gradient is exactly zero on both paths
     assert float(res["native"][1][1, :, :, T_ - 9:].abs().max()) == 0.0
     assert float(res["native"][1][2, :, :, 40:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("rows,S,p", [(1, 2, 0.0), (1, 33, 0.3), (4, 64, 0.0), (2, 77, 0.5)])
+def test_train_edge_shapes(rows, S, p):
+    """Smallest sequence (2 tokens), tile-boundary lengths (33, 64), one clip, heavy dropout: forward, input gradient and a
+    few parameter gradients against fp32 autograd with the engine's masks; frozen mode (grads=None) returns the same dL/dh."""
+    eng, w = engine_for("xia")
+    h = torch.from_numpy(syn.normal(SEED, f"edge/h/{rows}/{S}", (rows, S, D))).to(_dev())
+    r = torch.from_numpy(syn.normal(SEED, f"edge/r/{rows}/{S}", (rows, S, D))).to(_dev())
+    seed = 77 + S
+    params = layer_params(w, True)
+    href = h.clone().requires_grad_(True)
+    masks = engine_masks(eng, seed, p, rows, S) if p > 0 else None
+    ref = torch_stack(href, params, masks)
+    (ref * r).sum().backward()
+    out, tape = eng.train_forward(h, p, seed)
+    grads = [torch.zeros_like(q) for q in params]
+    d_in = eng.train_backward(tape, r, p, seed, grads)
+    assert rel_l2(out.cpu().numpy(), ref.detach().cpu().numpy()) <= TOL_FWD
+    assert rel_l2(d_in.cpu().numpy(), href.grad.cpu().numpy()) <= TOL_GRAD
+    for i in (0, 1, 2, 4, 6, 7, 8, 11, 84 + 0, 84 + 5, 84 + 10):
+        assert rel_l2(grads[i].cpu().numpy(), params[i].grad.cpu().numpy()) <= 2 * TOL_GRAD, (i, LAYER_TENSORS[i % 12])
+    d_in2 = eng.train_backward(tape, r, p, seed, None)
+    assert rel_l2(d_in2.cpu().numpy(), d_in.cpu().numpy()) < 1e-6
+
+
+def test_train_key_padding_mask_engine_level():
+    """mst_train_forward / backward with key_keep: padded keys get no attention and no K/V gradient; vs torch autograd."""
+    eng, w = engine_for("xia")
+    rows, S = 3, 50
+    h = torch.from_numpy(syn.normal(SEED, "kpm/h", (rows, S, D))).to(_dev())
+    r = torch.from_numpy(syn.normal(SEED, "kpm/r", (rows, S, D))).to(_dev())
+    keep = torch.ones(rows, S, dtype=torch.bool, device=_dev())
+    keep[0, 31:] = False
+    keep[2, 5:] = False
+    params = layer_params(w, True)
+    href = h.clone().requires_grad_(True)
+    x = href
+    import torch.nn as nn
+    layer = nn.TransformerEncoderLayer(d_model=D, nhead=H, dim_feedforward=1024, dropout=0.0, activation="gelu")
+    enc = nn.TransformerEncoder(layer, num_layers=L, enable_nested_tensor=False).to(_dev()).train()
+    enc.load_state_dict({k[len("seqTransEncoder."):]: torch.from_numpy(v) for k, v in w.items() if k.startswith("seqTransEncoder.")})
+    ref = enc(x.permute(1, 0, 2), src_key_padding_mask=~keep).permute(1, 0, 2)
+    valid = keep[:, :, None].float()                      # outputs at padded positions are unconstrained: score the real ones
+    (ref * r * valid).sum().backward()
+    out, tape = eng.train_forward(h, 0.0, 0, key_keep=keep)
+    grads = [torch.zeros_like(q) for q in params]
+    d_in = eng.train_backward(tape, r * valid, 0.0, 0, grads, key_keep=keep)
+    assert rel_l2((out * valid).cpu().numpy(), (ref.detach() * valid).cpu().numpy()) <= TOL_FWD
+    assert rel_l2(d_in.cpu().numpy(), href.grad.cpu().numpy()) <= TOL_GRAD
+    ref_g = dict(enc.named_parameters())
+    for i, k in enumerate(LAYER_TENSORS):
+        assert rel_l2(grads[i].cpu().numpy(), ref_g[f"layers.0.{k}"].grad.cpu().numpy()) <= 2 * TOL_GRAD, k
+    with pytest.raises(ValueError, match="key_keep must be"):
+        eng.train_forward(h, 0.0, 0, key_keep=keep[:, :10])

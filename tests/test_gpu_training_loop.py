@@ -84,3 +84,29 @@ def test_fused_adamw_step_equals_torch_adamw():
         c = [torch.randn(4, requires_grad=True)]
         c[0].grad = torch.randn(4)
         FusedAdamW(c).step()
+
+
+def test_loop_with_bucket_reducer_single_rank(golden, tmp_path):
+    """reducer=LayerBucketReducer(model): world size 1 must reproduce the plain loop (gradients live in the buckets,
+    the reducer is notified by the native gradient sink, finish() runs before the optimizer step)."""
+    import types
+    from mst_amd.diffusion import logger
+    from mst_amd.finetune_dp import LayerBucketReducer
+    from mst_amd.train.training_loop import TrainInpaintingLoop
+    g = golden["train_loop"]
+    model, diffusion = lf.build_model(torch.device("cuda:0"))
+    logger.configure(dir=str(tmp_path))
+    args = types.SimpleNamespace(save_dir=str(tmp_path), **lf.ARGS)
+    data, style_data = lf.batches()
+    platform = types.SimpleNamespace(report_scalar=lambda **k: None, close=lambda: None)
+    red = LayerBucketReducer(model)
+    assert red.native
+    loop = TrainInpaintingLoop(args, platform, model, data, diffusion=diffusion, style_data=style_data, reducer=red)
+    losses = []
+    orig = diffusion.few_shot_style_finetune_losses
+    diffusion.few_shot_style_finetune_losses = lambda *a, **k: (lambda t: (losses.append(float(t["loss"].detach())), t)[1])(orig(*a, **k))
+    np.random.seed(SEED % (2 ** 31))
+    with lf.recorded_noise("loop"):
+        loop.run_loop()
+    assert red.launch_order == list(range(7, -1, -1))                 # fired on the last step too
+    assert np.allclose(losses, g["loss"], rtol=2e-3), (losses, g["loss"])
