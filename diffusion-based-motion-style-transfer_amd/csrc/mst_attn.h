@@ -22,8 +22,10 @@ __device__ __forceinline__ int k_off(int row, int ch) { return row * 256 + ((ch 
 // at piece p ^ (key & 3): the 4 keys x 64 B a half-wave's transposed read touches cover all 64 banks.
 __device__ __forceinline__ int v_off(int key, int d) { return key * 256 + ((((d >> 5) ^ (key & 3))) << 6) + ((d & 31) << 1); }
 
+// qsplit = 1: grid.y = NKT and the workgroup computes only query tile blockIdx.y (small batches: rows * 4 workgroups
+// would leave the chip idle; re-staging K and V seven times is cheap when only a few clips run).
 template <int NKT>   // number of 32-key tiles = ceil(S / 32), 1..7
-__global__ __launch_bounds__(512) void k_attention(const f16* __restrict__ qkv, f16* __restrict__ out, int S) {
+__global__ __launch_bounds__(512) void k_attention(const f16* __restrict__ qkv, f16* __restrict__ out, int S, int qsplit) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KEYS = NKT * 32;
     char* ks = smem;
@@ -46,9 +48,14 @@ __global__ __launch_bounds__(512) void k_attention(const f16* __restrict__ qkv, 
     }
     __syncthreads();
     if (wave >= NKT) return;        // query tiles = key tiles; no barrier below
+    int qtile = wave;
+    if (qsplit) {
+        if (wave != 0) return;
+        qtile = blockIdx.y;
+    }
 
     const int hh = lane >> 5;
-    const int q_idx = wave * 32 + (lane & 31);
+    const int q_idx = qtile * 32 + (lane & 31);
     const int q_ld = q_idx < S ? q_idx : S - 1;
     f16x8 qf[8];
     {

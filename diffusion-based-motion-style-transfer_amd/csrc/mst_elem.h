@@ -91,6 +91,57 @@ __global__ void k_cond_token(const float* __restrict__ temb, int uniform_row, in
     lo[o] = (f16)(v - (float)h);
 }
 
+// Small launches: y = LayerNorm(acc + bias + residual) for rows of 512, one wave per row; the stream (hi/lo pair) is
+// read as the residual and rewritten in place.  `acc` is the fp32 GEMM result of a launch tiled over N (k_gemm_dma with
+// 64 x 128 tiles + DEpiPlainF32) -- the fused whole-row epilogue would leave all but 4 CUs idle at one clip.
+__global__ __launch_bounds__(256) void k_ln_rows(const float* __restrict__ acc, const float* __restrict__ bias,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                 f16* __restrict__ hi, f16* __restrict__ lo, int M) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int fa = lane * 4, fb = 256 + lane * 4;
+    const size_t off = (size_t)row * MST_D;
+    f32x4 xa = join4_f16(*reinterpret_cast<const uint2*>(hi + off + fa), *reinterpret_cast<const uint2*>(lo + off + fa));
+    f32x4 xb = join4_f16(*reinterpret_cast<const uint2*>(hi + off + fb), *reinterpret_cast<const uint2*>(lo + off + fb));
+    const f32x4 ta = *reinterpret_cast<const f32x4*>(acc + off + fa), tb = *reinterpret_cast<const f32x4*>(acc + off + fb);
+    const f32x4 ba = *reinterpret_cast<const f32x4*>(bias + fa), bb = *reinterpret_cast<const f32x4*>(bias + fb);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        xa[i] = ta[i] + ba[i] + xa[i];
+        xb[i] = tb[i] + bb[i] + xb[i];
+        s += xa[i] + xb[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s * (1.0f / MST_D);
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        xa[i] -= mean;
+        xb[i] -= mean;
+        s2 += xa[i] * xa[i] + xb[i] * xb[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
+    const float rstd = 1.0f / sqrtf(s2 * (1.0f / MST_D) + 1e-5f);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + fa), gb = *reinterpret_cast<const f32x4*>(gamma + fb);
+    const f32x4 ea = *reinterpret_cast<const f32x4*>(beta + fa), eb = *reinterpret_cast<const f32x4*>(beta + fb);
+    f32x4 ya, yb;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        ya[i] = xa[i] * rstd * ga[i] + ea[i];
+        yb[i] = xb[i] * rstd * gb[i] + eb[i];
+    }
+    uint2 h, l;
+    split4_f16(ya, h, l);
+    *reinterpret_cast<uint2*>(hi + off + fa) = h;
+    *reinterpret_cast<uint2*>(lo + off + fa) = l;
+    split4_f16(yb, h, l);
+    *reinterpret_cast<uint2*>(hi + off + fb) = h;
+    *reinterpret_cast<uint2*>(lo + off + fb) = l;
+}
+
 // debug / tests: the stream as float32
 __global__ void k_join_stream(const f16* __restrict__ hi, const f16* __restrict__ lo, float* __restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)

@@ -136,6 +136,8 @@ struct mst_engine {
     TrainWS tw;
     int dbg_layer = -1, dbg_stage = -1;   // stop the trunk after (layer, stage); -1 = run everything
     int fuse_qkv_attn = 1;                // K4 + K5 as one kernel per (clip, head); MST_FUSE_QKV_ATTN=0 keeps them apart
+    int small_m = 1024;                   // launches of at most this many token rows take the small-tile path (MST_SMALL_M, 0 = never)
+    float* zacc = nullptr;                // fp32 GEMM result feeding k_ln_rows on that path
     int wgrad_stream_on = 1;              // training: wgrads on a second stream beside the dgrad chain (MST_WGRAD_STREAM=0: one stream)
     int nsplit = 3;                       // sampling loops run the batch as this many independent slices on separate streams (same-box A/B: 2: 61.2, 3: 63.0, 4: 61.1 clips/s)
     static constexpr int MAX_SLICES = 4;
@@ -255,6 +257,8 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     }
     if (const char* v = getenv("MST_FUSE_QKV_ATTN")) e->fuse_qkv_attn = atoi(v) != 0;
     if (const char* v = getenv("MST_WGRAD_STREAM")) e->wgrad_stream_on = atoi(v) != 0;
+    if (const char* v = getenv("MST_SMALL_M")) e->small_m = atoi(v);
+    CHECK(dmalloc(&e->zacc, (size_t)e->M_pad * MST_D));
     *out = e;
     return 0;
 }
@@ -276,7 +280,7 @@ extern "C" void mst_engine_destroy(mst_engine* e) {
         for (void* q : p) (void)hipFree(q);
     }
     void* p[] = {e->w_pose_in, e->b_pose_in, e->w_pose_out, e->b_pose_out, e->w_t0, e->b_t0, e->w_t2, e->b_t2,
-                 e->w_text, e->b_text, e->pe, e->hl, e->hx, e->qkv, e->att, e->hid, e->xt, e->temb_hid, e->temb, e->textproj};
+                 e->w_text, e->b_text, e->pe, e->hl, e->hx, e->qkv, e->att, e->hid, e->xt, e->temb_hid, e->temb, e->textproj, e->zacc};
     for (void* q : p) (void)hipFree(q);
     for (int i = 0; i < mst_engine::MAX_SLICES - 1; i++) {
         if (e->aux_stream[i]) (void)hipStreamDestroy(e->aux_stream[i]);
@@ -466,8 +470,15 @@ static int launch_wide(int M, int ny, const SRC& xs, const f16* W, int ldw, int 
     return launch_gemm_dma<WIDE_BT, 256, WIDE_BT / 64, 2, WIDE_NS, 1>(wide_grid(M, ny), xs, W, ldw, K, epi, st, WIDE_XCD ? ny : 0);
 }
 
+// Few token rows (a clip or two): 64 x 128 tiles over a 2-D grid so that tens of workgroups share the weight matrix
+// instead of 4-12 of them each streaming all of it; LayerNorm then runs as its own row-wise kernel (k_ln_rows).
+template <class SRC, class EPI>
+static int launch_small(int M, int N, const SRC& xs, const f16* W, int ldw, int K, const EPI& epi, hipStream_t st) {
+    return launch_gemm_dma<64, 128, 1, 1, 3, 1, 64>(dim3((M + 63) / 64, N / 128), xs, W, ldw, K, epi, st, 0);
+}
+
 template <int NKT>
-static int launch_attn_n(const f16* qkv, f16* out, int S, int rows, hipStream_t st) {
+static int launch_attn_n(const f16* qkv, f16* out, int S, int rows, hipStream_t st, int qsplit) {
     auto kern = k_attention<NKT>;
     static bool attr_set = false;
     const int smem = NKT * 32 * 256 * 2;
@@ -475,7 +486,7 @@ static int launch_attn_n(const f16* qkv, f16* out, int S, int rows, hipStream_t 
         HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(rows * MST_H), dim3(512), smem, st, qkv, out, S);
+    hipLaunchKernelGGL(kern, dim3(rows * MST_H, qsplit ? NKT : 1), dim3(512), smem, st, qkv, out, S, qsplit);
     HIPCHECK(hipGetLastError());
     return 0;
 }
@@ -508,15 +519,15 @@ static int launch_qkv_attn(const f16* hx, const f16* w_in, const float* b_in, f1
     return fail("attention: S=%d unsupported", S);
 }
 
-static int launch_attn(const f16* qkv, f16* out, int S, int rows, hipStream_t st) {
+static int launch_attn(const f16* qkv, f16* out, int S, int rows, hipStream_t st, int qsplit = 0) {
     switch ((S + 31) / 32) {
-        case 1: return launch_attn_n<1>(qkv, out, S, rows, st);
-        case 2: return launch_attn_n<2>(qkv, out, S, rows, st);
-        case 3: return launch_attn_n<3>(qkv, out, S, rows, st);
-        case 4: return launch_attn_n<4>(qkv, out, S, rows, st);
-        case 5: return launch_attn_n<5>(qkv, out, S, rows, st);
-        case 6: return launch_attn_n<6>(qkv, out, S, rows, st);
-        case 7: return launch_attn_n<7>(qkv, out, S, rows, st);
+        case 1: return launch_attn_n<1>(qkv, out, S, rows, st, qsplit);
+        case 2: return launch_attn_n<2>(qkv, out, S, rows, st, qsplit);
+        case 3: return launch_attn_n<3>(qkv, out, S, rows, st, qsplit);
+        case 4: return launch_attn_n<4>(qkv, out, S, rows, st, qsplit);
+        case 5: return launch_attn_n<5>(qkv, out, S, rows, st, qsplit);
+        case 6: return launch_attn_n<6>(qkv, out, S, rows, st, qsplit);
+        case 7: return launch_attn_n<7>(qkv, out, S, rows, st, qsplit);
     }
     return fail("attention: S=%d unsupported", S);
 }
@@ -554,12 +565,12 @@ extern "C" int mst_set_text(mst_engine* e, const float* text_emb, const float* k
 // A slice of the workspace: clips [r0, r0 + n) of the batch get their own rows of every buffer, so slices can
 // run concurrently on different streams (tiles may over-READ into a neighbour's rows; they never write them).
 struct WS {
-    f16 *hl, *hx, *qkv, *att, *hid, *xt; float* textproj;
+    f16 *hl, *hx, *qkv, *att, *hid, *xt; float* textproj; float* zacc;
 };
 static WS ws_slice(const mst_engine* e, int r0, int T) {
     const size_t row = (size_t)r0 * (T + 1);
     return WS{e->hl + row * MST_D, e->hx + row * MST_D, e->qkv + row * 3 * MST_D, e->att + row * MST_D, e->hid + row * MST_FF,
-              e->xt + (size_t)r0 * T * e->kin_pad, e->textproj + (size_t)r0 * MST_D};
+              e->xt + (size_t)r0 * T * e->kin_pad, e->textproj + (size_t)r0 * MST_D, e->zacc + row * MST_D};
 }
 
 // K3 .. K8: token stream through the encoder stack.  rows = clips through the transformer.
@@ -585,7 +596,44 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
     }
     if (e->dbg_stage == 0) return 0;
 #define DBG_STOP(stage) if (e->dbg_layer == l && e->dbg_stage == stage) return 0;
-    for (int l = 0; l < e->cfg.num_layers; l++) {
+    const bool small = e->small_m > 0 && M <= e->small_m;
+    for (int l = 0; small && l < e->cfg.num_layers; l++) {
+        const LayerW& w = e->L[l];
+        {
+            ProfScope ps(e, FAM_QKV, st);
+            DEpiBiasF16<false> epi{w.b_in, ws.qkv, 3 * MST_D, M};
+            CHECK(launch_small(M, 3 * MST_D, RowsDirect{ws.hx, MST_D}, w.w_in, MST_D, MST_D, epi, st));
+        }
+        DBG_STOP(1)
+        {
+            ProfScope ps(e, FAM_ATTN, st);
+            CHECK(launch_attn(ws.qkv, ws.att, S, rows, st, 1));
+        }
+        DBG_STOP(2)
+        {
+            ProfScope ps(e, FAM_OUTPROJ_LN, st);
+            DEpiPlainF32 epi{ws.zacc, MST_D, M};
+            CHECK(launch_small(M, MST_D, RowsDirect{ws.att, MST_D}, w.w_out, MST_D, MST_D, epi, st));
+            hipLaunchKernelGGL(k_ln_rows, dim3((M + 3) / 4), dim3(256), 0, st, ws.zacc, w.b_out, w.g1, w.be1, ws.hx, ws.hl, M);
+            HIPCHECK(hipGetLastError());
+        }
+        DBG_STOP(3)
+        {
+            ProfScope ps(e, FAM_FFN1, st);
+            DEpiBiasF16<true> epi{w.b1, ws.hid, MST_FF, M};
+            CHECK(launch_small(M, MST_FF, RowsDirect{ws.hx, MST_D}, w.w1, MST_D, MST_D, epi, st));
+        }
+        DBG_STOP(4)
+        {
+            ProfScope ps(e, FAM_FFN2_LN, st);
+            DEpiPlainF32 epi{ws.zacc, MST_D, M};
+            CHECK(launch_small(M, MST_D, RowsDirect{ws.hid, MST_FF}, w.w2, MST_FF, MST_FF, epi, st));
+            hipLaunchKernelGGL(k_ln_rows, dim3((M + 3) / 4), dim3(256), 0, st, ws.zacc, w.b2, w.g2, w.be2, ws.hx, ws.hl, M);
+            HIPCHECK(hipGetLastError());
+        }
+        DBG_STOP(5)
+    }
+    for (int l = 0; !small && l < e->cfg.num_layers; l++) {
         const LayerW& w = e->L[l];
         if (e->fuse_qkv_attn && !(e->dbg_layer == l && e->dbg_stage == 1)) {
             ProfScope ps(e, FAM_QKV_ATTN, st);

@@ -220,14 +220,15 @@ struct DEpiBiasF16 {
     template <int BT, int BF> static constexpr int smem_bytes() { return pass_rows<BT, BF>() * (BF * 2 + 16); }
     template <int BT, int BF, int MT, int NT>
     __device__ __forceinline__ void run(f32x16 (&acc)[1][MT][NT], int tok0, int f0, char* smem) const {
-        static_assert(BF == 256 || BF == 512, "copy-out assumes 512-byte or 1-KiB tile rows");
+        static_assert(BF == 128 || BF == 256 || BF == 512, "copy-out assumes 256-byte, 512-byte or 1-KiB tile rows");
         constexpr int LD = BF * 2 + 16;                       // bytes per tile row (+16: spreads banks, keeps 16-B alignment)
         constexpr int PR = pass_rows<BT, BF>();
         constexpr int PASSES = BT / PR;
-        constexpr int RPA = 1024 / (BF * 2);                  // tile rows covered by one 1-KiB wave access (2 or 1)
+        constexpr int LPR = BF / 8;                           // lanes per tile row (16 B each)
+        constexpr int RPA = 64 / LPR;                         // tile rows covered by one 1-KiB wave access (4, 2 or 1)
         DLane<BT, BF, MT, NT> lc;
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int sub = RPA == 2 ? lane >> 5 : 0, col = (RPA == 2 ? (lane & 31) : lane) * 16;
+        const int sub = lane / LPR, col = (lane % LPR) * 16;
 #pragma unroll
         for (int pass = 0; pass < PASSES; pass++) {
 #pragma unroll
@@ -257,6 +258,47 @@ struct DEpiBiasF16 {
                 int tok = tok0 + pass * PR + row;
                 uint4 v = *reinterpret_cast<const uint4*>(smem + row * LD + col);
                 if (tok < M) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(out + (size_t)tok * ldo + f0) + col) = v;
+            }
+            if (pass + 1 < PASSES) __syncthreads();
+        }
+    }
+};
+
+// fp32 tile out (no bias): small launches whose LayerNorm runs as a separate row-wise kernel (k_ln_rows)
+struct DEpiPlainF32 {
+    float* out; int ldo; int M;
+    __device__ __forceinline__ int rows() const { return M; }
+    template <int BT, int BF> static constexpr int smem_bytes() { return 32 * (BF * 4 + 16); }
+    template <int BT, int BF, int MT, int NT>
+    __device__ __forceinline__ void run(f32x16 (&acc)[1][MT][NT], int tok0, int f0, char* smem) const {
+        static_assert(BF == 128 || BF == 256, "512-byte or 1-KiB fp32 tile rows");
+        constexpr int LD = BF * 4 + 16, PR = 32, PASSES = BT / PR;
+        constexpr int LPR = BF / 4;                           // lanes per row (16 B = 4 floats each)
+        constexpr int RPA = 64 / LPR;
+        DLane<BT, BF, MT, NT> lc;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int sub = lane / LPR, col = (lane % LPR) * 16;
+#pragma unroll
+        for (int pass = 0; pass < PASSES; pass++) {
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                const int tl = lc.tok(m);
+                if (tl / PR != pass) continue;
+                char* trow = smem + (tl - pass * PR) * LD;
+#pragma unroll
+                for (int n = 0; n < NT; n++)
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        f32x4 v = {acc[0][m][n][4 * g], acc[0][m][n][4 * g + 1], acc[0][m][n][4 * g + 2], acc[0][m][n][4 * g + 3]};
+                        *reinterpret_cast<f32x4*>(trow + lc.feat(n, g) * 4) = v;
+                    }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < PR / (8 * RPA); p++) {
+                const int row = p * 8 * RPA + wave * RPA + sub, tok = tok0 + pass * PR + row;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * LD + col);
+                if (tok < M) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(out + (size_t)tok * ldo + f0) + col) = v;
             }
             if (pass + 1 < PASSES) __syncthreads();
         }

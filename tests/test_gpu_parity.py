@@ -29,9 +29,18 @@ def _dev():
 _ENGINES = {}
 
 
+@pytest.fixture(autouse=True, params=["1024", "0"], ids=["small-tiles", "large-tiles"])
+def tile_path(request, monkeypatch):
+    """Every test of this module runs twice: launches of <= 1024 token rows (all the golden comparisons, at 2 clips) take
+    the small-tile path by default; MST_SMALL_M=0 sends the same inputs through the large-batch kernels."""
+    monkeypatch.setenv("MST_SMALL_M", request.param)
+    return request.param
+
+
 def engine_for(tag, prior=False, max_rows=4):
+    import os
     from mst_amd.engine import DenoiserEngine
-    key = (tag, prior, max_rows)
+    key = (tag, prior, max_rows, os.environ.get("MST_SMALL_M"))
     if key not in _ENGINES:
         F, T = SHAPES[tag]
         eng = DenoiserEngine(F, T, max_rows, device=_dev())
@@ -301,7 +310,7 @@ def test_loop_tail_vs_golden_hml(golden):
 
 
 # ------------------------------------------------------------------------------ properties at the bench size
-def test_full_size_properties():
+def test_full_size_properties(tile_path):
     """BASELINE.json configs[1] size (batch 64, 263 x 196): size-independent properties -- clips are
     independent (a batch-64 run equals the same clips run in batches of 2), masked rows come out
     exactly equal to the content clip, the Philox noise path is reproducible and has unit moments."""
@@ -330,4 +339,6 @@ def test_full_size_properties():
     full = eng.forward(x0, t)
     eng.set_text(txt[10:12])
     part = eng.forward(x0[10:12], t[10:12])
-    assert rel_l2(part.cpu().numpy(), full[10:12].cpu().numpy()) < 1e-6
+    # same kernels (large-tile path forced): identical up to fp32 reduction noise; with the default small-tile path the two
+    # clips run through differently tiled kernels -- two f16-operand evaluations of the same function
+    assert rel_l2(part.cpu().numpy(), full[10:12].cpu().numpy()) < (1e-6 if tile_path == "0" else TOL)
