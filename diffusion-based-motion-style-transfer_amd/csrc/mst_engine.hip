@@ -136,7 +136,8 @@ struct mst_engine {
     TrainWS tw;
     int dbg_layer = -1, dbg_stage = -1;   // stop the trunk after (layer, stage); -1 = run everything
     int fuse_qkv_attn = 1;                // K4 + K5 as one kernel per (clip, head); MST_FUSE_QKV_ATTN=0 keeps them apart
-    int small_m = 1024;                   // launches of at most this many token rows take the small-tile path (MST_SMALL_M, 0 = never)
+    int small_m = 2048;                   // launches of at most this many token rows take the small-tile path (MST_SMALL_M, 0 = never);
+                                          // tools/small_m_sweep.sh: 8 clips (1576 rows) 722 -> 417 us/step, 11-clip slices (2167 rows) 766 vs 796
     float* zacc = nullptr;                // fp32 GEMM result feeding k_ln_rows on that path
     int wgrad_stream_on = 1;              // training: wgrads on a second stream beside the dgrad chain (MST_WGRAD_STREAM=0: one stream)
     int nsplit = 3;                       // sampling loops run the batch as this many independent slices on separate streams (same-box A/B: 2: 61.2, 3: 63.0, 4: 61.1 clips/s)
@@ -910,7 +911,7 @@ extern "C" int64_t mst_train_tape_bytes(const mst_engine* e, int32_t rows, int32
 }
 
 template <int NKT>
-static int launch_attn_train_n(const f16* qkv, f16* out, int S, int rows, Drop d, const unsigned char* keep, hipStream_t st) {
+static int launch_attn_train_n(const f16* qkv, f16* out, int S, int rows, Drop d, const unsigned char* keep, int qsplit, hipStream_t st) {
     auto kern = k_attention_train<NKT>;
     static bool attr_set = false;
     const int smem = NKT * 32 * 256 * 2 + NKT * 32 * 4;
@@ -918,7 +919,7 @@ static int launch_attn_train_n(const f16* qkv, f16* out, int S, int rows, Drop d
         HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(rows * MST_H), dim3(512), smem, st, qkv, out, S, d, keep);
+    hipLaunchKernelGGL(kern, dim3(rows * MST_H, qsplit ? NKT : 1), dim3(512), smem, st, qkv, out, S, d, keep, qsplit);
     HIPCHECK(hipGetLastError());
     return 0;
 }
@@ -947,8 +948,8 @@ static int launch_attn_bwd_n(const f16* qkv, const f16* att, const f16* datt, f1
         case 7: return fn<7>(__VA_ARGS__);                        \
     }                                                             \
     return fail("attention: S=%d unsupported", S);
-static int launch_attn_train(const f16* qkv, f16* out, int S, int rows, Drop d, const unsigned char* keep, hipStream_t st) {
-    NKT_SWITCH(launch_attn_train_n, S, qkv, out, S, rows, d, keep, st)
+static int launch_attn_train(const f16* qkv, f16* out, int S, int rows, Drop d, const unsigned char* keep, int qsplit, hipStream_t st) {
+    NKT_SWITCH(launch_attn_train_n, S, qkv, out, S, rows, d, keep, qsplit, st)
 }
 static int launch_attn_bwd(const f16* qkv, const f16* att, const f16* datt, f16* dqkv, int S, int rows, Drop d,
                            const unsigned char* keep, hipStream_t st) {
@@ -970,14 +971,42 @@ extern "C" int mst_train_forward(mst_engine* e, const float* h_in, int32_t rows,
     hipLaunchKernelGGL(k_split_stream, dim3(1024), dim3(256), 0, st, h_in, n, t.sh[0], t.sl[0]);
     HIPCHECK(hipGetLastError());
     e->prof_now = 0;
-    for (int l = 0; l < nl; l++) {
+    const bool small = e->small_m > 0 && M <= e->small_m;
+    for (int l = 0; small && l < nl; l++) {              // few token rows: 64 x 128 tiles, row-wise LayerNorm, query-split attention
+        const LayerW& w = e->L[l];
+        const TapeL& a = t.L[l];
+        {
+            DEpiBiasF16<false> epi{w.b_in, a.qkv, 3 * MST_D, M};
+            CHECK(launch_small(M, 3 * MST_D, RowsDirect{t.sh[l], MST_D}, w.w_in, MST_D, MST_D, epi, st));
+        }
+        CHECK(launch_attn_train(a.qkv, a.att, S, rows, make_drop(seed, l, 0, p_drop), key_keep, 1, st));
+        {
+            DEpiPlainF32 epi{e->zacc, MST_D, M};
+            CHECK(launch_small(M, MST_D, RowsDirect{a.att, MST_D}, w.w_out, MST_D, MST_D, epi, st));
+            hipLaunchKernelGGL(k_ln_rows_train, dim3((M + 3) / 4), dim3(256), 0, st, e->zacc, w.b_out, w.g1, w.be1, t.sh[l], t.sl[l],
+                               a.z1h, a.z1l, a.x1h, a.x1l, M, make_drop(seed, l, 1, p_drop));
+            HIPCHECK(hipGetLastError());
+        }
+        {
+            DEpiRowOp<OpFfn1Train> epi{w.b1, M, OpFfn1Train{a.pre, a.hid, MST_FF, make_drop(seed, l, 2, p_drop)}};
+            CHECK(launch_small(M, MST_FF, RowsDirect{a.x1h, MST_D}, w.w1, MST_D, MST_D, epi, st));
+        }
+        {
+            DEpiPlainF32 epi{e->zacc, MST_D, M};
+            CHECK(launch_small(M, MST_D, RowsDirect{a.hid, MST_FF}, w.w2, MST_FF, MST_FF, epi, st));
+            hipLaunchKernelGGL(k_ln_rows_train, dim3((M + 3) / 4), dim3(256), 0, st, e->zacc, w.b2, w.g2, w.be2, a.x1h, a.x1l,
+                               a.z2h, a.z2l, t.sh[l + 1], t.sl[l + 1], M, make_drop(seed, l, 3, p_drop));
+            HIPCHECK(hipGetLastError());
+        }
+    }
+    for (int l = 0; !small && l < nl; l++) {
         const LayerW& w = e->L[l];
         const TapeL& a = t.L[l];
         {
             DEpiBiasF16<false> epi{w.b_in, a.qkv, 3 * MST_D, M};
             CHECK((launch_wide(M, 3 * MST_D / 256, RowsDirect{t.sh[l], MST_D}, w.w_in, MST_D, MST_D, epi, st)));
         }
-        CHECK(launch_attn_train(a.qkv, a.att, S, rows, make_drop(seed, l, 0, p_drop), key_keep, st));
+        CHECK(launch_attn_train(a.qkv, a.att, S, rows, make_drop(seed, l, 0, p_drop), key_keep, 0, st));
         {
             DEpiResidLNTrain epi{w.b_out, w.g1, w.be1, t.sh[l], t.sl[l], a.z1h, a.z1l, a.x1h, a.x1l, M, make_drop(seed, l, 1, p_drop)};
             CHECK((launch_gemm_dma<64, 512, 2, 2, LN_NS, 1, LN_BK>(dim3((M + 63) / 64, 1), RowsDirect{a.att, MST_D}, w.w_out, MST_D, MST_D, epi, st)));
@@ -1084,6 +1113,7 @@ extern "C" int mst_train_backward(mst_engine* e, const void* tape, const float* 
     float* gA = w_.g0;      // dz buffers
     float* gB = w_.g1;      // gradient wrt the current layer output
     const int ln_blocks = (M + 3) / 4 < 512 ? (M + 3) / 4 : 512;
+    const bool small = e->small_m > 0 && M <= e->small_m;
     e->prof_now = 0;
     // The dgrad chain (LayerNorm / GELU / attention backward and the four dgrad GEMMs) is serial; the four wgrads of a
     // layer only consume its by-products, so they run on a second stream beside it.  Their f16 operands are
@@ -1117,14 +1147,16 @@ extern "C" int mst_train_backward(mst_engine* e, const void* tape, const float* 
         // d pre = (dbr2 W2) * mask * gelu'(pre)
         {
             DEpiRowOp<OpGeluBwd> epi{nullptr, M, OpGeluBwd{a.pre, dpre, MST_FF, make_drop(seed, l, 2, p_drop)}};
-            CHECK((launch_wide(M, MST_FF / 256, RowsDirect{dbr2, MST_D}, w.w2T, MST_D, MST_D, epi, st)));
+            CHECK(small ? launch_small(M, MST_FF, RowsDirect{dbr2, MST_D}, w.w2T, MST_D, MST_D, epi, st)
+                        : launch_wide(M, MST_FF / 256, RowsDirect{dbr2, MST_D}, w.w2T, MST_D, MST_D, epi, st));
         }
         TO_SIDE()
         if (wg) CHECK(wgrad(e, dpre, MST_FF, a.x1h, MST_D, M, G[4], G[5], sw));                    // dW1 += dpre^T x1, db1
         // g(x1) = dpre W1 + dz2  -> gB
         {
             DEpiF32 epi{gA, gB, MST_D, M};
-            CHECK((launch_wide(M, MST_D / 256, RowsDirect{dpre, MST_FF}, w.w1T, MST_FF, MST_FF, epi, st)));
+            CHECK(small ? launch_small(M, MST_D, RowsDirect{dpre, MST_FF}, w.w1T, MST_FF, MST_FF, epi, st)
+                        : launch_wide(M, MST_D / 256, RowsDirect{dpre, MST_FF}, w.w1T, MST_FF, MST_FF, epi, st));
         }
         // LayerNorm1 backward: gB -> dz1 (gA), dbr1 = d(out-proj output); dgamma1, dbeta1, db_out
         hipLaunchKernelGGL(k_ln_bwd, dim3(ln_blocks), dim3(256), 0, st, gB, a.z1h, a.z1l, w.g1, M, make_drop(seed, l, 1, p_drop), w_.gscale,
@@ -1135,7 +1167,8 @@ extern "C" int mst_train_backward(mst_engine* e, const void* tape, const float* 
         // d att = dbr1 W_out
         {
             DEpiBiasF16<false> epi{w_.zeros, w_.datt, MST_D, M};
-            CHECK((launch_wide(M, MST_D / 256, RowsDirect{dbr1, MST_D}, w.w_outT, MST_D, MST_D, epi, st)));
+            CHECK(small ? launch_small(M, MST_D, RowsDirect{dbr1, MST_D}, w.w_outT, MST_D, MST_D, epi, st)
+                        : launch_wide(M, MST_D / 256, RowsDirect{dbr1, MST_D}, w.w_outT, MST_D, MST_D, epi, st));
         }
         // attention backward -> d qkv
         CHECK(launch_attn_bwd(a.qkv, a.att, w_.datt, dqkv, S, rows, make_drop(seed, l, 0, p_drop), key_keep, st));
@@ -1148,7 +1181,8 @@ extern "C" int mst_train_backward(mst_engine* e, const void* tape, const float* 
         // g(x_in) = dqkv W_in + dz1 -> gB
         {
             DEpiF32 epi{gA, gB, MST_D, M};
-            CHECK((launch_wide(M, MST_D / 256, RowsDirect{dqkv, 3 * MST_D}, w.w_inT, 3 * MST_D, 3 * MST_D, epi, st)));
+            CHECK(small ? launch_small(M, MST_D, RowsDirect{dqkv, 3 * MST_D}, w.w_inT, 3 * MST_D, 3 * MST_D, epi, st)
+                        : launch_wide(M, MST_D / 256, RowsDirect{dqkv, 3 * MST_D}, w.w_inT, 3 * MST_D, 3 * MST_D, epi, st));
         }
     }
 #undef TO_SIDE

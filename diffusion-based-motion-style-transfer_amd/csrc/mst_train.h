@@ -43,14 +43,14 @@ struct DEpiRowOp {
     template <int BT, int BF> static constexpr int smem_bytes() { return pass_rows<BT, BF>() * (BF * 2 + 16); }
     template <int BT, int BF, int MT, int NT>
     __device__ __forceinline__ void run(f32x16 (&acc)[1][MT][NT], int tok0, int f0, char* smem) const {
-        static_assert(BF == 256 || BF == 512, "copy-out assumes 512-byte or 1-KiB tile rows");
+        static_assert(BF == 128 || BF == 256 || BF == 512, "copy-out assumes 256-byte, 512-byte or 1-KiB tile rows");
         constexpr int LD = BF * 2 + 16;
         constexpr int PR = pass_rows<BT, BF>();
         constexpr int PASSES = BT / PR;
-        constexpr int RPA = 1024 / (BF * 2);
+        constexpr int LPR = BF / 8, RPA = 64 / LPR;           // lanes per tile row, rows per 1-KiB wave access
         DLane<BT, BF, MT, NT> lc;
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int sub = RPA == 2 ? lane >> 5 : 0, col = (RPA == 2 ? (lane & 31) : lane) * 16;
+        const int sub = lane / LPR, col = (lane % LPR) * 16;
 #pragma unroll
         for (int pass = 0; pass < PASSES; pass++) {
 #pragma unroll
@@ -122,10 +122,12 @@ struct DEpiF32 {
     template <int BT, int BF> static constexpr int smem_bytes() { return pass_rows<BT>() * (BF * 4 + 16); }
     template <int BT, int BF, int MT, int NT>
     __device__ __forceinline__ void run(f32x16 (&acc)[1][MT][NT], int tok0, int f0, char* smem) const {
-        static_assert(BF == 256, "one wave access = one 1-KiB row");
+        static_assert(BF == 256 || BF == 128, "1-KiB or 512-byte fp32 tile rows");
         constexpr int LD = BF * 4 + 16, PR = pass_rows<BT>(), PASSES = BT / PR;
+        constexpr int LPR = BF / 4, RPA = 64 / LPR;           // lanes per row (16 B each), rows per wave access
         DLane<BT, BF, MT, NT> lc;
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int sub = lane / LPR, lcol = lane % LPR;
 #pragma unroll
         for (int pass = 0; pass < PASSES; pass++) {
 #pragma unroll
@@ -143,11 +145,11 @@ struct DEpiF32 {
             }
             __syncthreads();
 #pragma unroll
-            for (int p = 0; p < PR / 8; p++) {
-                const int row = p * 8 + wave, tok = tok0 + pass * PR + row;
+            for (int p = 0; p < PR / (8 * RPA); p++) {
+                const int row = p * 8 * RPA + wave * RPA + sub, tok = tok0 + pass * PR + row;
                 if (tok >= M) continue;
-                f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * LD + lane * 16);
-                const size_t o = (size_t)tok * ldo + f0 + lane * 4;
+                f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * LD + lcol * 16);
+                const size_t o = (size_t)tok * ldo + f0 + lcol * 4;
                 if (gscale) {
                     const float us = gscale[1];
 #pragma unroll
@@ -290,6 +292,64 @@ struct DEpiResidLNTrain {
 // ------------------------------------------------------------------------------------------------------------
 // Elementwise / row-wise helpers of the training path
 // ------------------------------------------------------------------------------------------------------------
+// Small launches in training: z = resid + dropout(acc + bias), y = LayerNorm(z); residual from one tape slot, z and y to
+// two others (the row-wise counterpart of DEpiResidLNTrain; `acc` comes from a 64 x 128-tiled GEMM + DEpiPlainF32).
+__global__ __launch_bounds__(256) void k_ln_rows_train(const float* __restrict__ acc, const float* __restrict__ bias,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const f16* __restrict__ rin_hi, const f16* __restrict__ rin_lo,
+                                                       f16* __restrict__ z_hi, f16* __restrict__ z_lo, f16* __restrict__ y_hi,
+                                                       f16* __restrict__ y_lo, int M, Drop d) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int fa = lane * 4, fb = 256 + lane * 4;
+    const size_t off = (size_t)row * MST_D;
+    f32x4 xa = join4_f16(*reinterpret_cast<const uint2*>(rin_hi + off + fa), *reinterpret_cast<const uint2*>(rin_lo + off + fa));
+    f32x4 xb = join4_f16(*reinterpret_cast<const uint2*>(rin_hi + off + fb), *reinterpret_cast<const uint2*>(rin_lo + off + fb));
+    const f32x4 ta = *reinterpret_cast<const f32x4*>(acc + off + fa), tb = *reinterpret_cast<const f32x4*>(acc + off + fb);
+    const f32x4 ba = *reinterpret_cast<const f32x4*>(bias + fa), bb = *reinterpret_cast<const f32x4*>(bias + fb);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        xa[i] += (ta[i] + ba[i]) * drop_mul(d, (uint32_t)(off + fa + i));
+        xb[i] += (tb[i] + bb[i]) * drop_mul(d, (uint32_t)(off + fb + i));
+        s += xa[i] + xb[i];
+    }
+    uint2 h, l;
+    split4_f16(xa, h, l);
+    *reinterpret_cast<uint2*>(z_hi + off + fa) = h;
+    *reinterpret_cast<uint2*>(z_lo + off + fa) = l;
+    split4_f16(xb, h, l);
+    *reinterpret_cast<uint2*>(z_hi + off + fb) = h;
+    *reinterpret_cast<uint2*>(z_lo + off + fb) = l;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s * (1.0f / MST_D);
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        xa[i] -= mean;
+        xb[i] -= mean;
+        s2 += xa[i] * xa[i] + xb[i] * xb[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
+    const float rstd = 1.0f / sqrtf(s2 * (1.0f / MST_D) + 1e-5f);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + fa), gb = *reinterpret_cast<const f32x4*>(gamma + fb);
+    const f32x4 ea = *reinterpret_cast<const f32x4*>(beta + fa), eb = *reinterpret_cast<const f32x4*>(beta + fb);
+    f32x4 ya, yb;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        ya[i] = xa[i] * rstd * ga[i] + ea[i];
+        yb[i] = xb[i] * rstd * gb[i] + eb[i];
+    }
+    split4_f16(ya, h, l);
+    *reinterpret_cast<uint2*>(y_hi + off + fa) = h;
+    *reinterpret_cast<uint2*>(y_lo + off + fa) = l;
+    split4_f16(yb, h, l);
+    *reinterpret_cast<uint2*>(y_hi + off + fb) = h;
+    *reinterpret_cast<uint2*>(y_lo + off + fb) = l;
+}
+
 // fp32 rows -> hi/lo pair
 __global__ void k_split_stream(const float* __restrict__ in, size_t n, f16* __restrict__ hi, f16* __restrict__ lo) {
     for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
@@ -483,7 +543,7 @@ __device__ __forceinline__ void stage_key_bias(float* kbias, const unsigned char
 
 template <int NKT>
 __global__ __launch_bounds__(512) void k_attention_train(const f16* __restrict__ qkv, f16* __restrict__ out, int S, Drop d,
-                                                         const unsigned char* __restrict__ keep) {
+                                                         const unsigned char* __restrict__ keep, int qsplit) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KEYS = NKT * 32;
     char* ks = smem;
@@ -506,8 +566,13 @@ __global__ __launch_bounds__(512) void k_attention_train(const f16* __restrict__
     }
     __syncthreads();
     if (wave >= NKT) return;
+    int qtile = wave;
+    if (qsplit) {                      // small batches: grid.y = NKT, one query tile per workgroup (see k_attention)
+        if (wave != 0) return;
+        qtile = blockIdx.y;
+    }
     const int hh = lane >> 5;
-    const int q_idx = wave * 32 + (lane & 31);
+    const int q_idx = qtile * 32 + (lane & 31);
     const int q_ld = q_idx < S ? q_idx : S - 1;
     f16x8 qf[8];
     {

@@ -37,16 +37,26 @@ def _dev():
 _ENGINES = {}
 
 
+@pytest.fixture(autouse=True, params=["2048", "0"], ids=["small-tiles", "large-tiles"])
+def tile_path(request, monkeypatch):
+    """Every test here runs twice: these shapes (a few clips) take the small-launch path by default; MST_SMALL_M=0 (read when
+    an engine is created) sends them through the kernels the batch-64 fine-tune pass uses."""
+    monkeypatch.setenv("MST_SMALL_M", request.param)
+    return request.param
+
+
 def engine_for(tag, max_rows=4):
+    import os
     from mst_amd.engine import DenoiserEngine
-    if tag not in _ENGINES:
+    tag_key = (tag, os.environ.get("MST_SMALL_M"))
+    if tag_key not in _ENGINES:
         Fe, T = SHAPES[tag]
         eng = DenoiserEngine(Fe, T, max_rows, device=_dev())
         w = syn.denoiser_state(SEED, Fe, layer_prefix="seqTransEncoder.layers.")
         eng.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, layer_prefix="seqTransEncoder.layers.",
                             pe=torch.from_numpy(syn.positional_table(5000, 512)))
-        _ENGINES[tag] = (eng, w)
-    return _ENGINES[tag]
+        _ENGINES[tag_key] = (eng, w)
+    return _ENGINES[tag_key]
 
 
 def layer_params(w, requires_grad):

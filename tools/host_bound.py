@@ -8,7 +8,8 @@ from mst_amd.engine import DenoiserEngine, Schedule, SAMPLER_DDPM
 from mst_amd.diffusion.gaussian_diffusion import schedule_tables
 dev = torch.device("cuda:0")
 F, T = 263, 196
-for B in (64, 16, 1):
+import os
+for B in [int(b) for b in os.environ.get("HB_BATCHES", "64,16,1").split(",")]:
     eng = DenoiserEngine(F, T, B, device=dev)
     w = syn.denoiser_state(1, F)
     eng.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, pe=torch.from_numpy(syn.positional_table(5000, 512)))
