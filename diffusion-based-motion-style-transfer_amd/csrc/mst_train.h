@@ -656,12 +656,29 @@ __global__ __launch_bounds__(512) void k_attention_train(const f16* __restrict__
     }
 }
 
-// image helpers: [row][128] f16 in the transposed-read layout (v_off); both access patterns work on it
+// Images of the backward kernel are read BOTH ways (row-major ds_read_b128 fragments and transposed ds_read_b64_tr_b16
+// fragments).  Layout a_off: 256-B rows; the four 64-B pieces rotated by row & 3 (what the transposed read needs: its 4
+// rows x 32 B then cover 32 distinct banks) AND the four 16-B chunks inside a piece rotated by (row >> 2) & 3, so the 16
+// rows one ds_read_b128 phase touches land on 16 different chunk slots = all 64 banks.  (With v_off alone the row-major
+// reads were 8-way conflicted: a row stride of 256 B maps every row to the same banks.)
+__device__ __forceinline__ int a_off(int row, int d) {
+    return row * 256 + (((d >> 5) ^ (row & 3)) << 6) + (((((d & 31) >> 3) ^ ((row >> 2) & 3))) << 4) + ((d & 7) << 1);
+}
 __device__ __forceinline__ f16x8 img_row_frag(const char* img, int row, int s, int hh) {       // d = 16 s + 8 hh .. + 8
-    return *reinterpret_cast<const f16x8*>(img + v_off(row, 16 * s + 8 * hh));
+    return *reinterpret_cast<const f16x8*>(img + a_off(row, 16 * s + 8 * hh));
 }
 // A-operand fragment of img^T for MFMA k-step (tile t, half s2) and d tile dt: lane (d = dt*32 + l31) receives
 // rows t*32 + 16 s2 + 4 hh + {0..3} and + 8 + {0..3} -- the permuted k order the accumulator-as-operand trick needs.
+__device__ __forceinline__ f16x8 img_tr_frag_a(const char* img, int t, int s2, int dt, int lane) {
+    const int hh = lane >> 5, i16 = lane & 15, g = lane >> 4;
+    const int row = t * 32 + 16 * s2 + 4 * hh + (i16 >> 2);
+    const int dd = dt * 32 + 16 * (g & 1) + 4 * (i16 & 3);
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(img + a_off(row, dd)));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(img + a_off(row + 8, dd)));
+    const f16x4 lo_h = __builtin_bit_cast(f16x4, lo), hi_h = __builtin_bit_cast(f16x4, hi);
+    return __builtin_shufflevector(lo_h, hi_h, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// same for an image in the plain v_off layout (k_wgrad_tr: images written by the DMA ring, transposed reads only)
 __device__ __forceinline__ f16x8 img_tr_frag(const char* img, int t, int s2, int dt, int lane) {
     const int hh = lane >> 5, i16 = lane & 15, g = lane >> 4;
     const int row = t * 32 + 16 * s2 + 4 * hh + (i16 >> 2);
@@ -676,7 +693,7 @@ __device__ __forceinline__ void stage_image(char* img, const f16* src, size_t ro
         const int row = q >> 4, ch = q & 15;
         uint4 v = {0, 0, 0, 0};
         if (row < S) v = *reinterpret_cast<const uint4*>(src + (size_t)row * row_stride + ch * 8);
-        *reinterpret_cast<uint4*>(img + v_off(row, ch * 8)) = v;
+        *reinterpret_cast<uint4*>(img + a_off(row, ch * 8)) = v;
     }
 }
 
@@ -784,7 +801,7 @@ __global__ __launch_bounds__(512) void k_attention_bwd(const f16* __restrict__ q
 #pragma unroll
             for (int kt = 0; kt < NKT; kt++)
 #pragma unroll
-                for (int s2 = 0; s2 < 2; s2++) o = mfma_f16(img_tr_frag(img0, kt, s2, dt, lane), dsf[kt][s2], o);
+                for (int s2 = 0; s2 < 2; s2++) o = mfma_f16(img_tr_frag_a(img0, kt, s2, dt, lane), dsf[kt][s2], o);
             if (q_idx < S) {
 #pragma unroll
                 for (int gq = 0; gq < 4; gq++)
@@ -845,8 +862,8 @@ __global__ __launch_bounds__(512) void k_attention_bwd(const f16* __restrict__ q
             for (int dt = 0; dt < 4; dt++)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; s2++) {
-                    dv[dt] = mfma_f16(img_tr_frag(img1, qt, s2, dt, lane), pdf[s2], dv[dt]);
-                    dk[dt] = mfma_f16(img_tr_frag(img0, qt, s2, dt, lane), dsf[s2], dk[dt]);
+                    dv[dt] = mfma_f16(img_tr_frag_a(img1, qt, s2, dt, lane), pdf[s2], dv[dt]);
+                    dk[dt] = mfma_f16(img_tr_frag_a(img0, qt, s2, dt, lane), dsf[s2], dk[dt]);
                 }
         }
         if (key_idx < S) {
