@@ -146,6 +146,7 @@ def main():
         achieved = fl / (fam_ms[dom] * 1e-3) / 1e12 if fam_ms[dom] > 0 else 0.0
         # whole path: 7.353 GFLOP per clip per denoise step (14.706 with CFG), SURVEY.md section 8d
         flops_per_clip = 7.353e9 * NS * (2 if args.cfg else 1)
+        traffic, traffic_src = pmc_traffic(dom, rows)
         line = {
             "metric": "denoised motion clips/sec (1000-step DDPM, Bx263x196)",
             "value": round(value, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -156,7 +157,7 @@ def main():
                        "root_horizontal inpainting" + (", classifier-free guidance scale 2.5 (doubled batch)" if args.cfg else ""),
                        "global_batch": world * B, "denoise_steps": NS, "parallelism": f"clip-sharded x{world}, no collective"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_us": round(1e3 * fam_ms[dom], 2), "launches_timed": prof[dom][1],
                          "clips_per_timed_launch": rows, "concurrent_slices_elsewhere": slices,
                          "whole_path_tflops": round(value * flops_per_clip * 1e-12, 2),
@@ -167,6 +168,22 @@ def main():
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def pmc_traffic(family, rows):
+    """HBM bytes per launch of the dominant kernel from the PMC passes (tools/pmc_traffic.sh: separate rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE runs with full-batch launches, units and gfx950 correction per the microarch guide), committed as
+    profiles/r01_final_pmc_traffic.json.  Counters cannot be read from inside this process, so the figure is null unless that
+    file was collected for the same per-launch work (64 clips, no CFG)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_final_pmc_traffic.json")
+    key = "ln_gemm" if family in ("outproj_ln_gemm", "ffn2_ln_gemm") else family
+    try:
+        k = json.load(open(path))["kernels"][key]
+    except (OSError, KeyError, ValueError):
+        return None, None
+    if rows != 64:
+        return None, None
+    return k["hbm_bytes"], "profiles/r01_final_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 64-clip launches)"
 
 
 def cpu_baseline(w, pe, tab, tmap, B, F, T, NS, sample_steps, seed):
