@@ -81,3 +81,48 @@ def test_bucketed_allreduce_equals_full_batch_gradients():
         assert nbytes == [2102784 * 4, 2102784 * 4]  # one 8.4 MB bucket per layer
         for n, g in ref.items():
             assert torch.allclose(torch.from_numpy(grads[n]), g, rtol=1e-4, atol=1e-7), n
+
+
+def _worker_native_protocol(rank, ws, port, q):
+    """The native training node's hand-off, without the GPU: gradients are computed by autograd on CPU, then delivered the
+    way GradSink.flush delivers them (added into the existing p.grad bucket views in one go, followed by the
+    `_native_grads_ready` notification) to a reducer in native mode (no per-parameter hooks)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(ws))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        from mst_amd.finetune_dp import LayerBucketReducer
+        m = _model()
+        params = [p for p in m.parameters() if p.requires_grad]
+        local = torch.autograd.grad(_loss(m, 2 * rank, 2 * rank + 2), params)
+        red = LayerBucketReducer(m)
+        red.native = True                                   # as on GPU parameters with train_backend == "native"
+        m.__dict__["_native_grads_ready"] = red._native_ready
+        red.zero_grad()
+        torch._foreach_add_([p.grad for p in params], list(local))          # GradSink.flush, existing-gradient branch
+        m._native_grads_ready()
+        red.finish()
+        q.put((rank, {n: p.grad.clone().numpy() for n, p in m.named_parameters() if p.requires_grad}, red.launch_order))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_native_gradient_handoff_allreduces_buckets():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_native_protocol, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.set_num_threads(2)
+    m = _model()
+    _loss(m, 0, 4).backward()
+    ref = {n: p.grad for n, p in m.named_parameters() if p.requires_grad}
+    for rank, grads, order in res:
+        assert order == [1, 0]
+        for n, g in ref.items():
+            assert torch.allclose(torch.from_numpy(grads[n]), g, rtol=1e-4, atol=1e-7), n
