@@ -251,24 +251,6 @@ __global__ __launch_bounds__(512) void k_qkv_attention(const f16* __restrict__ h
 #if defined(QA_NOMFMA)
         if (kt < 0)
 #endif
-#if defined(QA_SPLIT)       // timing experiment only (QA_STOP=1): 2 token tiles x 6 feature tiles per wave, all 8 waves busy
-        {
-            const char* st = smem + (kt % TL::NSTAGE) * TL::STAGE;
-            const int tp = wave & 3, fh = wave >> 2;
-#pragma unroll
-            for (int ks = 0; ks < TL::KDEPTH / 16; ks++) {
-                const int c = ks * 2 + hh;
-                const f16x8 xf0 = *reinterpret_cast<const f16x8*>(st + ring_off_rb<TL::RB>((2 * tp) * 32 + l31, c));
-                const f16x8 xf1 = *reinterpret_cast<const f16x8*>(st + ring_off_rb<TL::RB>((2 * tp + 1) * 32 + l31, c));
-#pragma unroll
-                for (int n = 0; n < 6; n++) {
-                    const f16x8 wf = *reinterpret_cast<const f16x8*>(st + ring_off_rb<TL::RB>(TL::XR + (6 * fh + n) * 32 + l31, c));
-                    acc[n] = mfma_f16(wf, xf0, acc[n]);
-                    acc[6 + n] = mfma_f16(wf, xf1, acc[6 + n]);
-                }
-            }
-        }
-#else
         if (active) {
             const char* st = smem + (kt % TL::NSTAGE) * TL::STAGE;
 #pragma unroll
@@ -282,7 +264,6 @@ __global__ __launch_bounds__(512) void k_qkv_attention(const f16* __restrict__ h
                 }
             }
         }
-#endif
     }
     __builtin_amdgcn_s_barrier();                       // ring dead: reuse it for the K / V images
 #if defined(QA_STOP) && QA_STOP == 1                    // timing ablation: projection main loop only
