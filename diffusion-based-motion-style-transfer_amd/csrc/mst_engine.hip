@@ -866,7 +866,7 @@ extern "C" int mst_philox_normal(float* out, int32_t batch, int32_t feats, int32
 // ------------------------------------------------------------------------------------------ training ABI
 // The trainable encoder stack (seqTransEncoder, mdm_forstyledataset.py:539-546) in training mode.
 // Tape: per layer the activations the backward pass needs, in caller-owned memory.
-struct TapeL { f16 *qkv, *att, *z1h, *z1l, *x1h, *x1l, *pre, *hid, *z2h, *z2l; };
+struct TapeL { f16 *qkv, *att, *z1h, *z1l, *x1h, *x1l, *pre, *hid, *z2h, *z2l; float* lse; };
 struct Tape { f16* sh[17]; f16* sl[17]; TapeL L[16]; };
 static size_t tape_rows(int M) { return ((size_t)(M + 255) / 256) * 256 + 256; }     // whole tiles + one spare (over-read)
 static size_t tape_layout(char* base, int nl, size_t Mp, Tape* t) {
@@ -879,6 +879,7 @@ static size_t tape_layout(char* base, int nl, size_t Mp, Tape* t) {
         a.z1h = take(MST_D); a.z1l = take(MST_D); a.x1h = take(MST_D); a.x1l = take(MST_D);
         a.pre = take(MST_FF); a.hid = take(MST_FF);
         a.z2h = take(MST_D); a.z2l = take(MST_D);
+        a.lse = reinterpret_cast<float*>(take(2 * MST_H));            // softmax row statistics [rows][4][S] (4 floats per token)
     }
     return off;
 }
@@ -911,7 +912,7 @@ extern "C" int64_t mst_train_tape_bytes(const mst_engine* e, int32_t rows, int32
 }
 
 template <int NKT>
-static int launch_attn_train_n(const f16* qkv, f16* out, int S, int rows, Drop d, const unsigned char* keep, int qsplit, hipStream_t st) {
+static int launch_attn_train_n(const f16* qkv, f16* out, int S, int rows, Drop d, const unsigned char* keep, int qsplit, float* lse, hipStream_t st) {
     auto kern = k_attention_train<NKT>;
     static bool attr_set = false;
     const int smem = NKT * 32 * 256 * 2 + NKT * 32 * 4;
@@ -919,13 +920,13 @@ static int launch_attn_train_n(const f16* qkv, f16* out, int S, int rows, Drop d
         HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(rows * MST_H, qsplit ? NKT : 1), dim3(512), smem, st, qkv, out, S, d, keep, qsplit);
+    hipLaunchKernelGGL(kern, dim3(rows * MST_H, qsplit ? NKT : 1), dim3(512), smem, st, qkv, out, S, d, keep, qsplit, lse);
     HIPCHECK(hipGetLastError());
     return 0;
 }
 template <int NKT>
 static int launch_attn_bwd_n(const f16* qkv, const f16* att, const f16* datt, f16* dqkv, int S, int rows, Drop d,
-                             const unsigned char* keep, hipStream_t st) {
+                             const unsigned char* keep, const float* lse, int split, hipStream_t st) {
     auto kern = k_attention_bwd<NKT>;
     static bool attr_set = false;
     const int smem = NKT * 32 * 256 * 2 + NKT * 32 * 12;
@@ -933,7 +934,7 @@ static int launch_attn_bwd_n(const f16* qkv, const f16* att, const f16* datt, f1
         HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(rows * MST_H), dim3(512), smem, st, qkv, att, datt, dqkv, S, d, keep);
+    hipLaunchKernelGGL(kern, dim3(rows * MST_H, split ? 2 * NKT : 1), dim3(512), smem, st, qkv, att, datt, dqkv, S, d, keep, lse, split);
     HIPCHECK(hipGetLastError());
     return 0;
 }
@@ -948,12 +949,12 @@ static int launch_attn_bwd_n(const f16* qkv, const f16* att, const f16* datt, f1
         case 7: return fn<7>(__VA_ARGS__);                        \
     }                                                             \
     return fail("attention: S=%d unsupported", S);
-static int launch_attn_train(const f16* qkv, f16* out, int S, int rows, Drop d, const unsigned char* keep, int qsplit, hipStream_t st) {
-    NKT_SWITCH(launch_attn_train_n, S, qkv, out, S, rows, d, keep, qsplit, st)
+static int launch_attn_train(const f16* qkv, f16* out, int S, int rows, Drop d, const unsigned char* keep, int qsplit, float* lse, hipStream_t st) {
+    NKT_SWITCH(launch_attn_train_n, S, qkv, out, S, rows, d, keep, qsplit, lse, st)
 }
 static int launch_attn_bwd(const f16* qkv, const f16* att, const f16* datt, f16* dqkv, int S, int rows, Drop d,
-                           const unsigned char* keep, hipStream_t st) {
-    NKT_SWITCH(launch_attn_bwd_n, S, qkv, att, datt, dqkv, S, rows, d, keep, st)
+                           const unsigned char* keep, const float* lse, int split, hipStream_t st) {
+    NKT_SWITCH(launch_attn_bwd_n, S, qkv, att, datt, dqkv, S, rows, d, keep, lse, split, st)
 }
 
 // h_in / h_out: [rows][S][512] float32 (clip-major token rows).  mdm_forstyledataset.py:622 `self.seqTransEncoder(xseq)`
@@ -979,7 +980,7 @@ extern "C" int mst_train_forward(mst_engine* e, const float* h_in, int32_t rows,
             DEpiBiasF16<false> epi{w.b_in, a.qkv, 3 * MST_D, M};
             CHECK(launch_small(M, 3 * MST_D, RowsDirect{t.sh[l], MST_D}, w.w_in, MST_D, MST_D, epi, st));
         }
-        CHECK(launch_attn_train(a.qkv, a.att, S, rows, make_drop(seed, l, 0, p_drop), key_keep, 1, st));
+        CHECK(launch_attn_train(a.qkv, a.att, S, rows, make_drop(seed, l, 0, p_drop), key_keep, 1, a.lse, st));
         {
             DEpiPlainF32 epi{e->zacc, MST_D, M};
             CHECK(launch_small(M, MST_D, RowsDirect{a.att, MST_D}, w.w_out, MST_D, MST_D, epi, st));
@@ -1006,7 +1007,7 @@ extern "C" int mst_train_forward(mst_engine* e, const float* h_in, int32_t rows,
             DEpiBiasF16<false> epi{w.b_in, a.qkv, 3 * MST_D, M};
             CHECK((launch_wide(M, 3 * MST_D / 256, RowsDirect{t.sh[l], MST_D}, w.w_in, MST_D, MST_D, epi, st)));
         }
-        CHECK(launch_attn_train(a.qkv, a.att, S, rows, make_drop(seed, l, 0, p_drop), key_keep, 0, st));
+        CHECK(launch_attn_train(a.qkv, a.att, S, rows, make_drop(seed, l, 0, p_drop), key_keep, 0, a.lse, st));
         {
             DEpiResidLNTrain epi{w.b_out, w.g1, w.be1, t.sh[l], t.sl[l], a.z1h, a.z1l, a.x1h, a.x1l, M, make_drop(seed, l, 1, p_drop)};
             CHECK((launch_gemm_dma<64, 512, 2, 2, LN_NS, 1, LN_BK>(dim3((M + 63) / 64, 1), RowsDirect{a.att, MST_D}, w.w_out, MST_D, MST_D, epi, st)));
@@ -1171,7 +1172,7 @@ extern "C" int mst_train_backward(mst_engine* e, const void* tape, const float* 
                         : launch_wide(M, MST_D / 256, RowsDirect{dbr1, MST_D}, w.w_outT, MST_D, MST_D, epi, st));
         }
         // attention backward -> d qkv
-        CHECK(launch_attn_bwd(a.qkv, a.att, w_.datt, dqkv, S, rows, make_drop(seed, l, 0, p_drop), key_keep, st));
+        CHECK(launch_attn_bwd(a.qkv, a.att, w_.datt, dqkv, S, rows, make_drop(seed, l, 0, p_drop), key_keep, a.lse, small ? 1 : 0, st));
         TO_SIDE()
         if (wg) CHECK(wgrad(e, dqkv, 3 * MST_D, t.sh[l], MST_D, M, G[0], G[1], sw));               // dW_in += dqkv^T x_in, db_in
         if (two && wg) {

@@ -543,7 +543,8 @@ __device__ __forceinline__ void stage_key_bias(float* kbias, const unsigned char
 
 template <int NKT>
 __global__ __launch_bounds__(512) void k_attention_train(const f16* __restrict__ qkv, f16* __restrict__ out, int S, Drop d,
-                                                         const unsigned char* __restrict__ keep, int qsplit) {
+                                                         const unsigned char* __restrict__ keep, int qsplit,
+                                                         float* __restrict__ lse_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KEYS = NKT * 32;
     char* ks = smem;
@@ -615,6 +616,7 @@ __global__ __launch_bounds__(512) void k_attention_train(const f16* __restrict__
     l += __shfl_xor(l, 32);
     const float inv_l = 1.0f / l;
     const int ch = clip * MST_H + head;
+    if (lse_out && hh == 0 && q_idx < S) lse_out[(size_t)ch * S + q_idx] = m + __logf(l);   // row statistics for the split backward
     f16x8 pf[NKT][2];
 #pragma unroll
     for (int kt = 0; kt < NKT; kt++)
@@ -705,7 +707,11 @@ __device__ __forceinline__ void stage_image(char* img, const f16* src, size_t ro
 template <int NKT>
 __global__ __launch_bounds__(512) void k_attention_bwd(const f16* __restrict__ qkv, const f16* __restrict__ att,
                                                        const f16* __restrict__ datt, f16* __restrict__ dqkv, int S, Drop d,
-                                                       const unsigned char* __restrict__ keep) {
+                                                       const unsigned char* __restrict__ keep, const float* __restrict__ lse_in,
+                                                       int split) {
+    // split = 1 (small batches): grid.y = 2 NKT; workgroup y < NKT runs pass 1 for query tile y, workgroup NKT + j runs pass 2
+    // for key tile j, each on wave 0 with the row statistics of the forward (lse_in) instead of pass 1's -- 14 workgroups per
+    // (clip, head) instead of one whose waves walk both passes back to back.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KEYS = NKT * 32;
     char* img0 = smem;
@@ -722,13 +728,17 @@ __global__ __launch_bounds__(512) void k_attention_bwd(const f16* __restrict__ q
     f16* dbase = dqkv + (size_t)clip * S * (3 * MST_D) + head * MST_HD;
     const float scale = 0.08838834764831845f;
 
-    // ---------------- pass 1: K -> img0, V -> img1
+    const bool role_q = !split || (int)blockIdx.y < NKT, role_k = !split || (int)blockIdx.y >= NKT;   // block-uniform
+    const int tile = split ? (int)blockIdx.y % NKT : wave;
+    const bool act = split ? wave == 0 : wave < NKT;
     stage_key_bias(kbias, keep, clip, S, KEYS, tid);
+    // ---------------- pass 1: K -> img0, V -> img1
+    if (role_q) {
     stage_image(img0, base + MST_D, 3 * MST_D, S, KEYS, tid);
     stage_image(img1, base + 2 * MST_D, 3 * MST_D, S, KEYS, tid);
     __syncthreads();
-    if (wave < NKT) {
-        const int q_idx = wave * 32 + l31, q_ld = q_idx < S ? q_idx : S - 1;
+    if (act) {
+        const int q_idx = tile * 32 + l31, q_ld = q_idx < S ? q_idx : S - 1;
         f16x8 qf[8], dof[8];
         float D = 0.f;
         {
@@ -810,15 +820,34 @@ __global__ __launch_bounds__(512) void k_attention_bwd(const f16* __restrict__ q
             }
         }
     }
+    }   // role_q
+    if (!role_k) return;
     __syncthreads();
 
     // ---------------- pass 2: Q -> img0, dO -> img1
+    if (split) {                                          // statistics of every query row: lse from the forward, D = sum_d dO O
+        for (int q = tid; q < KEYS; q += 512) {
+            float D = 0.f, ls = INFINITY;
+            if (q < S) {
+                ls = lse_in[(size_t)ch * S + q];
+                const f16* dp = dobase + (size_t)q * MST_D;
+                const f16* op = obase + (size_t)q * MST_D;
+                for (int c8 = 0; c8 < 16; c8++) {
+                    const f16x8 a8 = *reinterpret_cast<const f16x8*>(dp + c8 * 8), b8 = *reinterpret_cast<const f16x8*>(op + c8 * 8);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) D += (float)a8[j] * (float)b8[j];
+                }
+            }
+            lse_s[q] = ls;
+            dq_s[q] = D;
+        }
+    }
     stage_image(img0, base, 3 * MST_D, S, KEYS, tid);
     stage_image(img1, dobase, MST_D, S, KEYS, tid);
     __syncthreads();
-    if (wave >= NKT) return;
+    if (!act) return;
     {
-        const int key_idx = wave * 32 + l31, key_ld = key_idx < S ? key_idx : S - 1;
+        const int key_idx = tile * 32 + l31, key_ld = key_idx < S ? key_idx : S - 1;
         const bool key_ok = kbias[key_idx] == 0.f;            // real, un-padded key
         f16x8 kf[8], vf[8];
         {
