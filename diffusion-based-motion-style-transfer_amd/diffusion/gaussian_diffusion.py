@@ -13,8 +13,7 @@ _extract_into_tensor :1605-1618, schedules :22-66), but the arithmetic runs in t
            (mst_step_epilogue), q_sample another (mst_q_sample).
   * `*_with_grad` variants (fine-tuning) keep x0-hat in the autograd graph, so
     their few elementwise lines are torch ops on the GPU; the model call inside them runs the native training node
-    (model/native_stack.py)
-    (DESIGN.md "out of scope this round").
+    (model/native_stack.py).
 
 Nothing here touches `oracle/`; CPU tensors are rejected instead of silently computed on the host.
 """
