@@ -22,8 +22,12 @@ __global__ void k_copy_pad_f32(const float* __restrict__ src, int n, float* __re
 
 // x [clips][F][T] float32 -> xt [clips*T][Kpad] f16 (frames as rows, features contiguous, zero padded):
 // the activation operand of the pose-embedding GEMM in the layout the LDS-DMA ring loads.
-__global__ __launch_bounds__(256) void k_frames_f16(const float* __restrict__ x, int F, int T, int Kpad, f16* __restrict__ xt) {
+// gscale != null: values are multiplied by gscale[0] first (backward of the output projection: the incoming gradient
+// is brought into f16 range by the device-side scale of the training path).
+__global__ __launch_bounds__(256) void k_frames_f16(const float* __restrict__ x, int F, int T, int Kpad, f16* __restrict__ xt,
+                                                    const float* __restrict__ gscale) {
     __shared__ float tile[32][33];
+    const float sc = gscale ? gscale[0] : 1.0f;
     const int clip = blockIdx.z, f0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
@@ -35,7 +39,7 @@ __global__ __launch_bounds__(256) void k_frames_f16(const float* __restrict__ x,
 #pragma unroll
     for (int j = ty; j < 32; j += 8) {
         int t = t0 + j, f = f0 + tx;
-        if (t < T && f < Kpad) xt[((size_t)clip * T + t) * Kpad + f] = (f16)tile[tx][j];
+        if (t < T && f < Kpad) xt[((size_t)clip * T + t) * Kpad + f] = (f16)(tile[tx][j] * sc);
     }
 }
 

@@ -123,6 +123,7 @@ struct mst_engine {
     int S_max = 0, M_pad = 0, kin_pad = 0, nt_out = 0, fout_pad = 0;
     LayerW L[16];
     f16 *w_pose_in = nullptr, *w_pose_out = nullptr;
+    f16 *w_pose_inT = nullptr, *w_pose_outT = nullptr;   // [fout_pad][512] and [512][kin_pad]: the projections' dgrad operands
     float *b_pose_in = nullptr, *b_pose_out = nullptr;
     float *w_t0 = nullptr, *b_t0 = nullptr, *w_t2 = nullptr, *b_t2 = nullptr, *w_text = nullptr, *b_text = nullptr;
     float* pe = nullptr;
@@ -230,6 +231,8 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     CHECK(dmalloc(&e->b_pose_in, MST_D));
     CHECK(dmalloc(&e->w_pose_out, (size_t)e->fout_pad * MST_D));
     CHECK(dmalloc(&e->b_pose_out, e->fout_pad));
+    CHECK(dmalloc(&e->w_pose_inT, (size_t)e->fout_pad * MST_D));
+    CHECK(dmalloc(&e->w_pose_outT, (size_t)MST_D * e->kin_pad));
     CHECK(dmalloc(&e->w_t0, (size_t)MST_D * MST_D));
     CHECK(dmalloc(&e->b_t0, MST_D));
     CHECK(dmalloc(&e->w_t2, (size_t)MST_D * MST_D));
@@ -280,7 +283,7 @@ extern "C" void mst_engine_destroy(mst_engine* e) {
         for (int i = 0; i < 2; i++) if (t.ev_side[i]) (void)hipEventDestroy(t.ev_side[i]);
         for (void* q : p) (void)hipFree(q);
     }
-    void* p[] = {e->w_pose_in, e->b_pose_in, e->w_pose_out, e->b_pose_out, e->w_t0, e->b_t0, e->w_t2, e->b_t2,
+    void* p[] = {e->w_pose_in, e->b_pose_in, e->w_pose_out, e->b_pose_out, e->w_pose_inT, e->w_pose_outT, e->w_t0, e->b_t0, e->w_t2, e->b_t2,
                  e->w_text, e->b_text, e->pe, e->hl, e->hx, e->qkv, e->att, e->hid, e->xt, e->temb_hid, e->temb, e->textproj, e->zacc};
     for (void* q : p) (void)hipFree(q);
     for (int i = 0; i < mst_engine::MAX_SLICES - 1; i++) {
@@ -302,7 +305,7 @@ static int put_matrix(const float* src, int N, int K, f16* dst, int Npad, int Kp
     return 0;
 }
 static int put_matrix_t(const float* src, int N, int K, f16* dst, hipStream_t st) {      // [N][K] f32 -> [K][N] f16
-    hipLaunchKernelGGL(k_convert_transpose, dim3((K + 31) / 32, (N + 31) / 32), dim3(256), 0, st, src, N, K, dst);
+    hipLaunchKernelGGL(k_convert_transpose, dim3((K + 31) / 32, (N + 31) / 32), dim3(256), 0, st, src, N, K, dst, N);
     HIPCHECK(hipGetLastError());
     return 0;
 }
@@ -349,12 +352,20 @@ extern "C" int mst_load_weight(mst_engine* e, const char* name, const float* src
     } else if (n == "input_process.poseEmbedding.weight") {
         if (!shape_is(shape, ndim, MST_D, F)) return fail("mst_load_weight: %s: bad shape", name);
         rc = put_matrix(src, MST_D, F, e->w_pose_in, MST_D, e->kin_pad, st);
+        if (!rc) {      // [512][F] -> [F (padded to fout_pad)][512]
+            hipLaunchKernelGGL(k_convert_transpose, dim3((F + 31) / 32, (MST_D + 31) / 32), dim3(256), 0, st, src, MST_D, F, e->w_pose_inT, MST_D);
+            HIPCHECK(hipGetLastError());
+        }
     } else if (n == "input_process.poseEmbedding.bias") {
         if (!shape_is(shape, ndim, MST_D)) return fail("mst_load_weight: %s: bad shape", name);
         rc = put_vector(src, MST_D, e->b_pose_in, MST_D, st);
     } else if (n == "output_process.poseFinal.weight") {
         if (!shape_is(shape, ndim, F, MST_D)) return fail("mst_load_weight: %s: bad shape", name);
         rc = put_matrix(src, F, MST_D, e->w_pose_out, e->fout_pad, MST_D, st);
+        if (!rc) {      // [F][512] -> [512][F (padded to kin_pad)]
+            hipLaunchKernelGGL(k_convert_transpose, dim3((MST_D + 31) / 32, (F + 31) / 32), dim3(256), 0, st, src, F, MST_D, e->w_pose_outT, e->kin_pad);
+            HIPCHECK(hipGetLastError());
+        }
     } else if (n == "output_process.poseFinal.bias") {
         if (!shape_is(shape, ndim, F)) return fail("mst_load_weight: %s: bad shape", name);
         rc = put_vector(src, F, e->b_pose_out, e->fout_pad, st);
@@ -575,9 +586,10 @@ static WS ws_slice(const mst_engine* e, int r0, int T) {
 }
 
 // K3 .. K8: token stream through the encoder stack.  rows = clips through the transformer.
-static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, int rows, int T, int temb_uniform_row, int temb_mod,
-                     hipStream_t st, int tp_uncond = 0) {
-    const int S = T + 1, M = rows * S;
+// K1-K3: conditioning token + pose embedding of the frames -> token stream rows (ws.hx / ws.hl)
+static int assemble_stream(mst_engine* e, const WS& ws, const float* x, int clips_x, int rows, int T, int temb_uniform_row, int temb_mod,
+                           hipStream_t st, int tp_uncond) {
+    const int S = T + 1;
     {
         ProfScope ps(e, FAM_COND, st);
         hipLaunchKernelGGL(k_cond_token, dim3((rows * MST_D + 255) / 256), dim3(256), 0, st, e->temb, temb_uniform_row,
@@ -589,12 +601,20 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
         // CFG batch feeds the same x to both halves: embed once, store twice (dup).
         ProfScope ps(e, FAM_EMBED_IN, st);
         const int F = e->cfg.feats, tot = clips_x * T;
-        hipLaunchKernelGGL(k_frames_f16, dim3((T + 31) / 32, e->kin_pad / 32, clips_x), dim3(256), 0, st, x, F, T, e->kin_pad, ws.xt);
+        hipLaunchKernelGGL(k_frames_f16, dim3((T + 31) / 32, e->kin_pad / 32, clips_x), dim3(256), 0, st, x, F, T, e->kin_pad, ws.xt, (const float*)nullptr);
         HIPCHECK(hipGetLastError());
         DEpiEmbedIn epi{e->b_pose_in, e->pe, ws.hx, ws.hl, T, S, tot, rows > clips_x ? (size_t)clips_x * S * MST_D : 0};
         CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1>(dim3((tot + 63) / 64, 1), RowsDirect{ws.xt, e->kin_pad}, e->w_pose_in, e->kin_pad,
                                                    e->kin_pad, epi, st)));
     }
+    return 0;
+}
+
+// K3 .. K8: token stream through the encoder stack.  rows = clips through the transformer.
+static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, int rows, int T, int temb_uniform_row, int temb_mod,
+                     hipStream_t st, int tp_uncond = 0) {
+    const int S = T + 1, M = rows * S;
+    CHECK(assemble_stream(e, ws, x, clips_x, rows, T, temb_uniform_row, temb_mod, st, tp_uncond));
     if (e->dbg_stage == 0) return 0;
 #define DBG_STOP(stage) if (e->dbg_layer == l && e->dbg_stage == stage) return 0;
     const bool small = e->small_m > 0 && M <= e->small_m;
@@ -682,22 +702,25 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
 
 // output projection tiles: 64 frames x (256 * NTO) features, 8 waves as 1 x 8 with 2 x NTO MFMA tiles each
 template <int MODE, int NTO, int NX>
-static int launch_out(mst_engine* e, const WS& ws, int batch, int T, float* out, const StepArgs& sa, hipStream_t st) {
+static int launch_out(mst_engine* e, const WS& ws, int batch, int T, float* out, const StepArgs& sa, hipStream_t st,
+                      const f16* w_override = nullptr, const float* b_override = nullptr) {
     const int S = T + 1;
     RowsFrames xs{ws.hx, MST_D, T, S, batch * T, 64, (size_t)batch * S};
-    DEpiEmbedOut<MODE> epi{e->b_pose_out, e->cfg.feats, T, batch * T, out, sa};
-    return launch_gemm_dma<64, 256 * NTO, 2, NTO, 4, NX>(dim3((batch * T + 63) / 64, 1), xs, e->w_pose_out, MST_D, MST_D, epi, st);
+    DEpiEmbedOut<MODE> epi{b_override ? b_override : e->b_pose_out, e->cfg.feats, T, batch * T, out, sa};
+    return launch_gemm_dma<64, 256 * NTO, 2, NTO, 4, NX>(dim3((batch * T + 63) / 64, 1), xs, w_override ? w_override : e->w_pose_out, MST_D, MST_D, epi, st);
 }
 template <int MODE, int NTO>
-static int launch_out_nx(mst_engine* e, const WS& ws, int cfg, int batch, int T, float* out, const StepArgs& sa, hipStream_t st) {
-    return cfg ? launch_out<MODE, NTO, 2>(e, ws, batch, T, out, sa, st) : launch_out<MODE, NTO, 1>(e, ws, batch, T, out, sa, st);
+static int launch_out_nx(mst_engine* e, const WS& ws, int cfg, int batch, int T, float* out, const StepArgs& sa, hipStream_t st,
+                         const f16* wo = nullptr, const float* bo = nullptr) {
+    return cfg ? launch_out<MODE, NTO, 2>(e, ws, batch, T, out, sa, st, wo, bo) : launch_out<MODE, NTO, 1>(e, ws, batch, T, out, sa, st, wo, bo);
 }
 template <int MODE>
-static int launch_out_nt(mst_engine* e, const WS& ws, int cfg, int batch, int T, float* out, const StepArgs& sa, hipStream_t st) {
+static int launch_out_nt(mst_engine* e, const WS& ws, int cfg, int batch, int T, float* out, const StepArgs& sa, hipStream_t st,
+                         const f16* wo = nullptr, const float* bo = nullptr) {
     ProfScope ps(e, FAM_EMBED_OUT, st);
     switch (e->nt_out) {
-        case 1: return launch_out_nx<MODE, 1>(e, ws, cfg, batch, T, out, sa, st);
-        case 2: return launch_out_nx<MODE, 2>(e, ws, cfg, batch, T, out, sa, st);
+        case 1: return launch_out_nx<MODE, 1>(e, ws, cfg, batch, T, out, sa, st, wo, bo);
+        case 2: return launch_out_nx<MODE, 2>(e, ws, cfg, batch, T, out, sa, st, wo, bo);
     }
     return fail("output projection: feats %d unsupported", e->cfg.feats);
 }
@@ -959,18 +982,10 @@ static int launch_attn_bwd(const f16* qkv, const f16* att, const f16* datt, f16*
 
 // h_in / h_out: [rows][S][512] float32 (clip-major token rows).  mdm_forstyledataset.py:622 `self.seqTransEncoder(xseq)`
 // with nn.TransformerEncoderLayer semantics (post-norm, erf GELU, dropout p at the four sites of the layer).
-extern "C" int mst_train_forward(mst_engine* e, const float* h_in, int32_t rows, int32_t S, float p_drop, uint64_t seed,
-                                 const uint8_t* key_keep, void* tape, float* h_out, void* stream) {
-    CHECK(train_check(e, rows, S, p_drop));
-    if (!h_in || !tape || !h_out) return fail("mst_train_forward: null argument");
-    hipStream_t st = (hipStream_t)stream;
-    HIPCHECK(hipSetDevice(e->cfg.device));
+// the eight layers from tape slot 0 to slot num_layers
+static int train_stack_forward(mst_engine* e, const Tape& t, int rows, int S, float p_drop, uint64_t seed, const uint8_t* key_keep,
+                               hipStream_t st) {
     const int M = rows * S, nl = e->cfg.num_layers;
-    Tape t;
-    tape_layout((char*)tape, nl, tape_rows(M), &t);
-    const size_t n = (size_t)M * MST_D;
-    hipLaunchKernelGGL(k_split_stream, dim3(1024), dim3(256), 0, st, h_in, n, t.sh[0], t.sl[0]);
-    HIPCHECK(hipGetLastError());
     e->prof_now = 0;
     const bool small = e->small_m > 0 && M <= e->small_m;
     for (int l = 0; small && l < nl; l++) {              // few token rows: 64 x 128 tiles, row-wise LayerNorm, query-split attention
@@ -1021,6 +1036,22 @@ extern "C" int mst_train_forward(mst_engine* e, const float* h_in, int32_t rows,
             CHECK((launch_gemm_dma<64, 512, 2, 2, LN_NS, 1, LN_BK>(dim3((M + 63) / 64, 1), RowsDirect{a.hid, MST_FF}, w.w2, MST_FF, MST_FF, epi, st)));
         }
     }
+    return 0;
+}
+
+extern "C" int mst_train_forward(mst_engine* e, const float* h_in, int32_t rows, int32_t S, float p_drop, uint64_t seed,
+                                 const uint8_t* key_keep, void* tape, float* h_out, void* stream) {
+    CHECK(train_check(e, rows, S, p_drop));
+    if (!h_in || !tape || !h_out) return fail("mst_train_forward: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHECK(hipSetDevice(e->cfg.device));
+    const int M = rows * S, nl = e->cfg.num_layers;
+    Tape t;
+    tape_layout((char*)tape, nl, tape_rows(M), &t);
+    const size_t n = (size_t)M * MST_D;
+    hipLaunchKernelGGL(k_split_stream, dim3(1024), dim3(256), 0, st, h_in, n, t.sh[0], t.sl[0]);
+    HIPCHECK(hipGetLastError());
+    CHECK(train_stack_forward(e, t, rows, S, p_drop, seed, key_keep, st));
     hipLaunchKernelGGL(k_join_stream, dim3(1024), dim3(256), 0, st, t.sh[nl], t.sl[nl], h_out, n);
     HIPCHECK(hipGetLastError());
     return 0;
@@ -1092,25 +1123,22 @@ static int wgrad(mst_engine* e, const f16* dY, int n_out, const f16* X, int k_in
 // grads: HOST array of num_layers * 12 device pointers in nn.TransformerEncoderLayer parameter order
 // (in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias, linear1.weight, linear1.bias, linear2.weight,
 //  linear2.bias, norm1.weight, norm1.bias, norm2.weight, norm2.bias); every buffer is ACCUMULATED into.
-extern "C" int mst_train_backward(mst_engine* e, const void* tape, const float* d_out, int32_t rows, int32_t S, float p_drop,
-                                  uint64_t seed, const uint8_t* key_keep, float* d_in, float* const* grads, void* stream) {
-    CHECK(train_check(e, rows, S, p_drop));
-    if (!tape || !d_out) return fail("mst_train_backward: null argument");
-    if (!grads && !d_in) return 0;                       // nothing asked for
-    hipStream_t st = (hipStream_t)stream;
-    HIPCHECK(hipSetDevice(e->cfg.device));
-    CHECK(train_ws(e));
+// device-side gradient scaling: gscale <- the power of two that brings max |g| into [16, 32)
+static int grad_scale_from(mst_engine* e, const float* g, size_t n, hipStream_t st) {
+    TrainWS& w_ = e->tw;
+    HIPCHECK(hipMemsetAsync(w_.amax, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL(k_amax, dim3(512), dim3(256), 0, st, g, n, w_.amax);
+    hipLaunchKernelGGL(k_grad_scale, dim3(1), dim3(1), 0, st, w_.amax, w_.gscale);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+// the eight layers backwards: on entry tw.g1 holds the SCALED gradient wrt the stack output, on exit the scaled gradient
+// wrt tape slot 0
+static int train_stack_backward(mst_engine* e, const Tape& t, int rows, int S, float p_drop, uint64_t seed, const uint8_t* key_keep,
+                                float* const* grads, hipStream_t st) {
     TrainWS& w_ = e->tw;
     const int M = rows * S, nl = e->cfg.num_layers;
-    Tape t;
-    tape_layout((char*)const_cast<void*>(tape), nl, tape_rows(M), &t);
-    const size_t n = (size_t)M * MST_D;
-    // device-side gradient scaling: max |d_out| -> [16, 32)
-    HIPCHECK(hipMemsetAsync(w_.amax, 0, sizeof(unsigned), st));
-    hipLaunchKernelGGL(k_amax, dim3(512), dim3(256), 0, st, d_out, n, w_.amax);
-    hipLaunchKernelGGL(k_grad_scale, dim3(1), dim3(1), 0, st, w_.amax, w_.gscale);
-    hipLaunchKernelGGL(k_scale_f32, dim3(1024), dim3(256), 0, st, d_out, n, w_.gscale, 0, w_.g1);
-    HIPCHECK(hipGetLastError());
     float* gA = w_.g0;      // dz buffers
     float* gB = w_.g1;      // gradient wrt the current layer output
     const int ln_blocks = (M + 3) / 4 < 512 ? (M + 3) / 4 : 512;
@@ -1190,8 +1218,106 @@ extern "C" int mst_train_backward(mst_engine* e, const void* tape, const float* 
     if (two)
         for (int i = 0; i < 2; i++)
             if (side_used[i]) HIPCHECK(hipStreamWaitEvent(st, w_.ev_side[i], 0));
+    return 0;
+}
+
+extern "C" int mst_train_backward(mst_engine* e, const void* tape, const float* d_out, int32_t rows, int32_t S, float p_drop,
+                                  uint64_t seed, const uint8_t* key_keep, float* d_in, float* const* grads, void* stream) {
+    CHECK(train_check(e, rows, S, p_drop));
+    if (!tape || !d_out) return fail("mst_train_backward: null argument");
+    if (!grads && !d_in) return 0;                       // nothing asked for
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHECK(hipSetDevice(e->cfg.device));
+    CHECK(train_ws(e));
+    TrainWS& w_ = e->tw;
+    const int M = rows * S, nl = e->cfg.num_layers;
+    Tape t;
+    tape_layout((char*)const_cast<void*>(tape), nl, tape_rows(M), &t);
+    const size_t n = (size_t)M * MST_D;
+    CHECK(grad_scale_from(e, d_out, n, st));
+    hipLaunchKernelGGL(k_scale_f32, dim3(1024), dim3(256), 0, st, d_out, n, w_.gscale, 0, w_.g1);
+    HIPCHECK(hipGetLastError());
+    CHECK(train_stack_backward(e, t, rows, S, p_drop, seed, key_keep, grads, st));
     if (d_in) {
-        hipLaunchKernelGGL(k_scale_f32, dim3(1024), dim3(256), 0, st, gB, n, w_.gscale, 1, d_in);
+        hipLaunchKernelGGL(k_scale_f32, dim3(1024), dim3(256), 0, st, w_.g1, n, w_.gscale, 1, d_in);
+        HIPCHECK(hipGetLastError());
+    }
+    return 0;
+}
+
+// ---- the whole denoiser inside the native graph: conditioning token, pose embedding, positional-encoding dropout, the
+// trainable stack, output projection (StyleDiffusion.forward / MDM.forward, mdm_forstyledataset.py:602-625 / :315-364, in
+// train mode).  Text conditioning as for mst_forward: mst_set_text(batch, cfg = 0) first.
+static Drop pe_drop(uint64_t seed, float p) { return make_drop(seed, 32, 0, p); }       // site of its own, beyond any layer
+
+extern "C" int mst_train_model_forward(mst_engine* e, const float* x, const int64_t* t_idx, int32_t batch, int32_t frames,
+                                       float p_drop, float p_pe, uint64_t seed, void* tape, float* out, void* stream) {
+    CHECK(check_ready(e, batch, frames, 0));
+    const int S = frames + 1;
+    CHECK(train_check(e, batch, S, p_drop));
+    if (!(p_pe >= 0.f && p_pe < 1.f)) return fail("mst_train_model_forward: positional-encoding dropout %g outside [0, 1)", (double)p_pe);
+    if (!x || !t_idx || !tape || !out) return fail("mst_train_model_forward: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHECK(hipSetDevice(e->cfg.device));
+    const int M = batch * S, nl = e->cfg.num_layers;
+    Tape t;
+    tape_layout((char*)tape, nl, tape_rows(M), &t);
+    e->prof_now = 0;
+    CHECK(timestep_rows(e, (const long long*)t_idx, batch, st));
+    WS ws = ws_slice(e, 0, frames);
+    ws.hx = t.sh[0];                                      // the token stream is assembled straight into tape slot 0
+    ws.hl = t.sl[0];
+    CHECK(assemble_stream(e, ws, x, batch, batch, frames, -1, batch, st, batch));
+    if (p_pe > 0.f) {
+        hipLaunchKernelGGL(k_dropout_stream, dim3(1024), dim3(256), 0, st, t.sh[0], t.sl[0], (size_t)M * MST_D, pe_drop(seed, p_pe));
+        HIPCHECK(hipGetLastError());
+    }
+    CHECK(train_stack_forward(e, t, batch, S, p_drop, seed, nullptr, st));
+    ws.hx = t.sh[nl];
+    StepArgs sa{};
+    return launch_out_nt<0>(e, ws, 0, batch, frames, out, sa, st);
+}
+
+extern "C" int mst_train_model_backward(mst_engine* e, const void* tape, const float* d_out, int32_t batch, int32_t frames,
+                                        float p_drop, float p_pe, uint64_t seed, float* d_x, float* const* grads, void* stream) {
+    const int S = frames + 1;
+    CHECK(train_check(e, batch, S, p_drop));
+    if (!tape || !d_out) return fail("mst_train_model_backward: null argument");
+    if (!grads && !d_x) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHECK(hipSetDevice(e->cfg.device));
+    CHECK(train_ws(e));
+    TrainWS& w_ = e->tw;
+    const int M = batch * S, nl = e->cfg.num_layers, F = e->cfg.feats, tot = batch * frames;
+    Tape t;
+    tape_layout((char*)const_cast<void*>(tape), nl, tape_rows(M), &t);
+    const size_t n_out = (size_t)batch * F * frames, n = (size_t)M * MST_D;
+    e->prof_now = 0;
+    CHECK(grad_scale_from(e, d_out, n_out, st));
+    // output projection backward: token-stream gradient rows = (scaled d_out as frame rows) x W_out; token 0 gets none
+    hipLaunchKernelGGL(k_frames_f16, dim3((frames + 31) / 32, e->kin_pad / 32, batch), dim3(256), 0, st, d_out, F, frames, e->kin_pad, e->xt,
+                       (const float*)w_.gscale);
+    hipLaunchKernelGGL(k_zero_token0, dim3((batch * MST_D + 255) / 256), dim3(256), 0, st, w_.g1, S, batch);
+    HIPCHECK(hipGetLastError());
+    {
+        DEpiFramesGrad epi{w_.g1, frames, S, tot};
+        CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1>(dim3((tot + 63) / 64, 1), RowsDirect{e->xt, e->kin_pad}, e->w_pose_outT, e->kin_pad,
+                                                   e->kin_pad, epi, st)));
+    }
+    CHECK(train_stack_backward(e, t, batch, S, p_drop, seed, nullptr, grads, st));
+    if (d_x) {
+        if (p_pe > 0.f) {
+            hipLaunchKernelGGL(k_mask_f32, dim3(1024), dim3(256), 0, st, w_.g1, n, pe_drop(seed, p_pe));
+            HIPCHECK(hipGetLastError());
+        }
+        // pose embedding backward: d x[b][f][t] = sum_k W_in[k][f] g[b, 1 + t, k]  == the output-projection kernel with W_in^T
+        hipLaunchKernelGGL(k_f32_to_f16, dim3(1024), dim3(256), 0, st, w_.g1, n, w_.datt);
+        HIPCHECK(hipGetLastError());
+        WS ws = ws_slice(e, 0, frames);
+        ws.hx = w_.datt;
+        StepArgs sa{};
+        CHECK(launch_out_nt<0>(e, ws, 0, batch, frames, d_x, sa, st, e->w_pose_inT, w_.zeros));
+        hipLaunchKernelGGL(k_scale_f32, dim3(1024), dim3(256), 0, st, d_x, n_out, w_.gscale, 1, d_x);
         HIPCHECK(hipGetLastError());
     }
     return 0;

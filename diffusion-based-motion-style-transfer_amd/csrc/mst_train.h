@@ -350,6 +350,72 @@ __global__ __launch_bounds__(256) void k_ln_rows_train(const float* __restrict__
     *reinterpret_cast<uint2*>(y_lo + off + fb) = l;
 }
 
+// Model-level training node (input / output projections inside the native graph): positional-encoding dropout on the
+// assembled token stream (PositionalEncoding.dropout, mdm_forstyledataset.py:404), its backward on the fp32 gradient, a
+// plain f32 -> f16 copy, and the epilogue that scatters frame-row gradients back into token rows.
+__global__ void k_dropout_stream(f16* __restrict__ hi, f16* __restrict__ lo, size_t n, Drop d) {
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
+        f32x4 v = join4_f16(*reinterpret_cast<const uint2*>(hi + i), *reinterpret_cast<const uint2*>(lo + i));
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] *= drop_mul(d, (uint32_t)(i + j));
+        uint2 h, l;
+        split4_f16(v, h, l);
+        *reinterpret_cast<uint2*>(hi + i) = h;
+        *reinterpret_cast<uint2*>(lo + i) = l;
+    }
+}
+__global__ void k_mask_f32(float* __restrict__ g, size_t n, Drop d) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) g[i] *= drop_mul(d, (uint32_t)i);
+}
+__global__ void k_f32_to_f16(const float* __restrict__ in, size_t n, f16* __restrict__ out) {
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(in + i);
+        *reinterpret_cast<uint2*>(out + i) = pack4_f16(v[0], v[1], v[2], v[3]);
+    }
+}
+// backward of the output projection: frame rows x W_out -> gradient of the token stream, fp32 row clip*S + 1 + t
+// (the conditioning token's row is zeroed by the caller); 64 x 512 tile, whole rows, like DEpiEmbedIn.
+struct DEpiFramesGrad {
+    float* out; int T, S, total;
+    __device__ __forceinline__ int rows() const { return total; }
+    template <int BT, int BF> static constexpr int smem_bytes() { return BT * (MST_D * 4 + 16); }
+    template <int BT, int BF, int MT, int NT>
+    __device__ __forceinline__ void run(f32x16 (&acc)[1][MT][NT], int tok0, int f0, char* smem) const {
+        static_assert(BF == MST_D, "whole rows");
+        constexpr int LD = MST_D * 4 + 16;
+        DLane<BT, BF, MT, NT> lc;
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            char* trow = smem + lc.tok(m) * LD;
+#pragma unroll
+            for (int n = 0; n < NT; n++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    f32x4 v = {acc[0][m][n][4 * g], acc[0][m][n][4 * g + 1], acc[0][m][n][4 * g + 2], acc[0][m][n][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(trow + lc.feat(n, g) * 4) = v;
+                }
+        }
+        __syncthreads();
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int fa = lane * 4, fb = 256 + lane * 4;
+        constexpr int RPW = BT / 8;
+#pragma unroll
+        for (int r = 0; r < RPW; r++) {
+            const int row = wave * RPW + r, tok = tok0 + row;
+            if (tok >= total) continue;
+            const int clip = tok / T, t = tok - clip * T;
+            const size_t off = ((size_t)clip * S + 1 + t) * MST_D;
+            *reinterpret_cast<f32x4*>(out + off + fa) = *reinterpret_cast<const f32x4*>(smem + row * LD + fa * 4);
+            *reinterpret_cast<f32x4*>(out + off + fb) = *reinterpret_cast<const f32x4*>(smem + row * LD + fb * 4);
+        }
+    }
+};
+// zero the conditioning token's row of every clip in an fp32 [rows][S][512] buffer
+__global__ void k_zero_token0(float* __restrict__ g, int S, int rows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows * MST_D) g[(size_t)(i / MST_D) * S * MST_D + (i % MST_D)] = 0.f;
+}
+
 // fp32 rows -> hi/lo pair
 __global__ void k_split_stream(const float* __restrict__ in, size_t n, f16* __restrict__ hi, f16* __restrict__ lo) {
     for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
@@ -515,13 +581,13 @@ __global__ __launch_bounds__(256) void k_transpose_f16(const f16* __restrict__ i
 }
 
 // [N][K] float32 -> [K][N] f16 (transposed weight copies: the "weights" operand of the dgrad GEMMs)
-__global__ void k_convert_transpose(const float* __restrict__ src, int N, int K, f16* __restrict__ dst) {
+__global__ void k_convert_transpose(const float* __restrict__ src, int N, int K, f16* __restrict__ dst, int ldd) {
     __shared__ float tile[32][33];
     const int n0 = blockIdx.y * 32, k0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int j = ty; j < 32; j += 8) tile[j][tx] = (n0 + j < N && k0 + tx < K) ? src[(size_t)(n0 + j) * K + k0 + tx] : 0.f;
     __syncthreads();
     for (int j = ty; j < 32; j += 8)
-        if (k0 + j < K && n0 + tx < N) dst[(size_t)(k0 + j) * N + n0 + tx] = (f16)tile[tx][j];
+        if (k0 + j < K && n0 + tx < N) dst[(size_t)(k0 + j) * ldd + n0 + tx] = (f16)tile[tx][j];
 }
 
 // debug / tests: the keep-multiplier of `n` consecutive elements of a site

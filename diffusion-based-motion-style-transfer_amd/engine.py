@@ -211,6 +211,31 @@ class DenoiserEngine:
                                            N.ptr(kk), N.ptr(d_in), arr, N.stream_ptr(self.device)))
         return d_in
 
+    def train_model_forward(self, x, t, p_drop, p_pe, seed):
+        """Whole denoiser in train mode: x [B, F, 1, T], t int64 [B] -> (model output [B, F, 1, T], tape).  set_text first."""
+        x = _f32c(x, self.device, "x")
+        B, F, one, T = x.shape
+        assert F * one == self.feats, (F, one, self.feats)
+        t = t.to(device=self.device, dtype=torch.int64).contiguous()
+        tape = self.train_tape(B, T + 1)
+        out = torch.empty_like(x)
+        N.check(N.lib().mst_train_model_forward(self.handle, N.ptr(x), N.ptr(t), B, T, float(p_drop), float(p_pe), int(seed),
+                                                N.ptr(tape), N.ptr(out), N.stream_ptr(self.device)))
+        return out, tape
+
+    def train_model_backward(self, tape, d_out, p_drop, p_pe, seed, grads, need_input_grad=True):
+        d_out = _f32c(d_out, self.device, "d_out")
+        B, F, one, T = d_out.shape
+        arr = None
+        if grads is not None:
+            if len(grads) != self.num_layers * 12:
+                raise ValueError(f"expected {self.num_layers * 12} gradient buffers, got {len(grads)}")
+            arr = (C.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
+        d_x = torch.empty_like(d_out) if need_input_grad else None
+        N.check(N.lib().mst_train_model_backward(self.handle, N.ptr(tape), N.ptr(d_out), B, T, float(p_drop), float(p_pe), int(seed),
+                                                 N.ptr(d_x), arr, N.stream_ptr(self.device)))
+        return d_x
+
     def dropout_mask(self, seed, layer, site, p, n):
         out = torch.empty(n, dtype=torch.float32, device=self.device)
         N.check(N.lib().mst_dropout_mask(int(seed), layer, site, float(p), n, N.ptr(out), N.stream_ptr(self.device)))

@@ -173,6 +173,20 @@ class _EngineHost:
         p = self.seqTransEncoder.layers[0].dropout.p if self.seqTransEncoder.training else 0.0
         return EncoderStackFn.apply(seq, self, float(p), key_keep, *stack_parameters(self.seqTransEncoder))
 
+    def _native_train_call(self, x, timesteps, y):
+        """model(x, t, y) inside an autograd graph as ONE native node (DenoiserTrainFn); None when this module cannot use it
+        (CPU tensors, train_backend 'torch', no text conditioning) and the caller should assemble the graph from torch ops."""
+        if self.train_backend != "native" or not x.is_cuda or 'text' not in getattr(self, "cond_mode", ""):
+            return None
+        from .native_stack import DenoiserTrainFn, stack_parameters
+        prior = self._prior()
+        enc = y['text_embed'] if y.get('text_embed') is not None else prior.encode_text(y['text'])
+        enc = self.mask_cond(enc, force_mask=y.get('uncond', False))
+        stack, pe = self.seqTransEncoder, prior.sequence_pos_encoder
+        p = stack.layers[0].dropout.p if stack.training else 0.0
+        p_pe = pe.dropout.p if pe.training else 0.0
+        return DenoiserTrainFn.apply(x, self, float(p), float(p_pe), timesteps, enc, *stack_parameters(stack))
+
     def _wants_autograd(self, x):
         return torch.is_grad_enabled() and (self.training or x.requires_grad
                                             or any(p.requires_grad for p in self.parameters()))
@@ -266,6 +280,9 @@ class MDM(nn.Module, _EngineHost):
     def forward(self, x, timesteps, y=None):
         if not self._wants_autograd(x):
             return self._native_forward(x, timesteps, y)
+        out = self._native_train_call(x, timesteps, y)
+        if out is not None:
+            return out
         emb = self._condition(timesteps, y)
         seq = self.sequence_pos_encoder(torch.cat((emb, self.input_process(x)), axis=0))
         return self.output_process(self._encoder_stack(seq)[1:])
@@ -418,6 +435,9 @@ class StyleDiffusion(nn.Module, _EngineHost):
     def forward(self, x, timesteps, y=None):
         if not self._wants_autograd(x):
             return self._native_forward(x, timesteps, y)
+        out = self._native_train_call(x, timesteps, y)
+        if out is not None:
+            return out
         prior = self._prior()
         emb = prior.embed_timestep(timesteps)
         enc = y['text_embed'] if y.get('text_embed') is not None else prior.encode_text(y['text'])

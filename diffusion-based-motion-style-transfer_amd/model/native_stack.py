@@ -71,14 +71,55 @@ class GradSink:
             ready()
 
 
+def _draw_seed(p):
+    """One 62-bit seed per call from torch's CPU generator: torch.manual_seed reproduces the dropout masks."""
+    return int(torch.randint(0, 2 ** 62, (1,), device="cpu").item()) if p > 0 else 0
+
+
+def _sink_views(ctx, params_need_grad, device):
+    """The flat gradient accumulator of this backward pass (None when no stack parameter needs a gradient)."""
+    if not params_need_grad:
+        return None
+    sink = ctx.host.__dict__.get("_mst_grad_sink")
+    if sink is None or sink.ids != tuple(id(p) for p in ctx.params):
+        sink = ctx.host.__dict__["_mst_grad_sink"] = GradSink(ctx.host, list(ctx.params))
+    if not sink.active:
+        sink.begin(device)
+    return sink.views
+
+
+class DenoiserTrainFn(torch.autograd.Function):
+    """The WHOLE denoiser call as one node: conditioning token, pose embedding, positional-encoding dropout, the trainable
+    stack and the output projection (mst_train_model_forward / _backward).  Used when the module conditions on text (every
+    shipped script); gradients: dL/dx and the 96 stack tensors -- projections, timestep MLP and text projection are frozen."""
+
+    @staticmethod
+    def forward(ctx, x, host, p_drop, p_pe, timesteps, text_emb, *params):
+        B, F, one, T = x.shape
+        eng = host.mst_engine(B, T)
+        eng.set_text(text_emb.detach())
+        seed = _draw_seed(max(p_drop, p_pe))
+        out, tape = eng.train_model_forward(x.detach(), timesteps, p_drop, p_pe, seed)
+        ctx.eng, ctx.tape, ctx.p_drop, ctx.p_pe, ctx.seed, ctx.host, ctx.params = eng, tape, p_drop, p_pe, seed, host, params
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        need_in = ctx.needs_input_grad[0]
+        views = _sink_views(ctx, any(ctx.needs_input_grad[6:]), grad_out.device)
+        d_x = ctx.eng.train_model_backward(ctx.tape, grad_out.contiguous(), ctx.p_drop, ctx.p_pe, ctx.seed, views,
+                                           need_input_grad=need_in)
+        ctx.tape = None
+        return (d_x, None, None, None, None, None) + (None,) * len(ctx.params)
+
+
 class EncoderStackFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, seq, host, p_drop, key_keep, *params):
         """key_keep: None or bool [B, S], False = padding key (the motion encoder's ~src_key_padding_mask)."""
         S, B, d = seq.shape
         eng = host.mst_engine(B, S - 1)
-        # one 62-bit seed per call from torch's generator: torch.manual_seed reproduces the masks
-        seed = int(torch.randint(0, 2 ** 62, (1,), device="cpu").item()) if p_drop > 0 else 0
+        seed = _draw_seed(p_drop)
         h = seq.detach().permute(1, 0, 2).contiguous()
         if key_keep is not None:
             key_keep = key_keep.to(torch.uint8).contiguous()
@@ -90,14 +131,7 @@ class EncoderStackFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         need_in = ctx.needs_input_grad[0]
-        views = None
-        if any(ctx.needs_input_grad[4:]):
-            sink = ctx.host.__dict__.get("_mst_grad_sink")
-            if sink is None or sink.ids != tuple(id(p) for p in ctx.params):
-                sink = ctx.host.__dict__["_mst_grad_sink"] = GradSink(ctx.host, list(ctx.params))
-            if not sink.active:
-                sink.begin(grad_out.device)
-            views = sink.views
+        views = _sink_views(ctx, any(ctx.needs_input_grad[4:]), grad_out.device)
         d_out = grad_out.permute(1, 0, 2).contiguous()
         d_in = ctx.eng.train_backward(ctx.tape, d_out, ctx.p_drop, ctx.seed, views, need_input_grad=need_in, key_keep=ctx.keep)
         ctx.tape = None

@@ -214,6 +214,18 @@ int mst_train_forward(mst_engine* e, const float* h_in_dev, int32_t rows, int32_
 int mst_train_backward(mst_engine* e, const void* tape_dev, const float* d_out_dev, int32_t rows,
                        int32_t S, float p_drop, uint64_t seed, const uint8_t* key_keep_dev,
                        float* d_in_dev, float* const* grads_host_array, void* stream);
+/* The whole denoiser as one training node: StyleDiffusion.forward / MDM.forward in train mode
+ * (model/mdm_forstyledataset.py:602-625, :315-364): conditioning token (timestep MLP + text projection, text set with
+ * mst_set_text as for mst_forward), pose embedding + positional rows, PositionalEncoding's dropout p_pe (:404) on the
+ * assembled sequence, the trainable stack (p_drop), output projection.  Backward returns dL/dx and accumulates the 96
+ * stack gradients (the projections, the timestep MLP and the text projection are frozen in every shipped script).
+ * x, out, d_out, d_x: float32 [batch][feats][1][frames]; t_idx: int64 [batch] original-process timesteps. */
+int mst_train_model_forward(mst_engine* e, const float* x_dev, const int64_t* t_idx_dev, int32_t batch,
+                            int32_t frames, float p_drop, float p_pe, uint64_t seed, void* tape_dev,
+                            float* out_dev, void* stream);
+int mst_train_model_backward(mst_engine* e, const void* tape_dev, const float* d_out_dev, int32_t batch,
+                             int32_t frames, float p_drop, float p_pe, uint64_t seed, float* d_x_dev,
+                             float* const* grads_host_array, void* stream);
 int mst_dropout_mask(uint64_t seed, int32_t layer, int32_t site, float p, uint64_t n, float* out_dev,
                      void* stream);
 
