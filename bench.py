@@ -148,7 +148,7 @@ def main():
         flops_per_clip = 7.353e9 * NS * (2 if args.cfg else 1)
         traffic, traffic_src = pmc_traffic(dom, rows)
         line = {
-            "metric": "denoised motion clips/sec (1000-step DDPM, Bx263x196)",
+            "metric": f"denoised motion clips/sec ({NS}-step DDPM, Bx263x196)",
             "value": round(value, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16 MFMA operands, fp32 accumulate/stream", "data": "synthetic",
