@@ -76,6 +76,14 @@ def _draw_seed(p):
     return int(torch.randint(0, 2 ** 62, (1,), device="cpu").item()) if p > 0 else 0
 
 
+def _take_tape(ctx):
+    if ctx.tape is None:
+        raise RuntimeError("backward through a native training node a second time: its activation tape is released by the "
+                           "first backward (retain_graph / double backward are not supported)")
+    tape, ctx.tape = ctx.tape, None
+    return tape
+
+
 def _sink_views(ctx, params_need_grad, device):
     """The flat gradient accumulator of this backward pass (None when no stack parameter needs a gradient)."""
     if not params_need_grad:
@@ -107,9 +115,8 @@ class DenoiserTrainFn(torch.autograd.Function):
     def backward(ctx, grad_out):
         need_in = ctx.needs_input_grad[0]
         views = _sink_views(ctx, any(ctx.needs_input_grad[6:]), grad_out.device)
-        d_x = ctx.eng.train_model_backward(ctx.tape, grad_out.contiguous(), ctx.p_drop, ctx.p_pe, ctx.seed, views,
+        d_x = ctx.eng.train_model_backward(_take_tape(ctx), grad_out.contiguous(), ctx.p_drop, ctx.p_pe, ctx.seed, views,
                                            need_input_grad=need_in)
-        ctx.tape = None
         return (d_x, None, None, None, None, None) + (None,) * len(ctx.params)
 
 
@@ -133,7 +140,6 @@ class EncoderStackFn(torch.autograd.Function):
         need_in = ctx.needs_input_grad[0]
         views = _sink_views(ctx, any(ctx.needs_input_grad[4:]), grad_out.device)
         d_out = grad_out.permute(1, 0, 2).contiguous()
-        d_in = ctx.eng.train_backward(ctx.tape, d_out, ctx.p_drop, ctx.seed, views, need_input_grad=need_in, key_keep=ctx.keep)
-        ctx.tape = None
+        d_in = ctx.eng.train_backward(_take_tape(ctx), d_out, ctx.p_drop, ctx.seed, views, need_input_grad=need_in, key_keep=ctx.keep)
         gi = d_in.permute(1, 0, 2).contiguous() if need_in else None
         return (gi, None, None, None) + (None,) * len(ctx.params)

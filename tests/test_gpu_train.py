@@ -376,3 +376,12 @@ def test_train_key_padding_mask_engine_level():
         assert rel_l2(grads[i].cpu().numpy(), ref_g[f"layers.0.{k}"].grad.cpu().numpy()) <= 2 * TOL_GRAD, k
     with pytest.raises(ValueError, match="key_keep must be"):
         eng.train_forward(h, 0.0, 0, key_keep=keep[:, :10])
+
+
+def test_second_backward_is_refused():
+    m = _style_model().eval()
+    x, t, y, tgt = _model_batch()
+    loss = ((m(x, t, y=y) - tgt) ** 2).mean()
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="a second time"):
+        loss.backward()
