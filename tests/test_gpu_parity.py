@@ -351,6 +351,34 @@ def test_loop_tail_vs_golden_hml(golden):
     assert np.array_equal(out[:, :3], motion[:, :3])
 
 
+def test_full_length_loop_vs_oracle():
+    """The headline configuration's LENGTH: all 1000 DDPM steps (no respacing) of one (181,1,76) clip with recorded noise,
+    the engine's fused loop against the CPU oracle stepping the same 1000 indices (10-20 s of CPU): rounding does not
+    accumulate over a full-length trajectory (x0-prediction contracts it), and the inpainted rows stay exact."""
+    from mst_amd.engine import Schedule, SAMPLER_DDPM
+    from oracle import denoiser, diffusion, schedule
+    eng, w = engine_for("xia")
+    F, T, x, t, txt = inputs("xia")
+    shape = (1, F, 1, T)
+    pe = syn.positional_table(5000, 512)
+    mask = syn.root_horizontal_mask(1, F, T)
+    motion = syn.normal(SEED, "xia/motion", (2, F, 1, T))[:1]
+    tab, tmap = schedule.make("cosine", 1000, "")
+    rng = np.random.default_rng(SEED)
+    nz = rng.standard_normal((1001,) + shape, dtype=np.float32)
+    torch.set_num_threads(16)
+    ref = diffusion.sample_loop(lambda xx, tt: denoiser.forward(w, pe, xx, tt, txt[:1]), tab, tmap, shape, lambda k: torch.from_numpy(nz[k]),
+                                "ddpm", True, torch.from_numpy(mask), torch.from_numpy(motion))
+    ref = (ref["sample"] if isinstance(ref, dict) else ref).numpy()
+    eng.set_text(cu(txt[:1]))
+    sch = Schedule(tab, tmap, _dev())
+    out = eng.sample_loop(sch, cu(nz[0]).clone(), 999, 0, SAMPLER_DDPM, mask=cu(mask), motion=cu(motion), noise=cu(nz[1:])).cpu().numpy()
+    e = rel_l2(out, ref)
+    print("1000-step loop", e)
+    assert e < TOL, e
+    assert np.array_equal(out[:, :3], motion[:, :3])
+
+
 # ------------------------------------------------------------------------------ properties at the bench size
 def test_full_size_properties(tile_path):
     """BASELINE.json configs[1] size (batch 64, 263 x 196): size-independent properties -- clips are
