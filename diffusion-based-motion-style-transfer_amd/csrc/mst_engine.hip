@@ -140,6 +140,9 @@ struct mst_engine {
     int small_m = 2048;                   // launches of at most this many token rows take the small-tile path (MST_SMALL_M, 0 = never);
                                           // tools/small_m_sweep.sh: 8 clips (1576 rows) 722 -> 417 us/step, 11-clip slices (2167 rows) 766 vs 796
     float* zacc = nullptr;                // fp32 GEMM result feeding k_ln_rows on that path
+    int ln128_min_m = 1 << 30;            // MST_LN128_M=n: launches of >= n token rows use 128-token LayerNorm tiles (half the weight
+                                          // re-streaming).  Off by default: wins 16-21 % in gemm_bench, nothing in the pipeline (CFG 39.7 vs
+                                          // 39.9, batch 128 77.2 vs 77.1 clips/s; forced at batch 64: 58.7 vs 68.3) -- kept, parity-tested
     int wgrad_stream_on = 1;              // training: wgrads on a second stream beside the dgrad chain (MST_WGRAD_STREAM=0: one stream)
     int nsplit = 3;                       // sampling loops run the batch as this many independent slices on separate streams (same-box A/B: 2: 61.2, 3: 63.0, 4: 61.1 clips/s)
     static constexpr int MAX_SLICES = 4;
@@ -262,6 +265,7 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     if (const char* v = getenv("MST_FUSE_QKV_ATTN")) e->fuse_qkv_attn = atoi(v) != 0;
     if (const char* v = getenv("MST_WGRAD_STREAM")) e->wgrad_stream_on = atoi(v) != 0;
     if (const char* v = getenv("MST_SMALL_M")) e->small_m = atoi(v);
+    if (const char* v = getenv("MST_LN128_M")) e->ln128_min_m = atoi(v);
     CHECK(dmalloc(&e->zacc, (size_t)e->M_pad * MST_D));
     *out = e;
     return 0;
@@ -675,7 +679,10 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
         {
             ProfScope ps(e, FAM_OUTPROJ_LN, st);
             DEpiResidLN epi{w.b_out, w.g1, w.be1, ws.hx, ws.hl, M};
-            CHECK((launch_gemm_dma<64, 512, 2, 2, LN_NS, 1, LN_BK>(dim3((M + 63) / 64, 1), RowsDirect{ws.att, MST_D}, w.w_out, MST_D, ABL_K(MST_D), epi, st)));
+            if (M >= e->ln128_min_m)
+                CHECK((launch_gemm_dma<128, 512, 2, 4, 2, 1, 64>(dim3((M + 127) / 128, 1), RowsDirect{ws.att, MST_D}, w.w_out, MST_D, ABL_K(MST_D), epi, st)));
+            else
+                CHECK((launch_gemm_dma<64, 512, 2, 2, LN_NS, 1, LN_BK>(dim3((M + 63) / 64, 1), RowsDirect{ws.att, MST_D}, w.w_out, MST_D, ABL_K(MST_D), epi, st)));
         }
         DBG_STOP(3)
         {
@@ -692,7 +699,10 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
         {
             ProfScope ps(e, FAM_FFN2_LN, st);
             DEpiResidLN epi{w.b2, w.g2, w.be2, ws.hx, ws.hl, M};
-            CHECK((launch_gemm_dma<64, 512, 2, 2, LN_NS, 1, LN_BK>(dim3((M + 63) / 64, 1), RowsDirect{ws.hid, MST_FF}, w.w2, MST_FF, ABL_K(MST_FF), epi, st)));
+            if (M >= e->ln128_min_m)
+                CHECK((launch_gemm_dma<128, 512, 2, 4, 2, 1, 64>(dim3((M + 127) / 128, 1), RowsDirect{ws.hid, MST_FF}, w.w2, MST_FF, ABL_K(MST_FF), epi, st)));
+            else
+                CHECK((launch_gemm_dma<64, 512, 2, 2, LN_NS, 1, LN_BK>(dim3((M + 63) / 64, 1), RowsDirect{ws.hid, MST_FF}, w.w2, MST_FF, ABL_K(MST_FF), epi, st)));
         }
         DBG_STOP(5)
     }

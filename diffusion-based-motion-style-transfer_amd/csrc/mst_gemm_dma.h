@@ -312,7 +312,7 @@ struct DEpiResidLN {
     const float* bias; const float* gamma; const float* beta;
     f16* hi; f16* lo; int M;                 // the stream (read as residual, rewritten in place): hi + lo pair
     __device__ __forceinline__ int rows() const { return M; }
-    template <int BT, int BF> static constexpr int smem_bytes() { return BT * (MST_D * 4 + 16); }
+    template <int BT, int BF> static constexpr int smem_bytes() { return 64 * (MST_D * 4 + 16); }     // 64 rows per pass
     template <int BT, int BF, int MT, int NT>
     __device__ __forceinline__ void run(f32x16 (&acc)[1][MT][NT], int tok0, int f0, char* smem) const {
         static_assert(BF == MST_D, "LayerNorm needs the whole row in one block");
@@ -325,10 +325,18 @@ struct DEpiResidLN {
         }
 #endif
         constexpr int LD = MST_D * 4 + 16;                    // 2064-B rows: conflict-free b128 writes and reads
+        constexpr int PR = 64, PASSES = BT / PR;              // 128-token tiles (large launches) go through LDS in two halves
         DLane<BT, BF, MT, NT> lc;
+        const int tok0_tile = tok0;
+#pragma unroll
+        for (int pass = 0; pass < PASSES; pass++) {
+        if (pass > 0) __syncthreads();                        // previous half consumed
+        tok0 = tok0_tile + pass * PR;
 #pragma unroll
         for (int m = 0; m < MT; m++) {
-            char* trow = smem + lc.tok(m) * LD;
+            const int tl = lc.tok(m);
+            if (tl / PR != pass) continue;                    // wave-uniform
+            char* trow = smem + (tl - pass * PR) * LD;
 #pragma unroll
             for (int n = 0; n < NT; n++)
 #pragma unroll
@@ -342,12 +350,15 @@ struct DEpiResidLN {
         // lane owns features [4*lane, 4*lane+4) and [256 + 4*lane, ...): two 1-KiB accesses per row
         const int fa = lane * 4, fb = 256 + lane * 4;
         const f32x4 ba = *reinterpret_cast<const f32x4*>(bias + fa), bb = *reinterpret_cast<const f32x4*>(bias + fb);
-        constexpr int RPW = BT / 8;                           // rows per wave
+        constexpr int RPW = PASSES > 1 ? 4 : 8;               // rows a wave handles at once (8 per pass; 128-row tiles keep 128
+                                                              // accumulator registers live across the passes, so they go 4 + 4)
+        for (int chunk = 0; chunk < (PR / 8) / RPW; chunk++) {
+        const int row0 = wave * (PR / 8) + chunk * RPW;
         // all residual loads in flight first (they overlap the LDS reads below)
         f32x4 xa[RPW], xb[RPW];
 #pragma unroll
         for (int r = 0; r < RPW; r++) {
-            int tok = tok0 + wave * RPW + r;
+            int tok = tok0 + row0 + r;
             size_t off = (size_t)(tok < M ? tok : 0) * MST_D;
             xa[r] = join4_f16(*reinterpret_cast<const uint2*>(hi + off + fa), *reinterpret_cast<const uint2*>(lo + off + fa));
             xb[r] = join4_f16(*reinterpret_cast<const uint2*>(hi + off + fb), *reinterpret_cast<const uint2*>(lo + off + fb));
@@ -357,7 +368,7 @@ struct DEpiResidLN {
         float s[RPW], s2[RPW];
 #pragma unroll
         for (int r = 0; r < RPW; r++) {
-            const int row = wave * RPW + r;
+            const int row = row0 + r;
             const f32x4 ta = *reinterpret_cast<const f32x4*>(smem + row * LD + fa * 4);
             const f32x4 tb = *reinterpret_cast<const f32x4*>(smem + row * LD + fb * 4);
             s[r] = 0.f;
@@ -391,7 +402,7 @@ struct DEpiResidLN {
         const f32x4 ea = *reinterpret_cast<const f32x4*>(beta + fa), eb = *reinterpret_cast<const f32x4*>(beta + fb);
 #pragma unroll
         for (int r = 0; r < RPW; r++) {
-            const int tok = tok0 + wave * RPW + r;
+            const int tok = tok0 + row0 + r;
             if (tok >= M) continue;
             const float rstd = 1.0f / sqrtf(s2[r] * (1.0f / MST_D) + 1e-5f);
             f32x4 ya, yb;
@@ -409,6 +420,8 @@ struct DEpiResidLN {
             *reinterpret_cast<uint2*>(hi + off + fb) = h;
             *reinterpret_cast<uint2*>(lo + off + fb) = l;
         }
+        }   // chunk
+        }   // pass
     }
 };
 

@@ -65,5 +65,6 @@ int main() {
     CASEK(128, 256, 2, 2, 2, 64)
     CASEK(128, 256, 2, 2, 3, 64)
     CASEK(256, 256, 4, 2, 2, 64)
+    CASEK(128, 512, 2, 4, 2, 64)
     return 0;
 }

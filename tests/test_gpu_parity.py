@@ -29,18 +29,22 @@ def _dev():
 _ENGINES = {}
 
 
-@pytest.fixture(autouse=True, params=["1024", "0"], ids=["small-tiles", "large-tiles"])
+@pytest.fixture(autouse=True, params=["default", "0", "ln128"], ids=["small-tiles", "large-tiles", "large-tiles-ln128"])
 def tile_path(request, monkeypatch):
-    """Every test of this module runs twice: launches of <= 1024 token rows (all the golden comparisons, at 2 clips) take
-    the small-tile path by default; MST_SMALL_M=0 sends the same inputs through the large-batch kernels."""
-    monkeypatch.setenv("MST_SMALL_M", request.param)
+    """Every test of this module runs three times: launches of a few clips (all the golden comparisons) take the small-tile
+    path by default; MST_SMALL_M=0 sends the same inputs through the batch-64 kernels; MST_LN128_M=1 additionally through the
+    optional 128-token LayerNorm tiles (off by default: no gain in the pipeline)."""
+    if request.param != "default":
+        monkeypatch.setenv("MST_SMALL_M", "0")
+    if request.param == "ln128":
+        monkeypatch.setenv("MST_LN128_M", "1")
     return request.param
 
 
 def engine_for(tag, prior=False, max_rows=4):
     import os
     from mst_amd.engine import DenoiserEngine
-    key = (tag, prior, max_rows, os.environ.get("MST_SMALL_M"))
+    key = (tag, prior, max_rows, os.environ.get("MST_SMALL_M"), os.environ.get("MST_LN128_M"))
     if key not in _ENGINES:
         F, T = SHAPES[tag]
         eng = DenoiserEngine(F, T, max_rows, device=_dev())
