@@ -34,6 +34,7 @@ class MstLoopArgs(C.Structure):
 SIGNATURES = {
     "mst_last_error": (C.c_char_p, []),
     "mst_version": (C.c_int, []),
+    "mst_source_hash": (C.c_char_p, []),
     "mst_engine_create": (C.c_int, [C.POINTER(MstConfig), C.POINTER(C.c_void_p)]),
     "mst_engine_destroy": (None, [C.c_void_p]),
     "mst_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_void_p]),
@@ -64,7 +65,7 @@ SIGNATURES = {
     "mst_adamw_workspace_bytes": (C.c_int64, [C.c_int32, C.POINTER(C.c_int64)]),
     "mst_adamw_step": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                  C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_float, C.c_float, C.c_float, C.c_float,
-                                 C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+                                 C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "mst_recover_from_ric": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_void_p, C.c_void_p]),
     "mst_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
@@ -75,12 +76,44 @@ SIGNATURES = {
 }
 
 
+def source_files():
+    """Everything the library is compiled from: csrc/*.hip, csrc/*.h and the public header."""
+    import glob
+    csrc = os.path.join(_HERE, "csrc")
+    return sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))) + \
+        [os.path.join(os.path.dirname(_HERE), "include", "mst_engine.h")]
+
+
+def source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for f in source_files():
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def built_hash():
+    """Source hash the in-tree library was built from (side file written by the build), or None."""
+    try:
+        with open(LIB_PATH + ".srchash") as fh:
+            return fh.read().strip()
+    except OSError:
+        return None
+
+
+def is_stale():
+    return not os.path.exists(LIB_PATH) or built_hash() != source_hash()
+
+
 def lib():
     """The loaded library; raises RuntimeError (never falls back) when it cannot be loaded."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH) and "MST_ENGINE_LIB" not in os.environ:
-            _build_in_place()
+        custom = "MST_ENGINE_LIB" in os.environ
+        if not custom and is_stale():          # fresh checkout (the .so is git-ignored) or a kernel source edited since the build
+            build_in_place()
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`. "
@@ -90,24 +123,36 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
+        if not custom and l.mst_source_hash().decode() != source_hash():
+            raise RuntimeError(f"{LIB_PATH} was built from other sources than the ones in csrc/ (hipcc missing or the build "
+                               "failed?): rebuild it with `python -c 'import __graft_entry__ as g; g.build(force=True)'`")
         _lib = l
     return _lib
 
 
-def _build_in_place():
-    """Fresh checkout (the .so is git-ignored): compile the library with hipcc where it belongs.
-    Same command as __graft_entry__.build(); failures surface as the 'missing' error above."""
+def build_in_place(check=False):
+    """Compile the library with hipcc where it belongs (the one build recipe: __graft_entry__.build() calls this too).
+    The source hash is compiled in (mst_source_hash) and written beside the .so, so a library that is older than an edit
+    of ANY csrc/ file is rebuilt instead of silently used."""
     import shutil
     import subprocess
     hipcc = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
+        if check:
+            raise RuntimeError("hipcc not found")
         return
+    h = source_hash()
     try:
-        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH,
-                        "mst_engine.hip"], cwd=os.path.join(_HERE, "csrc"), check=True)
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", f'-DMST_SRC_HASH="{h}"',
+                        "-o", LIB_PATH, "mst_engine.hip"], cwd=os.path.join(_HERE, "csrc"), check=True)
+        with open(LIB_PATH + ".srchash", "w") as fh:
+            fh.write(h + "\n")
     except (subprocess.CalledProcessError, OSError):
-        if os.path.exists(LIB_PATH):
-            os.remove(LIB_PATH)
+        for f in (LIB_PATH, LIB_PATH + ".srchash"):
+            if os.path.exists(f):
+                os.remove(f)
+        if check:
+            raise
 
 
 def check(rc):

@@ -6,7 +6,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <map>
+#include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -80,7 +81,45 @@ static int fail(const char* fmt, ...) {
     } while (0)
 
 extern "C" const char* mst_last_error(void) { return g_err; }
-extern "C" int mst_version(void) { return 1; }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE opt-in: remember (kernel, device) pairs, so a second
+// engine on another GPU of the same process gets its own (a process-wide "done" flag would launch there without it).
+static int ensure_dyn_lds(const void* kern, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    HIPCHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({kern, dev})) return 0;
+    HIPCHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.insert({kern, dev});
+    return 0;
+}
+
+// Every ABI entry runs on its engine's / schedule's device and leaves the caller's current device as it found it.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) cur = -1;
+        if (cur != dev) {
+            ok = hipSetDevice(dev) == hipSuccess;
+            prev = cur;
+        }
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define ON_DEVICE(dev)                                                    \
+    DeviceGuard _dev_guard(dev);                                          \
+    if (!_dev_guard.ok) return fail("hipSetDevice(%d) failed (%s:%d)", (int)(dev), __FILE__, __LINE__)
+extern "C" int mst_version(void) { return 2; }
+#ifndef MST_SRC_HASH
+#define MST_SRC_HASH "unhashed"
+#endif
+extern "C" const char* mst_source_hash(void) { return MST_SRC_HASH; }
 
 // ------------------------------------------------------------------------------------------ state
 struct mst_schedule {
@@ -167,7 +206,7 @@ static int dmalloc(T** p, size_t count) {
 extern "C" int mst_schedule_create(int32_t num_steps, const float* tables_host, const int32_t* timestep_map_host,
                                    int32_t device, mst_schedule** out) {
     if (!out || !tables_host || !timestep_map_host || num_steps <= 0) return fail("mst_schedule_create: bad arguments");
-    HIPCHECK(hipSetDevice(device));
+    ON_DEVICE(device);
     mst_schedule* s = new mst_schedule();
     s->n = num_steps;
     s->device = device;
@@ -199,7 +238,7 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     if (c->max_frames < 1 || c->max_frames > 223) return fail("mst_engine_create: max_frames must be 1..223 (got %d)", c->max_frames);
     if (c->max_rows < 1) return fail("mst_engine_create: max_rows must be >= 1");
     if (c->clip_dim < 1 || c->pe_len < c->max_frames + 1) return fail("mst_engine_create: bad clip_dim / pe_len");
-    HIPCHECK(hipSetDevice(c->device));
+    ON_DEVICE(c->device);
     mst_engine* e = new mst_engine();
     e->cfg = *c;
     e->S_max = c->max_frames + 1;
@@ -327,7 +366,7 @@ extern "C" int mst_load_weight(mst_engine* e, const char* name, const float* src
                                void* stream) {
     if (!e || !name || !src || !shape) return fail("mst_load_weight: null argument");
     hipStream_t st = (hipStream_t)stream;
-    HIPCHECK(hipSetDevice(e->cfg.device));
+    ON_DEVICE(e->cfg.device);
     const int F = e->cfg.feats, C = e->cfg.clip_dim;
     std::string n(name);
     int rc = -1;
@@ -462,11 +501,7 @@ static int launch_gemm_dma(dim3 grid, const SRC& xs, const f16* W, int ldw, int 
     static_assert(EPI::template smem_bytes<BT, BF>() <= TL::SMEM, "epilogue tile must fit the ring");
     static_assert(TL::SMEM <= 163840, "ring exceeds the 160 KiB LDS");
     auto kern = k_gemm_dma<BT, BF, MT, NT, NS, NX, SRC, EPI, BK>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TL::SMEM));
-        attr_set = true;
-    }
+    CHECK(ensure_dyn_lds((const void*)kern, TL::SMEM));
     if (K < BK * (NS - 1) || (K % BK)) return fail("gemm: K=%d unsupported by the %d-slot ring", K, NS);
     hipLaunchKernelGGL(kern, grid, dim3(512), TL::SMEM, st, xs, W, ldw, K, xcd_ny, epi);
     HIPCHECK(hipGetLastError());
@@ -496,12 +531,8 @@ static int launch_small(int M, int N, const SRC& xs, const f16* W, int ldw, int 
 template <int NKT>
 static int launch_attn_n(const f16* qkv, f16* out, int S, int rows, hipStream_t st, int qsplit) {
     auto kern = k_attention<NKT>;
-    static bool attr_set = false;
     const int smem = NKT * 32 * 256 * 2;
-    if (!attr_set) {
-        HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
-    }
+    CHECK(ensure_dyn_lds((const void*)kern, smem));
     hipLaunchKernelGGL(kern, dim3(rows * MST_H, qsplit ? NKT : 1), dim3(512), smem, st, qkv, out, S, qsplit);
     HIPCHECK(hipGetLastError());
     return 0;
@@ -510,13 +541,9 @@ static int launch_attn_n(const f16* qkv, f16* out, int S, int rows, hipStream_t 
 template <int NKT>
 static int launch_qkv_attn_n(const f16* hx, const f16* w_in, const float* b_in, f16* out, int S, int rows, hipStream_t st) {
     auto kern = k_qkv_attention<NKT>;
-    static bool attr_set = false;
     constexpr int smem = QATile<NKT>::SMEM;
     static_assert(smem <= 163840, "fused QKV+attention exceeds the 160 KiB LDS");
-    if (!attr_set) {
-        HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
-    }
+    CHECK(ensure_dyn_lds((const void*)kern, smem));
     hipLaunchKernelGGL(kern, dim3(rows * MST_H), dim3(512), smem, st, hx, w_in, b_in, out, S);
     HIPCHECK(hipGetLastError());
     return 0;
@@ -570,7 +597,7 @@ extern "C" int mst_set_text(mst_engine* e, const float* text_emb, const float* k
     int rows = cfg ? 2 * batch : batch;
     if (batch < 1 || rows > e->cfg.max_rows) return fail("mst_set_text: %d rows exceed max_rows %d", rows, e->cfg.max_rows);
     hipStream_t st = (hipStream_t)stream;
-    HIPCHECK(hipSetDevice(e->cfg.device));
+    ON_DEVICE(e->cfg.device);
     CHECK(rowwise_linear(text_emb, e->cfg.clip_dim, nullptr, keep, cfg ? batch : rows, e->w_text, e->b_text, e->cfg.clip_dim,
                          MST_D, 0, e->textproj, batch, rows, st));
     e->text_batch = batch;
@@ -751,7 +778,7 @@ extern "C" int mst_forward(mst_engine* e, const float* x, const int64_t* t, cons
     CHECK(check_ready(e, batch, frames, cfg));
     if (!x || !t || !out || (cfg && !scale)) return fail("mst_forward: null argument");
     hipStream_t st = (hipStream_t)stream;
-    HIPCHECK(hipSetDevice(e->cfg.device));
+    ON_DEVICE(e->cfg.device);
     e->prof_now = e->prof_on;
     CHECK(timestep_rows(e, (const long long*)t, batch, st));
     const int rows = cfg ? 2 * batch : batch;
@@ -778,7 +805,7 @@ extern "C" int mst_sample_loop(mst_engine* e, const mst_schedule* s, const mst_l
     if (a->noise_mode == MST_NOISE_BUFFER && !a->noise_dev) return fail("mst_sample_loop: noise buffer missing");
     if (a->sampler != MST_SAMPLER_DDPM && a->sampler != MST_SAMPLER_DDIM) return fail("mst_sample_loop: bad sampler");
     hipStream_t st = (hipStream_t)stream;
-    HIPCHECK(hipSetDevice(e->cfg.device));
+    ON_DEVICE(e->cfg.device);
     const int nrun = a->t_start - a->t_end + 1;
     const int rows = a->cfg ? 2 * a->batch : a->batch;
     const size_t clip_elems = (size_t)a->batch * e->cfg.feats * a->frames;
@@ -787,11 +814,12 @@ extern "C" int mst_sample_loop(mst_engine* e, const mst_schedule* s, const mst_l
     CHECK(timestep_rows(e, s->tmap + a->t_end, nrun, st));
     // Clips are independent, so the batch runs as `nsplit` slices on separate streams: one slice's kernels fill
     // the CUs the other leaves idle in its prologues, tails and launch gaps (per-launch time is per-CU bound and
-    // flat in the block count at this size).  CFG already has 2x the rows and stays one slice.
+    // flat in the block count at this size).  CFG batches are sliced the same way (cond + uncond twins stay together).
     const int nsl = mst_loop_slices(e, a->batch, a->cfg);
     const size_t per_clip = (size_t)e->cfg.feats * a->frames;
     hipStream_t streams[mst_engine::MAX_SLICES] = {st, e->aux_stream[0], e->aux_stream[1], e->aux_stream[2]};
     bool forked = false;
+    auto steps = [&]() -> int {
     for (int j = 0; j < nrun; j++) {
         const int ti = a->t_start - j;
         e->prof_now = e->prof_on && (j % e->prof_period == 0);
@@ -843,21 +871,25 @@ extern "C" int mst_sample_loop(mst_engine* e, const mst_schedule* s, const mst_l
             else CHECK(launch_out_nt<2>(e, ws, a->cfg, nb, a->frames, nullptr, sa, ss));
         }
     }
+    return 0;
+    };
+    const int rc = steps();
+    // join the slice streams whatever happened: after an error mid-loop the slices' work is still in flight on the
+    // caller's tensors, so the caller's stream must not run ahead of it (best effort: errors here are not reported twice)
     if (forked) {
         for (int i = 1; i < nsl; i++) {
-            HIPCHECK(hipEventRecord(e->ev_join[i - 1], streams[i]));
-            HIPCHECK(hipStreamWaitEvent(st, e->ev_join[i - 1], 0));
+            if (hipEventRecord(e->ev_join[i - 1], streams[i]) == hipSuccess) (void)hipStreamWaitEvent(st, e->ev_join[i - 1], 0);
         }
     }
     e->prof_now = 0;
-    return 0;
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------ elementwise ABI
 extern "C" int mst_q_sample(const mst_schedule* s, const float* x0, const float* noise, const float* mask, const int64_t* t,
                             int32_t batch, int64_t per_clip, float* out, void* stream) {
     if (!s || !x0 || !noise || !t || !out || batch < 1 || per_clip < 1) return fail("mst_q_sample: bad arguments");
-    HIPCHECK(hipSetDevice(s->device));
+    ON_DEVICE(s->device);
     int gx = (int)((per_clip + 255) / 256);
     if (gx > 2048) gx = 2048;
     hipLaunchKernelGGL(k_q_sample, dim3(gx, batch), dim3(256), 0, (hipStream_t)stream, s->tab, s->n, x0, noise, mask,
@@ -871,7 +903,7 @@ extern "C" int mst_step_epilogue(const mst_schedule* s, const float* model_out, 
                                  int32_t sampler, float eta, int32_t mask_noise, int32_t clip_denoised, float* sample,
                                  float* xstart, void* stream) {
     if (!s || !model_out || !x || !t || batch < 1 || per_clip < 1) return fail("mst_step_epilogue: bad arguments");
-    HIPCHECK(hipSetDevice(s->device));
+    ON_DEVICE(s->device);
     int gx = (int)((per_clip + 255) / 256);
     if (gx > 2048) gx = 2048;
     if (sampler == MST_SAMPLER_DDPM)
@@ -947,12 +979,8 @@ extern "C" int64_t mst_train_tape_bytes(const mst_engine* e, int32_t rows, int32
 template <int NKT>
 static int launch_attn_train_n(const f16* qkv, f16* out, int S, int rows, Drop d, const unsigned char* keep, int qsplit, float* lse, hipStream_t st) {
     auto kern = k_attention_train<NKT>;
-    static bool attr_set = false;
     const int smem = NKT * 32 * 256 * 2 + NKT * 32 * 4;
-    if (!attr_set) {
-        HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
-    }
+    CHECK(ensure_dyn_lds((const void*)kern, smem));
     hipLaunchKernelGGL(kern, dim3(rows * MST_H, qsplit ? NKT : 1), dim3(512), smem, st, qkv, out, S, d, keep, qsplit, lse);
     HIPCHECK(hipGetLastError());
     return 0;
@@ -961,12 +989,8 @@ template <int NKT>
 static int launch_attn_bwd_n(const f16* qkv, const f16* att, const f16* datt, f16* dqkv, int S, int rows, Drop d,
                              const unsigned char* keep, const float* lse, int split, hipStream_t st) {
     auto kern = k_attention_bwd<NKT>;
-    static bool attr_set = false;
     const int smem = NKT * 32 * 256 * 2 + NKT * 32 * 12;
-    if (!attr_set) {
-        HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
-    }
+    CHECK(ensure_dyn_lds((const void*)kern, smem));
     hipLaunchKernelGGL(kern, dim3(rows * MST_H, split ? 2 * NKT : 1), dim3(512), smem, st, qkv, att, datt, dqkv, S, d, keep, lse, split);
     HIPCHECK(hipGetLastError());
     return 0;
@@ -1054,7 +1078,7 @@ extern "C" int mst_train_forward(mst_engine* e, const float* h_in, int32_t rows,
     CHECK(train_check(e, rows, S, p_drop));
     if (!h_in || !tape || !h_out) return fail("mst_train_forward: null argument");
     hipStream_t st = (hipStream_t)stream;
-    HIPCHECK(hipSetDevice(e->cfg.device));
+    ON_DEVICE(e->cfg.device);
     const int M = rows * S, nl = e->cfg.num_layers;
     Tape t;
     tape_layout((char*)tape, nl, tape_rows(M), &t);
@@ -1104,11 +1128,7 @@ static int wgrad(mst_engine* e, const f16* dY, int n_out, const f16* X, int k_in
     const int kchunk = ((slabs + nsplit - 1) / nsplit) * 32;
     nsplit = (M + kchunk - 1) / kchunk;
     auto kern = k_wgrad_tr;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, WgTile::SMEM));
-        attr_set = true;
-    }
+    CHECK(ensure_dyn_lds((const void*)kern, WgTile::SMEM));
     static_assert(DEpiF32::smem_bytes<128, 256>() <= WgTile::SMEM, "epilogue tile must fit the ring");
     const size_t nelem = (size_t)n_out * k_in;
     if (nsplit == 1) {
@@ -1237,7 +1257,7 @@ extern "C" int mst_train_backward(mst_engine* e, const void* tape, const float* 
     if (!tape || !d_out) return fail("mst_train_backward: null argument");
     if (!grads && !d_in) return 0;                       // nothing asked for
     hipStream_t st = (hipStream_t)stream;
-    HIPCHECK(hipSetDevice(e->cfg.device));
+    ON_DEVICE(e->cfg.device);
     CHECK(train_ws(e));
     TrainWS& w_ = e->tw;
     const int M = rows * S, nl = e->cfg.num_layers;
@@ -1268,7 +1288,7 @@ extern "C" int mst_train_model_forward(mst_engine* e, const float* x, const int6
     if (!(p_pe >= 0.f && p_pe < 1.f)) return fail("mst_train_model_forward: positional-encoding dropout %g outside [0, 1)", (double)p_pe);
     if (!x || !t_idx || !tape || !out) return fail("mst_train_model_forward: null argument");
     hipStream_t st = (hipStream_t)stream;
-    HIPCHECK(hipSetDevice(e->cfg.device));
+    ON_DEVICE(e->cfg.device);
     const int M = batch * S, nl = e->cfg.num_layers;
     Tape t;
     tape_layout((char*)tape, nl, tape_rows(M), &t);
@@ -1295,7 +1315,7 @@ extern "C" int mst_train_model_backward(mst_engine* e, const void* tape, const f
     if (!tape || !d_out) return fail("mst_train_model_backward: null argument");
     if (!grads && !d_x) return 0;
     hipStream_t st = (hipStream_t)stream;
-    HIPCHECK(hipSetDevice(e->cfg.device));
+    ON_DEVICE(e->cfg.device);
     CHECK(train_ws(e));
     TrainWS& w_ = e->tw;
     const int M = batch * S, nl = e->cfg.num_layers, F = e->cfg.feats, tot = batch * frames;
@@ -1354,34 +1374,38 @@ extern "C" int64_t mst_adamw_workspace_bytes(int32_t n_tensors, const int64_t* n
 extern "C" int mst_adamw_step(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                               float* const* exp_avg_sq, const int64_t* numel, float lr, float beta1, float beta2, float eps,
                               float weight_decay, int32_t step, float* norms_dev, void* workspace_dev, int64_t workspace_bytes,
-                              void* stream) {
+                              int32_t upload_tables, void* stream) {
     if (n_tensors < 1 || !params || !grads || !exp_avg || !exp_avg_sq || !numel || !workspace_dev || step < 1)
         return fail("mst_adamw_step: bad arguments");
     if (workspace_bytes < mst_adamw_workspace_bytes(n_tensors, numel)) return fail("mst_adamw_step: workspace too small");
-    std::vector<AdamTensor> tt(n_tensors);
-    std::vector<AdamChunk> cc;
+    size_t nchunks = 0;
     for (int i = 0; i < n_tensors; i++) {
         if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i] || numel[i] < 1) return fail("mst_adamw_step: null tensor %d", i);
-        tt[i] = AdamTensor{params[i], grads[i], exp_avg[i], exp_avg_sq[i], (long long)numel[i]};
-        for (long long s0 = 0; s0 < numel[i]; s0 += kAdamChunk) cc.push_back(AdamChunk{i, 0, s0});
+        nchunks += (size_t)((numel[i] + kAdamChunk - 1) / kAdamChunk);
     }
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)workspace_dev;
-    const size_t tb = sizeof(AdamTensor) * tt.size();
+    const size_t tb = sizeof(AdamTensor) * (size_t)n_tensors;
     const size_t tb_al = (tb + 255) / 256 * 256;
-    // The tables change only when a tensor moves (a new gradient buffer): upload them synchronously then, and not at all
-    // when the same pointers come back (the usual case: torch's caching allocator returns the same blocks every iteration)
-    static std::map<void*, std::vector<AdamTensor>> uploaded;
-    std::vector<AdamTensor>& last = uploaded[workspace_dev];
-    if (last.size() != tt.size() || memcmp(last.data(), tt.data(), tb) != 0) {
+    // The tables change only when a tensor moves (a new gradient buffer) or the workspace is new: the owner of the
+    // workspace tracks that (optim.FusedAdamW keeps the pointer tuple the tables were written from) and says so; the
+    // library keeps no per-workspace state (a process-global cache keyed by the workspace address would survive the
+    // workspace itself and hand a later optimizer stale tables).
+    if (upload_tables) {
+        std::vector<AdamTensor> tt(n_tensors);
+        std::vector<AdamChunk> cc;
+        cc.reserve(nchunks);
+        for (int i = 0; i < n_tensors; i++) {
+            tt[i] = AdamTensor{params[i], grads[i], exp_avg[i], exp_avg_sq[i], (long long)numel[i]};
+            for (long long s0 = 0; s0 < numel[i]; s0 += kAdamChunk) cc.push_back(AdamChunk{i, 0, s0});
+        }
         HIPCHECK(hipStreamSynchronize(st));                 // a previous step may still be reading the old tables
         HIPCHECK(hipMemcpy(ws, tt.data(), tb, hipMemcpyHostToDevice));
         HIPCHECK(hipMemcpy(ws + tb_al, cc.data(), sizeof(AdamChunk) * cc.size(), hipMemcpyHostToDevice));
-        last = tt;
     }
     const float bias1 = 1.0f - (float)pow((double)beta1, (double)step);
     const float bias2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
-    hipLaunchKernelGGL(k_adamw_multi, dim3((unsigned)cc.size()), dim3(256), 0, st, (const AdamTensor*)ws, (const AdamChunk*)(ws + tb_al),
+    hipLaunchKernelGGL(k_adamw_multi, dim3((unsigned)nchunks), dim3(256), 0, st, (const AdamTensor*)ws, (const AdamChunk*)(ws + tb_al),
                        lr, beta1, beta2, eps, weight_decay, bias1, bias2_sqrt, norms_dev);
     HIPCHECK(hipGetLastError());
     return 0;

@@ -103,7 +103,8 @@ class GaussianDiffusion:
               "posterior_mean_coef1", "posterior_mean_coef2")
     noise_source = "torch"      # "torch": th.randn_like per step in the reference's call order;
     #                             "philox": in-kernel counter-based noise (no per-step torch call)
-    noise_chunk = 64            # torch mode: steps of noise drawn per engine call
+    noise_chunk = 64            # torch mode: at most this many steps of noise drawn per engine call ...
+    noise_chunk_bytes = 256 << 20   # ... and at most this many bytes of them (batch 64 x 263 x 196: 19 steps = 251 MB)
 
     def __init__(self, *, betas, model_mean_type, model_var_type, loss_type, rescale_timesteps=False,
                  lambda_rcxyz=0., lambda_vel=0., lambda_pose=1., lambda_orient=1., lambda_loc=1., data_rep='rot6d',
@@ -323,10 +324,13 @@ class GaussianDiffusion:
         return device, img, indices
 
     def _engine_loop(self, sampler, denoiser, cfg, img, indices, clip_denoised, model_kwargs, const_noise, eta, progress,
-                     chunked):
+                     chunked, want_xstart=True):
         """Loop inside the library.  chunked=True (the non-progressive entry points): `noise_chunk`
         indices per native call, intermediate 'sample' entries are None; chunked=False (public
-        progressive generators): one index per call and a fresh 'sample' tensor every step."""
+        progressive generators): one index per call and a fresh 'sample' tensor every step.
+        want_xstart=False (p_sample_loop / ddim_sample_loop without dump_all_xstart): the x0-hat of every step is
+        neither written by the step kernel nor allocated ([steps, B, F, 1, T]: 13.2 GB for a 1000-step batch-64 loop);
+        'pred_xstart' entries are then None."""
         y = self._y(model_kwargs)
         eng = denoiser.mst_engine(img.shape[0] * (2 if cfg is not None else 1), img.shape[-1])
         denoiser.mst_prepare(eng, y, cfg is not None)
@@ -335,7 +339,13 @@ class GaussianDiffusion:
         scale = y['scale'] if cfg is not None else None
         sch = self._schedule(img.device)
         x = img.contiguous().float().clone()
-        chunk = 1 if not chunked else (len(indices) if self.noise_source == "philox" else max(1, int(self.noise_chunk)))
+        if not chunked:
+            chunk = 1
+        elif self.noise_source == "philox":
+            # no noise buffer; with an x0-hat dump the dump itself is bounded the same way
+            chunk = len(indices) if not want_xstart else max(1, int(self.noise_chunk_bytes // (x.numel() * 4)))
+        else:
+            chunk = max(1, min(int(self.noise_chunk), int(self.noise_chunk_bytes // (x.numel() * 4))))
         seed = int(th.randint(0, 2 ** 31 - 1, (1,)).item()) if self.noise_source == "philox" else 0
         it = range(0, len(indices), chunk)
         if progress:
@@ -346,16 +356,18 @@ class GaussianDiffusion:
             noise = None
             if self.noise_source != "philox":
                 noise = th.stack([self._draw(x, const_noise) for _ in idx])
-            _, dump = eng.sample_loop(sch, x, idx[0], idx[-1], sampler, eta, cfg=cfg is not None, scale=scale,
-                                      mask=mask if mask is not None else nmask, motion=motion, mask_noise=nmask is not None,
-                                      clip_denoised=clip_denoised, noise=noise, seed=seed + c0, dump_xstart=True)
+            res = eng.sample_loop(sch, x, idx[0], idx[-1], sampler, eta, cfg=cfg is not None, scale=scale,
+                                  mask=mask if mask is not None else nmask, motion=motion, mask_noise=nmask is not None,
+                                  clip_denoised=clip_denoised, noise=noise, seed=seed + c0, dump_xstart=want_xstart)
+            dump = res[1] if want_xstart else None
             for j in range(len(idx)):
                 end = j == len(idx) - 1
-                yield {"sample": (x if chunked else x.clone()) if end else None, "pred_xstart": dump[j]}
+                yield {"sample": (x if chunked else x.clone()) if end else None,
+                       "pred_xstart": dump[j] if want_xstart else None}
 
     def _sample_loop_progressive(self, ddim, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device,
                                  progress, skip_timesteps, init_image, randomize_class, cond_fn_with_grad, const_noise,
-                                 pred_xstart_in_graph, stop_timesteps, eta=0.0, chunked=False):
+                                 pred_xstart_in_graph, stop_timesteps, eta=0.0, chunked=False, want_xstart=True):
         if randomize_class:
             raise NotImplementedError("randomize_class is an image-diffusion leftover, unused by this model family")
         device, img, indices = self._loop_setup(model, shape, noise, device, skip_timesteps, init_image, stop_timesteps, model_kwargs)
@@ -364,7 +376,7 @@ class GaussianDiffusion:
         sampler = _eng.SAMPLER_DDIM if ddim else _eng.SAMPLER_DDPM
         if denoiser is not None and not with_grad and cond_fn is None and denoised_fn is None and not denoiser.training:
             yield from self._engine_loop(sampler, denoiser, cfg, img, indices, clip_denoised, model_kwargs, const_noise, eta,
-                                         progress, chunked)
+                                         progress, chunked, want_xstart)
             return
         if progress:
             from tqdm.auto import tqdm
@@ -410,7 +422,7 @@ class GaussianDiffusion:
         for i, out in enumerate(self._sample_loop_progressive(
                 False, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device, progress,
                 skip_timesteps, init_image, randomize_class, cond_fn_with_grad, const_noise, pred_xstart_in_graph,
-                stop_timesteps, chunked=dump_steps is None)):
+                stop_timesteps, chunked=dump_steps is None, want_xstart=bool(dump_all_xstart))):
             if dump_steps is not None and i in dump_steps:
                 dump.append(deepcopy(out["sample"]))
             if dump_all_xstart:
@@ -427,7 +439,8 @@ class GaussianDiffusion:
         dump, final = [], None
         for out in self._sample_loop_progressive(
                 True, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device, progress, skip_timesteps,
-                init_image, randomize_class, cond_fn_with_grad, False, pred_xstart_in_graph, stop_timesteps, eta, chunked=True):
+                init_image, randomize_class, cond_fn_with_grad, False, pred_xstart_in_graph, stop_timesteps, eta, chunked=True,
+                want_xstart=bool(dump_all_xstart)):
             if dump_all_xstart:
                 dump.append(out["pred_xstart"])
             final = out

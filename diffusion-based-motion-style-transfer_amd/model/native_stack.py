@@ -39,7 +39,12 @@ class GradSink:
     def __init__(self, host, params):
         self.host, self.params = host, params
         self.ids = tuple(id(p) for p in params)
-        self.flat, self.views, self.active = None, None, False
+        self.flat, self.views, self.active, self.task = None, None, False, -1
+
+    def abort(self):
+        """A backward pass died (the autograd engine drops queued callbacks when a node raises): forget its partial sums."""
+        self.flat = self.views = None
+        self.active, self.task = False, -1
 
     def begin(self, device):
         total = sum(p.numel() for p in self.params)
@@ -48,12 +53,14 @@ class GradSink:
         for p in self.params:
             self.views.append(self.flat[off:off + p.numel()].view(p.shape))
             off += p.numel()
-        self.active = True
+        self.active, self.task = True, _graph_task()
         Variable._execution_engine.queue_callback(self.flush)
 
     def flush(self):
         """End of the backward pass: p.grad (+)= accumulated gradient, then tell a gradient reducer."""
-        self.active = False
+        if not self.active:
+            return
+        self.active, self.task = False, -1
         have, add = [], []
         for p, v in zip(self.params, self.views):
             if not p.requires_grad:
@@ -69,6 +76,12 @@ class GradSink:
         ready = getattr(self.host, "_native_grads_ready", None)
         if ready is not None:
             ready()
+
+
+def _graph_task():
+    """Id of the running backward pass (-1 outside one): a sink stamped with another id was left behind by a pass that failed."""
+    fn = getattr(torch._C, "_current_graph_task_id", None)
+    return int(fn()) if fn is not None else -1
 
 
 def _draw_seed(p):
@@ -91,9 +104,17 @@ def _sink_views(ctx, params_need_grad, device):
     sink = ctx.host.__dict__.get("_mst_grad_sink")
     if sink is None or sink.ids != tuple(id(p) for p in ctx.params):
         sink = ctx.host.__dict__["_mst_grad_sink"] = GradSink(ctx.host, list(ctx.params))
+    if sink.active and sink.task != _graph_task():
+        sink.abort()                      # stale: its pass raised before the flush callback could run
     if not sink.active:
         sink.begin(device)
     return sink.views
+
+
+def _abort_sink(ctx):
+    sink = ctx.host.__dict__.get("_mst_grad_sink")
+    if sink is not None:
+        sink.abort()
 
 
 class DenoiserTrainFn(torch.autograd.Function):
@@ -114,9 +135,14 @@ class DenoiserTrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         need_in = ctx.needs_input_grad[0]
-        views = _sink_views(ctx, any(ctx.needs_input_grad[6:]), grad_out.device)
-        d_x = ctx.eng.train_model_backward(_take_tape(ctx), grad_out.contiguous(), ctx.p_drop, ctx.p_pe, ctx.seed, views,
-                                           need_input_grad=need_in)
+        tape = _take_tape(ctx)            # raises on a second backward BEFORE the sink is touched
+        try:
+            views = _sink_views(ctx, any(ctx.needs_input_grad[6:]), grad_out.device)
+            d_x = ctx.eng.train_model_backward(tape, grad_out.contiguous(), ctx.p_drop, ctx.p_pe, ctx.seed, views,
+                                               need_input_grad=need_in)
+        except BaseException:
+            _abort_sink(ctx)
+            raise
         return (d_x, None, None, None, None, None) + (None,) * len(ctx.params)
 
 
@@ -138,8 +164,13 @@ class EncoderStackFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         need_in = ctx.needs_input_grad[0]
-        views = _sink_views(ctx, any(ctx.needs_input_grad[4:]), grad_out.device)
-        d_out = grad_out.permute(1, 0, 2).contiguous()
-        d_in = ctx.eng.train_backward(_take_tape(ctx), d_out, ctx.p_drop, ctx.seed, views, need_input_grad=need_in, key_keep=ctx.keep)
+        tape = _take_tape(ctx)
+        try:
+            views = _sink_views(ctx, any(ctx.needs_input_grad[4:]), grad_out.device)
+            d_out = grad_out.permute(1, 0, 2).contiguous()
+            d_in = ctx.eng.train_backward(tape, d_out, ctx.p_drop, ctx.seed, views, need_input_grad=need_in, key_keep=ctx.keep)
+        except BaseException:
+            _abort_sink(ctx)
+            raise
         gi = d_in.permute(1, 0, 2).contiguous() if need_in else None
         return (gi, None, None, None) + (None,) * len(ctx.params)

@@ -13,6 +13,7 @@ class FusedAdamW(torch.optim.AdamW):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, foreach=False, fused=False)
         self._ws = None
         self._norms = None
+        self._tables_for = None            # the pointer tuple the device-side tables in self._ws were written from
         self.last_sq_norms = None          # device tensor [sum g^2, sum p^2 before the update] of the last step()
 
     @torch.no_grad()
@@ -45,16 +46,23 @@ class FusedAdamW(torch.optim.AdamW):
             n = len(ps)
             numel = (C.c_int64 * n)(*[p.numel() for p in ps])
             need = N.lib().mst_adamw_workspace_bytes(n, numel)
+            if len(self.param_groups) > 1:
+                raise NotImplementedError("FusedAdamW keeps one table workspace: a single parameter group")
             if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
-                self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+                self._ws = torch.empty(need, dtype=torch.uint8, device=dev)       # owned for the optimizer's lifetime
                 self._norms = torch.zeros(2, dtype=torch.float32, device=dev)
+                self._tables_for = None
             self._norms.zero_()
+            tensors = (ps, [p.grad for p in ps], [self.state[p]["exp_avg"] for p in ps], [self.state[p]["exp_avg_sq"] for p in ps])
+            key = tuple(t.data_ptr() for ts in tensors for t in ts) + tuple(numel)
+            dirty = key != self._tables_for      # first step, a tensor moved (new gradient buffer, load_state_dict), new workspace
             arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
             b1, b2 = group["betas"]
-            N.check(N.lib().mst_adamw_step(n, arr(ps), arr([p.grad for p in ps]), arr([self.state[p]["exp_avg"] for p in ps]),
-                                           arr([self.state[p]["exp_avg_sq"] for p in ps]), numel, float(group["lr"]), float(b1),
-                                           float(b2), float(group["eps"]), float(group["weight_decay"]), steps.pop(),
-                                           N.ptr(self._norms), N.ptr(self._ws), self._ws.numel(), N.stream_ptr(dev)))
+            N.check(N.lib().mst_adamw_step(n, arr(tensors[0]), arr(tensors[1]), arr(tensors[2]), arr(tensors[3]), numel,
+                                           float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                           float(group["weight_decay"]), steps.pop(), N.ptr(self._norms), N.ptr(self._ws),
+                                           self._ws.numel(), int(dirty), N.stream_ptr(dev)))
+            self._tables_for = key
             for p in ps:                                   # written through raw pointers: tell autograd (and the engine's
                 torch.autograd.graph.increment_version(p)  # weight-version check, which re-uploads f16 copies) they changed
             self.last_sq_norms = self._norms if self.last_sq_norms is None else self.last_sq_norms + self._norms

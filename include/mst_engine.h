@@ -48,6 +48,7 @@ typedef struct mst_config {
  * ----------------------------------------------------------------------------------------- */
 const char* mst_last_error(void);
 int  mst_version(void);
+const char* mst_source_hash(void);   /* hash of csrc/ + this header the library was compiled from (stale-build check) */
 int  mst_engine_create(const mst_config* cfg, mst_engine** out);
 void mst_engine_destroy(mst_engine* e);
 
@@ -238,12 +239,19 @@ int mst_dropout_mask(uint64_t seed, int32_t layer, int32_t site, float p, uint64
  * norms_dev[1] += sum p^2 of the parameters BEFORE the update (what the reference logs).
  * All pointer arrays are HOST arrays of device pointers; workspace_dev holds the device-side tables
  * (mst_adamw_workspace_bytes).  `step` is the 1-based step count of these tensors.
+ * `upload_tables` != 0: (re)write the device-side tables from the host arrays before the launch (one
+ * stream synchronisation + two small copies).  The OWNER of the workspace decides: it must pass 1 on the
+ * first call with a workspace, whenever any pointer / size changed since the tables were last written
+ * into THIS workspace allocation, and whenever the workspace memory may have been reused in between;
+ * 0 re-uses the tables already there (the steady state: torch's caching allocator returns the same
+ * blocks every iteration).  The library keeps no state of its own about workspaces.
  * ----------------------------------------------------------------------------------------- */
 int64_t mst_adamw_workspace_bytes(int32_t n_tensors, const int64_t* numel_host);
 int mst_adamw_step(int32_t n_tensors, float* const* params, const float* const* grads,
                    float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel_host, float lr,
                    float beta1, float beta2, float eps, float weight_decay, int32_t step,
-                   float* norms_dev, void* workspace_dev, int64_t workspace_bytes, void* stream);
+                   float* norms_dev, void* workspace_dev, int64_t workspace_bytes, int32_t upload_tables,
+                   void* stream);
 
 /* -------------------------------------------------------------------------------------------
  * Post-sampling tensor ops, one launch (sample/demo_style_transfer.py:265-267,

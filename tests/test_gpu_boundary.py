@@ -104,6 +104,26 @@ def test_model_call_and_cfg_wrapper(golden):
     assert rel_l2(out_c.cpu().numpy(), g["xia|cfg"]) < TOL
 
 
+def test_motion_encoder_mu_vs_golden(golden):
+    """MotionEncoder.forward (mdm_forstyledataset.py:90-124) with ragged lengths against the reference's own
+    `xia|motion_enc_mu`, both without a graph (sampling-time use) and inside one (the fine-tune objective's use)."""
+    c = build()
+    x, t, y, _, _ = inputs()
+    fm = torch.zeros(2, 1, 1, T, device=dev())
+    fm[0, ..., :T] = 1
+    fm[1, ..., :T - 17] = 1
+    enc = c["m"].motion_enc
+    with torch.no_grad():
+        mu, txt = enc(x, y={"mask": fm, "text": PROMPTS})
+    e0 = rel_l2(mu.cpu().numpy(), golden["denoise"]["xia|motion_enc_mu"])
+    xin = x.clone().requires_grad_(True)
+    mu_g, _ = enc(xin, y={"mask": fm, "text": PROMPTS})
+    e1 = rel_l2(mu_g.detach().cpu().numpy(), golden["denoise"]["xia|motion_enc_mu"])
+    print("motion_enc_mu", e0, e1)
+    assert e0 < TOL and e1 < TOL
+    assert txt.shape == (2, 512)
+
+
 def test_single_steps_through_diffusion_objects(golden):
     c = build()
     g = golden["denoise"]

@@ -48,7 +48,7 @@ def test_forward_and_loop_on_ragged_shapes(F, T, B):
     eng.set_text(cu(txt), cfg=True)
     sc = np.linspace(1.5, 2.5, B).astype(np.float32)
     out = eng.forward(cu(x), cu(t), scale=cu(sc), cfg=True).cpu().numpy()
-    assert rel_l2(out, denoiser.cfg_forward(w, pe, x, t, txt, sc).numpy()) < 2 * TOL
+    assert rel_l2(out, denoiser.cfg_forward(w, pe, x, t, txt, sc).numpy()) < TOL
     # a short loop per sampler, with a mask that is not the root pattern (every third feature, frames 0..T/2)
     mask = np.zeros(shape, np.float32)
     mask[:, ::3, :, : max(1, T // 2)] = 1

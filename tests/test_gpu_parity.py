@@ -171,7 +171,7 @@ def test_forward_vs_oracle_and_golden(golden, tag):
     out_c = eng.forward(cu(x), cu(t), scale=cu(np.array([2.5, 1.5], np.float32)), cfg=True).cpu().numpy()
     e_cfg = rel_l2(out_c, golden["denoise"][f"{tag}|cfg"])
     print("cfg", tag, e_cfg)
-    assert e_cfg < 2 * TOL   # guidance extrapolates (scale 2.5): rounding of c - u is amplified
+    assert e_cfg < TOL       # guidance extrapolates (scale 2.5) and still has to meet the north_star bar
 
 
 def test_forward_single_clip_and_odd_batch():
@@ -320,7 +320,7 @@ def test_loops_vs_golden_xia(golden):
                           motion=cu(motion), noise=cu(nz[1:])).cpu().numpy()
     e = rel_l2(out, g["xia|cfgloop|sample"])
     print("cfgloop", e)
-    assert e < 2 * TOL
+    assert e < TOL
 
     # neutralisation pre-pass: the frozen prior as denoiser, stop_timesteps = 990 (indices 999..990)
     engp, _ = engine_for("xia", prior=True)
@@ -416,3 +416,99 @@ def test_full_size_properties(tile_path):
     # same kernels (large-tile path forced): identical up to fp32 reduction noise; with the default small-tile path the two
     # clips run through differently tiled kernels -- two f16-operand evaluations of the same function
     assert rel_l2(part.cpu().numpy(), full[10:12].cpu().numpy()) < (1e-6 if tile_path == "0" else TOL)
+
+
+# ------------------------------------------------------------------------------ BASELINE.json configs[4] and configs[2] at full size
+def _big_batch(tag, B):
+    """Clips 0..1 are the golden inputs, the rest seeded fill: the golden vectors pin two rows of a full-size launch."""
+    F, T, x2, t2, txt2 = inputs(tag)
+    x = np.concatenate([x2, syn.normal(SEED, f"{tag}/bigx/{B}", (B - 2, F, 1, T))])
+    t = np.concatenate([t2, np.random.default_rng(B).integers(0, 1000, B - 2)])
+    txt = np.concatenate([txt2, syn.normal(SEED, f"{tag}/bigtxt/{B}", (B - 2, 512))])
+    return F, T, x, t, txt
+
+
+def test_batch128_prior_as_denoiser_hml(golden, tile_path):
+    """BASELINE.json configs[4]: 128 clips per GPU of (263,1,196) through the T2M prior as the denoiser
+    (train/finetune_style_diffusion.py:195-212 drives MDM.forward this way).  M = 25 216 token rows: the only size that
+    reaches the 128-token LayerNorm tiles by row count; run on the default tiles and with MST_LN128_M=1 (fixture).
+    Rows 0..1 against the reference's golden `hml|prior_fwd`, then the size-independent properties at 128."""
+    from mst_amd.engine import Schedule, SAMPLER_DDPM
+    from oracle import schedule
+    B = 128
+    eng, w = engine_for("hml", prior=True, max_rows=B)
+    F, T, x, t, txt = _big_batch("hml", B)
+    eng.set_text(cu(txt))
+    out = eng.forward(cu(x), cu(t))
+    e = rel_l2(out[1:2].cpu().numpy(), golden["denoise"]["hml|prior_fwd"])       # the fixture keeps clip 1 of the hml shape
+    print("batch128 prior_fwd", tile_path, e)
+    assert e < TOL
+    assert torch.isfinite(out).all()
+    assert torch.equal(out, eng.forward(cu(x), cu(t)))                              # deterministic
+    # clip independence: clips 0..1 and 77..78 alone reproduce their rows of the batch-128 launch
+    for lo in (0, 77):
+        eng.set_text(cu(txt[lo:lo + 2]))
+        part = eng.forward(cu(x[lo:lo + 2]), cu(t[lo:lo + 2]))
+        # forced large tiles: the very same kernels -> fp32 reduction noise only; default: two clips take the small-tile kernels
+        # (two f16-operand evaluations of one function, each within TOL of the fp32 path)
+        assert rel_l2(part.cpu().numpy(), out[lo:lo + 2].cpu().numpy()) < (1e-6 if tile_path != "default" else 1.5 * TOL)
+    # a short sampling loop at 128 clips: deterministic, masked rows bit-exact, the same numbers whether Philox runs in the
+    # kernel or is injected, slices (3 x 43 clips) consistent with clip-wise runs
+    tab, tmap = schedule.make("cosine", 1000, "")
+    sch = Schedule(tab, tmap, _dev())
+    mask = cu(syn.root_horizontal_mask(B, F, T))
+    motion = cu(syn.normal(SEED, "hml/bigmotion", (B, F, 1, T)))
+    x0 = cu(x)
+    eng.set_text(cu(txt))
+    assert eng.loop_slices(B) == 3
+    a = eng.sample_loop(sch, x0.clone(), 3, 0, SAMPLER_DDPM, mask=mask, motion=motion, seed=11)
+    b = eng.sample_loop(sch, x0.clone(), 3, 0, SAMPLER_DDPM, mask=mask, motion=motion, seed=11)
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+    assert torch.equal(a[:, :3], motion[:, :3])
+    nz = torch.stack([eng.philox_normal(B, T, 11, j) for j in range(4)])
+    c = eng.sample_loop(sch, x0.clone(), 3, 0, SAMPLER_DDPM, mask=mask, motion=motion, noise=nz)
+    assert torch.equal(a, c)
+    eng.set_text(cu(txt[100:102]))
+    alone = eng.sample_loop(sch, x0[100:102].clone(), 3, 0, SAMPLER_DDPM, mask=mask[100:102], motion=motion[100:102],
+                            noise=nz[:, 100:102].contiguous())
+    assert rel_l2(alone.cpu().numpy(), a[100:102].cpu().numpy()) < (1e-6 if tile_path != "default" else 1.5 * TOL)
+
+
+def test_cfg_at_headline_size_hml(golden, tile_path):
+    """BASELINE.json configs[2] at the headline size: 64 clips = 128 rows through the transformer (cond | uncond doubled
+    batch, model/cfg_sampler.py:36-43).  Rows 0..1 against the reference's golden `hml|cfg` (scales 2.5 / 1.5), then
+    determinism, masked rows, and equality with clip-wise runs of a sliced CFG loop."""
+    from mst_amd.engine import Schedule, SAMPLER_DDPM
+    from oracle import schedule
+    B = 64
+    eng, w = engine_for("hml", max_rows=2 * B)
+    F, T, x, t, txt = _big_batch("hml", B)
+    scale = np.concatenate([np.array([2.5, 1.5], np.float32), np.linspace(1.0, 3.0, B - 2).astype(np.float32)])
+    eng.set_text(cu(txt), cfg=True)
+    out = eng.forward(cu(x), cu(t), scale=cu(scale), cfg=True)
+    e = rel_l2(out[:2].cpu().numpy(), golden["denoise"]["hml|cfg"])
+    print("cfg64", tile_path, e)
+    assert e < TOL
+    assert torch.equal(out, eng.forward(cu(x), cu(t), scale=cu(scale), cfg=True))
+    eng.set_text(cu(txt[30:32]), cfg=True)
+    part = eng.forward(cu(x[30:32]), cu(t[30:32]), scale=cu(scale[30:32]), cfg=True)
+    assert rel_l2(part.cpu().numpy(), out[30:32].cpu().numpy()) < (1e-6 if tile_path != "default" else 1.5 * TOL)
+    tab, tmap = schedule.make("cosine", 1000, "")
+    sch = Schedule(tab, tmap, _dev())
+    mask = cu(syn.root_horizontal_mask(B, F, T))
+    motion = cu(syn.normal(SEED, "hml/cfgmotion", (B, F, 1, T)))
+    nz = cu(np.stack([syn.normal(SEED, f"hml/cfgnz/{k}", (B, F, 1, T)) for k in range(3)]))
+    x0 = cu(x)
+    eng.set_text(cu(txt), cfg=True)
+    assert eng.loop_slices(B, cfg=True) == 3
+    a = eng.sample_loop(sch, x0.clone(), 2, 0, SAMPLER_DDPM, cfg=True, scale=cu(scale), mask=mask, motion=motion, noise=nz)
+    b = eng.sample_loop(sch, x0.clone(), 2, 0, SAMPLER_DDPM, cfg=True, scale=cu(scale), mask=mask, motion=motion, noise=nz)
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+    assert torch.equal(a[:, :3], motion[:, :3])
+    for i in (0, 22, 63):                                   # one clip of every slice, alone
+        eng.set_text(cu(txt[i:i + 1]), cfg=True)
+        one = eng.sample_loop(sch, x0[i:i + 1].clone(), 2, 0, SAMPLER_DDPM, cfg=True, scale=cu(scale[i:i + 1]),
+                              mask=mask[i:i + 1], motion=motion[i:i + 1], noise=nz[:, i:i + 1].contiguous())
+        # forced large tiles: the very same kernels.  Default: the single clip takes the small-tile kernels, i.e. this compares
+        # TWO f16-operand evaluations, each within TOL of the fp32 path (checked against the golden above): sqrt(2) x TOL apart
+        assert rel_l2(one.cpu().numpy(), a[i:i + 1].cpu().numpy()) < (1e-6 if tile_path != "default" else 1.5 * TOL)

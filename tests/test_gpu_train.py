@@ -385,3 +385,39 @@ def test_second_backward_is_refused():
     loss.backward(retain_graph=True)
     with pytest.raises(RuntimeError, match="a second time"):
         loss.backward()
+
+
+def test_failed_backward_does_not_poison_the_gradient_sink():
+    """the autograd engine drops queued callbacks when a node raises, so a backward pass that dies after the
+    sink was opened must not leave it open: the next, normal backward on the SAME model has to deliver the gradients a
+    fresh model gets."""
+    x, t, y, tgt = _model_batch()
+
+    def grads_of(m):
+        m.zero_grad()
+        ((m(x, t, y=y) - tgt) ** 2).mean().backward()
+        return {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    fresh = grads_of(_style_model().eval())
+    m = _style_model().eval()
+    # (1) the refused second backward
+    loss = ((m(x, t, y=y) - tgt) ** 2).mean()
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="a second time"):
+        loss.backward()
+    # (2) an error raised INSIDE the native backward call, after the sink was opened
+    out = m(x, t, y=y)
+    eng = m.mst_engine(x.shape[0], x.shape[-1])
+    orig = eng.train_model_backward
+    eng.train_model_backward = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("injected failure"))
+    try:
+        with pytest.raises(RuntimeError, match="injected failure"):
+            ((out - tgt) ** 2).mean().backward()
+    finally:
+        eng.train_model_backward = orig
+    sink = m.__dict__.get("_mst_grad_sink")
+    assert sink is not None and not sink.active
+    again = grads_of(m)
+    assert set(again) == set(fresh) and len(fresh) >= 96
+    for n in fresh:
+        assert rel_l2(again[n].cpu().numpy(), fresh[n].cpu().numpy()) < 1e-6, n

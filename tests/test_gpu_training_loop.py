@@ -86,6 +86,37 @@ def test_fused_adamw_step_equals_torch_adamw():
         FusedAdamW(c).step()
 
 
+def test_fused_adamw_rebuilt_on_the_same_model_equals_torch_adamw():
+    """build, step, delete and rebuild an optimizer on the same tensors (the caching allocator hands the second
+    one the same workspace address, and small tensors reuse that block in between): the device-side tables are re-uploaded
+    because the OWNER of the workspace tracks them, not a process-global cache keyed by address."""
+    import gc
+    from mst_amd.optim import FusedAdamW
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    shapes = [(512, 512), (1024,), (4099,)]
+    a = [torch.randn(s, device=dev).requires_grad_(True) for s in shapes]
+    b = [p.detach().clone().requires_grad_(True) for p in a]
+    ref = torch.optim.AdamW(b, lr=1e-3, weight_decay=0.01)
+    for round_ in range(3):
+        fused = FusedAdamW(a, lr=1e-3, weight_decay=0.01)
+        fused.load_state_dict(ref.state_dict())                 # carry the moments over, as a resumed run does
+        for it in range(2):
+            for p, q in zip(a, b):
+                g = torch.randn_like(p)
+                p.grad, q.grad = g.clone(), g.clone()           # fresh gradient tensors: pointers move between steps
+            fused.step()
+            ref.step()
+            for p, q in zip(a, b):
+                assert torch.allclose(p, q, rtol=2e-6, atol=1e-7), (round_, it)
+        ws_ptr = fused._ws.data_ptr()
+        del fused
+        gc.collect()
+        junk = [torch.full((ws_n,), 0xAB, dtype=torch.uint8, device=dev) for ws_n in (512, 4096, 9000)]   # scribble over freed blocks
+        del junk
+    assert ws_ptr
+
+
 def test_loop_with_bucket_reducer_single_rank(golden, tmp_path):
     """reducer=LayerBucketReducer(model): world size 1 must reproduce the plain loop (gradients live in the buckets,
     the reducer is notified by the native gradient sink, finish() runs before the optimizer step)."""
