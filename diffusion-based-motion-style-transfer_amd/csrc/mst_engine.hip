@@ -144,6 +144,8 @@ struct TrainWS {
     f16 *dbr2[2] = {nullptr, nullptr}, *dbr1[2] = {nullptr, nullptr}, *dpre[2] = {nullptr, nullptr}, *dqkv[2] = {nullptr, nullptr};
     f16* datt = nullptr;
     hipEvent_t ev_ready = nullptr, ev_side[2] = {nullptr, nullptr};
+    hipEvent_t ev_layer[16] = {nullptr};                // recorded when layer l's parameter gradients of the LAST backward call are enqueued
+    bool layer_done[16] = {false};
     float* part = nullptr;                              // split-K partial products
     float* zeros = nullptr;                             // zero bias
     float* gscale = nullptr;                            // [0] scale applied to the incoming gradient, [1] its inverse
@@ -323,6 +325,7 @@ extern "C" void mst_engine_destroy(mst_engine* e) {
         void* p[] = {t.g0, t.g1, t.dbr2[0], t.dbr2[1], t.dbr1[0], t.dbr1[1], t.dpre[0], t.dpre[1], t.dqkv[0], t.dqkv[1],
                      t.datt, t.part, t.zeros, t.gscale, t.amax};
         if (t.ev_ready) (void)hipEventDestroy(t.ev_ready);
+        for (int i = 0; i < 16; i++) if (t.ev_layer[i]) (void)hipEventDestroy(t.ev_layer[i]);
         for (int i = 0; i < 2; i++) if (t.ev_side[i]) (void)hipEventDestroy(t.ev_side[i]);
         for (void* q : p) (void)hipFree(q);
     }
@@ -1106,6 +1109,7 @@ static int train_ws(mst_engine* e) {
         HIPCHECK(hipEventCreateWithFlags(&t.ev_side[i], hipEventDisableTiming));
     }
     HIPCHECK(hipEventCreateWithFlags(&t.ev_ready, hipEventDisableTiming));
+    for (int i = 0; i < 16; i++) HIPCHECK(hipEventCreateWithFlags(&t.ev_layer[i], hipEventDisableTiming));
     CHECK(dmalloc(&t.datt, Mp * MST_D));
     CHECK(dmalloc(&t.part, t.split_cap * (size_t)3 * MST_D * MST_D));
     CHECK(dmalloc(&t.zeros, 3 * MST_D + MST_D));          // zero bias [1536] + a 512-float dump for unwanted reductions
@@ -1237,6 +1241,14 @@ static int train_stack_backward(mst_engine* e, const Tape& t, int rows, int S, f
             HIPCHECK(hipEventRecord(w_.ev_side[par], sw));
             side_used[par] = true;
         }
+        if (wg) {
+            // everything that writes layer l's 12 gradient tensors is enqueued: the wgrads on `sw` (which waited for the
+            // dgrad chain up to the attention backward, i.e. for both LayerNorm-backward kernels of this layer too).
+            // A data-parallel reducer makes its communication stream wait for THIS event (mst_train_wait_layer_grads) and
+            // starts the layer's all-reduce while the layers below are still being differentiated.
+            HIPCHECK(hipEventRecord(w_.ev_layer[l], sw));
+            w_.layer_done[l] = true;
+        }
         // g(x_in) = dqkv W_in + dz1 -> gB
         {
             DEpiF32 epi{gA, gB, MST_D, M};
@@ -1272,6 +1284,14 @@ extern "C" int mst_train_backward(mst_engine* e, const void* tape, const float* 
         hipLaunchKernelGGL(k_scale_f32, dim3(1024), dim3(256), 0, st, w_.g1, n, w_.gscale, 1, d_in);
         HIPCHECK(hipGetLastError());
     }
+    return 0;
+}
+
+extern "C" int mst_train_wait_layer_grads(mst_engine* e, int32_t layer, void* stream) {
+    if (!e || layer < 0 || layer >= e->cfg.num_layers) return fail("mst_train_wait_layer_grads: bad arguments");
+    if (!e->tw.ready || !e->tw.layer_done[layer]) return fail("mst_train_wait_layer_grads: no backward pass has produced gradients of layer %d yet", layer);
+    ON_DEVICE(e->cfg.device);
+    HIPCHECK(hipStreamWaitEvent((hipStream_t)stream, e->tw.ev_layer[layer], 0));
     return 0;
 }
 

@@ -236,6 +236,10 @@ class DenoiserEngine:
                                                  N.ptr(d_x), arr, N.stream_ptr(self.device)))
         return d_x
 
+    def wait_layer_grads(self, layer, stream):
+        """Make the torch stream `stream` wait for layer `layer`'s parameter gradients of the most recent backward call."""
+        N.check(N.lib().mst_train_wait_layer_grads(self.handle, int(layer), C.c_void_p(stream.cuda_stream)))
+
     def dropout_mask(self, seed, layer, site, p, n):
         out = torch.empty(n, dtype=torch.float32, device=self.device)
         N.check(N.lib().mst_dropout_mask(int(seed), layer, site, float(p), n, N.ptr(out), N.stream_ptr(self.device)))

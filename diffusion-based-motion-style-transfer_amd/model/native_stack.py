@@ -10,10 +10,18 @@ parameters (re-uploaded by `_EngineHost.mst_engine` whenever a parameter's versi
 Parameter gradients.  One fine-tune iteration passes through the stack 7 times (one 64-clip call, six
 chained single-clip steps); handing 96 fresh gradient tensors per pass to autograd would cost 96 fills +
 96 adds per pass (~1300 tiny launches per iteration, more host time than the kernels).  Instead every
-node of one backward pass accumulates -- inside the kernels, which add into their output -- into ONE flat
-buffer owned by the module (`GradSink`), and a callback queued on the autograd engine adds that buffer
-into `p.grad` once, when the backward pass ends (the mechanism DDP-style reducers use).  The parameters
-are still inputs of the node, so autograd knows the node needs to run; it receives None for them."""
+node of one backward pass accumulates -- inside the kernels, which add into their output -- into the
+module's `GradSink`: straight into the existing `p.grad` tensors when every parameter has one (the
+data-parallel reducer's bucket views, or gradients left from an earlier backward), else into ONE fresh flat
+buffer that a callback queued on the autograd engine hands to `p.grad` when the backward pass ends (the
+mechanism DDP-style reducers use).  The parameters are still inputs of the node, so autograd knows the node
+needs to run; it receives None for them.
+
+Data-parallel overlap.  The sink counts the nodes the forward pass created; the node whose backward runs LAST
+(in the fine-tune objective: the 64-clip text-to-motion call, by far the longest) tells the reducer
+(`host._native_layer_ready`) as soon as its native backward call has returned -- the call only enqueues GPU
+work -- and the reducer starts every layer's all-reduce behind that layer's gradient event
+(mst_train_wait_layer_grads), layer 7 first, while the GPU is still differentiating the layers below."""
 import torch
 from torch.autograd import Variable
 
@@ -40,19 +48,25 @@ class GradSink:
         self.host, self.params = host, params
         self.ids = tuple(id(p) for p in params)
         self.flat, self.views, self.active, self.task = None, None, False, -1
+        self.open_nodes = 0            # native nodes with parameter gradients created since the last backward pass ended
 
     def abort(self):
         """A backward pass died (the autograd engine drops queued callbacks when a node raises): forget its partial sums."""
         self.flat = self.views = None
         self.active, self.task = False, -1
+        self.open_nodes = 0
 
     def begin(self, device):
-        total = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(total, dtype=torch.float32, device=device)      # fresh: views may become p.grad
-        self.views, off = [], 0
-        for p in self.params:
-            self.views.append(self.flat[off:off + p.numel()].view(p.shape))
-            off += p.numel()
+        grads = [p.grad for p in self.params]
+        if all(g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.device == device for g in grads):
+            self.flat, self.views = None, grads          # accumulate in place (kernels add into their output)
+        else:
+            total = sum(p.numel() for p in self.params)
+            self.flat = torch.zeros(total, dtype=torch.float32, device=device)      # fresh: views may become p.grad
+            self.views, off = [], 0
+            for p in self.params:
+                self.views.append(self.flat[off:off + p.numel()].view(p.shape))
+                off += p.numel()
         self.active, self.task = True, _graph_task()
         Variable._execution_engine.queue_callback(self.flush)
 
@@ -61,17 +75,19 @@ class GradSink:
         if not self.active:
             return
         self.active, self.task = False, -1
-        have, add = [], []
-        for p, v in zip(self.params, self.views):
-            if not p.requires_grad:
-                continue
-            if p.grad is None:
-                p.grad = v
-            else:
-                have.append(p.grad)
-                add.append(v)
-        if have:
-            torch._foreach_add_(have, add)
+        self.open_nodes = 0
+        if self.flat is not None:
+            have, add = [], []
+            for p, v in zip(self.params, self.views):
+                if not p.requires_grad:
+                    continue
+                if p.grad is None:
+                    p.grad = v
+                else:
+                    have.append(p.grad)
+                    add.append(v)
+            if have:
+                torch._foreach_add_(have, add)
         self.flat = self.views = None
         ready = getattr(self.host, "_native_grads_ready", None)
         if ready is not None:
@@ -97,13 +113,18 @@ def _take_tape(ctx):
     return tape
 
 
+def _sink_of(host, params):
+    sink = host.__dict__.get("_mst_grad_sink")
+    if sink is None or sink.ids != tuple(id(p) for p in params):
+        sink = host.__dict__["_mst_grad_sink"] = GradSink(host, list(params))
+    return sink
+
+
 def _sink_views(ctx, params_need_grad, device):
-    """The flat gradient accumulator of this backward pass (None when no stack parameter needs a gradient)."""
+    """The gradient accumulators of this backward pass (None when no stack parameter needs a gradient)."""
     if not params_need_grad:
         return None
-    sink = ctx.host.__dict__.get("_mst_grad_sink")
-    if sink is None or sink.ids != tuple(id(p) for p in ctx.params):
-        sink = ctx.host.__dict__["_mst_grad_sink"] = GradSink(ctx.host, list(ctx.params))
+    sink = _sink_of(ctx.host, ctx.params)
     if sink.active and sink.task != _graph_task():
         sink.abort()                      # stale: its pass raised before the flush callback could run
     if not sink.active:
@@ -115,6 +136,20 @@ def _abort_sink(ctx):
     sink = ctx.host.__dict__.get("_mst_grad_sink")
     if sink is not None:
         sink.abort()
+
+
+def _node_done(ctx, had_param_grads):
+    """After a node's native backward call returned (its GPU work is enqueued): the LAST node of the pass hands the layers to
+    a data-parallel reducer right away instead of at the end of the pass."""
+    if not had_param_grads:
+        return
+    sink = ctx.host.__dict__.get("_mst_grad_sink")
+    if sink is None:
+        return
+    sink.open_nodes -= 1
+    ready = getattr(ctx.host, "_native_layer_ready", None)
+    if sink.open_nodes == 0 and ready is not None and sink.flat is None:      # in-place mode: p.grad IS the reducer's bucket
+        ready(ctx.eng)
 
 
 class DenoiserTrainFn(torch.autograd.Function):
@@ -130,6 +165,8 @@ class DenoiserTrainFn(torch.autograd.Function):
         seed = _draw_seed(max(p_drop, p_pe))
         out, tape = eng.train_model_forward(x.detach(), timesteps, p_drop, p_pe, seed)
         ctx.eng, ctx.tape, ctx.p_drop, ctx.p_pe, ctx.seed, ctx.host, ctx.params = eng, tape, p_drop, p_pe, seed, host, params
+        if any(ctx.needs_input_grad[6:]):
+            _sink_of(host, params).open_nodes += 1
         return out
 
     @staticmethod
@@ -140,6 +177,7 @@ class DenoiserTrainFn(torch.autograd.Function):
             views = _sink_views(ctx, any(ctx.needs_input_grad[6:]), grad_out.device)
             d_x = ctx.eng.train_model_backward(tape, grad_out.contiguous(), ctx.p_drop, ctx.p_pe, ctx.seed, views,
                                                need_input_grad=need_in)
+            _node_done(ctx, views is not None)
         except BaseException:
             _abort_sink(ctx)
             raise
@@ -159,6 +197,8 @@ class EncoderStackFn(torch.autograd.Function):
         out, tape = eng.train_forward(h, p_drop, seed, key_keep=key_keep)
         ctx.eng, ctx.tape, ctx.p_drop, ctx.seed, ctx.host, ctx.keep = eng, tape, p_drop, seed, host, key_keep
         ctx.params = params
+        if any(ctx.needs_input_grad[4:]):
+            _sink_of(host, params).open_nodes += 1
         return out.permute(1, 0, 2).contiguous()
 
     @staticmethod
@@ -169,6 +209,7 @@ class EncoderStackFn(torch.autograd.Function):
             views = _sink_views(ctx, any(ctx.needs_input_grad[4:]), grad_out.device)
             d_out = grad_out.permute(1, 0, 2).contiguous()
             d_in = ctx.eng.train_backward(tape, d_out, ctx.p_drop, ctx.seed, views, need_input_grad=need_in, key_keep=ctx.keep)
+            _node_done(ctx, views is not None)
         except BaseException:
             _abort_sink(ctx)
             raise

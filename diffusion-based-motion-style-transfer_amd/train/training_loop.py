@@ -216,6 +216,12 @@ class TrainInpaintingLoop:
         return f"model{(self.step + self.resume_step):09d}.pt"
 
     def save(self):
+        # data-parallel (reducer present): replicas are identical, one rank writes, the others wait for the files
+        import torch.distributed as dist
+        multi = self.reducer is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if multi and dist.get_rank() != 0:
+            dist.barrier()
+            return
         state_dict = self.mp_trainer.master_params_to_state_dict(self.mp_trainer.master_params)
         drop = ('motion_enc.', 'clip_model.') if self.dataset != 'humanml' else ('controlmdm.', 'clip_model.')
         state_dict = {k: v for k, v in state_dict.items() if not k.startswith(drop)}
@@ -225,3 +231,5 @@ class TrainInpaintingLoop:
             torch.save(state_dict, f)
         with open(os.path.join(self.save_dir, f"opt{(self.step + self.resume_step):09d}.pt"), "wb") as f:
             torch.save(self.opt.state_dict(), f)
+        if multi:
+            dist.barrier()

@@ -227,6 +227,13 @@ int mst_train_model_forward(mst_engine* e, const float* x_dev, const int64_t* t_
 int mst_train_model_backward(mst_engine* e, const void* tape_dev, const float* d_out_dev, int32_t batch,
                              int32_t frames, float p_drop, float p_pe, uint64_t seed, float* d_x_dev,
                              float* const* grads_host_array, void* stream);
+/* Data-parallel fine-tuning (BASELINE.json configs[3]; the reference is single-device, train/training_loop.py:73).
+ * Make `stream` wait until every kernel that writes layer `layer`'s 12 gradient tensors in the MOST RECENT
+ * mst_train_backward / mst_train_model_backward call (grads != NULL) has finished.  The backward calls only ENQUEUE
+ * work; a reducer calls this right after the backward call returns, layer num_layers-1 first, and launches that
+ * layer's gradient all-reduce on `stream`: it then runs on the GPU while the layers below are still being
+ * differentiated. */
+int mst_train_wait_layer_grads(mst_engine* e, int32_t layer, void* stream);
 int mst_dropout_mask(uint64_t seed, int32_t layer, int32_t site, float p, uint64_t n, float* out_dev,
                      void* stream);
 

@@ -52,10 +52,21 @@ def _worker(rank, ws, port, q):
         m = _model()
         red = LayerBucketReducer(m)
         red.zero_grad()
+        # overlap: the all-reduce of layer 1 must be LAUNCHED while backward is still running, i.e. before layer 0 has been
+        # differentiated (its bucket is still all zeros at that moment)
+        layer0 = [p for n, p in m.named_parameters() if p.requires_grad and ".layers.0." in n]
+        seen, launch = [], red._launch
+
+        def spy(b, where):
+            seen.append((b["layer"], where, float(sum(p.grad.abs().sum() for p in layer0))))
+            launch(b, where)
+
+        red._launch = spy
         _loss(m, 2 * rank, 2 * rank + 2).backward()
+        done = len(seen)                                     # launches that happened before backward() returned
         red.finish()
         g = {n: p.grad.clone() for n, p in m.named_parameters() if p.requires_grad}
-        q.put((rank, {k: v.numpy() for k, v in g.items()}, red.launch_order, red.bucket_bytes()))
+        q.put((rank, {k: v.numpy() for k, v in g.items()}, red.launch_order, red.bucket_bytes(), seen, done, red.launched_in))
     finally:
         dist.destroy_process_group()
 
@@ -76,8 +87,11 @@ def test_bucketed_allreduce_equals_full_batch_gradients():
     _loss(m, 0, 4).backward()                       # single process, whole batch (mean over 4 clips)
     ref = {n: p.grad for n, p in m.named_parameters() if p.requires_grad}
     assert len(ref) == 24                            # 2 layers x 12 tensors; frozen prior has none
-    for rank, grads, order, nbytes in res:
+    for rank, grads, order, nbytes, seen, done, where in res:
         assert order == [1, 0]                       # buckets fire in backward order: last layer first
+        assert done == 2 and where == ["backward", "backward"]      # both launched from inside the backward pass ...
+        assert seen[0][0] == 1 and seen[0][2] == 0.0                 # ... layer 1's before layer 0 was differentiated
+        assert seen[1][0] == 0 and seen[1][2] > 0.0
         assert nbytes == [2102784 * 4, 2102784 * 4]  # one 8.4 MB bucket per layer
         for n, g in ref.items():
             assert torch.allclose(torch.from_numpy(grads[n]), g, rtol=1e-4, atol=1e-7), n
@@ -97,7 +111,7 @@ def _worker_native_protocol(rank, ws, port, q):
         local = torch.autograd.grad(_loss(m, 2 * rank, 2 * rank + 2), params)
         red = LayerBucketReducer(m)
         red.native = True                                   # as on GPU parameters with train_backend == "native"
-        m.__dict__["_native_grads_ready"] = red._native_ready
+        m.__dict__["_native_grads_ready"] = red._native_grads_ready
         red.zero_grad()
         torch._foreach_add_([p.grad for p in params], list(local))          # GradSink.flush, existing-gradient branch
         m._native_grads_ready()
@@ -123,6 +137,6 @@ def test_native_gradient_handoff_allreduces_buckets():
     _loss(m, 0, 4).backward()
     ref = {n: p.grad for n, p in m.named_parameters() if p.requires_grad}
     for rank, grads, order in res:
-        assert order == [1, 0]
+        assert order == [1, 0]                       # the end-of-pass fallback still launches last layer first
         for n, g in ref.items():
             assert torch.allclose(torch.from_numpy(grads[n]), g, rtol=1e-4, atol=1e-7), n

@@ -285,6 +285,7 @@ def test_native_gradients_reach_a_bucket_reducer():
     step()
     red.finish()
     assert red.launch_order == list(range(7, -1, -1))
+    assert red.launched_in == ["backward"] * 8
     for n, p in m.named_parameters():
         if p.requires_grad:
             assert rel_l2(p.grad.cpu().numpy(), plain[n].cpu().numpy()) < 1e-6, n

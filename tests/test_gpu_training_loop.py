@@ -140,4 +140,7 @@ def test_loop_with_bucket_reducer_single_rank(golden, tmp_path):
     with lf.recorded_noise("loop"):
         loop.run_loop()
     assert red.launch_order == list(range(7, -1, -1))                 # fired on the last step too
+    # ... and from INSIDE the backward pass: the last native node (the text-to-motion call) hands every layer to the reducer
+    # behind that layer's gradient event, before the pass has ended
+    assert red.launched_in == ["backward"] * 8, red.launched_in
     assert np.allclose(losses, g["loss"], rtol=2e-3), (losses, g["loss"])
