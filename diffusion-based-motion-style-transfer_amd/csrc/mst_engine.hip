@@ -17,6 +17,7 @@
 #include "mst_common.h"
 #include "mst_elem.h"
 #include "mst_gemm_dma.h"
+#include "mst_tail.h"
 
 using namespace mst;
 
@@ -134,6 +135,7 @@ struct LayerW {
     float *g1 = nullptr, *be1 = nullptr, *g2 = nullptr, *be2 = nullptr;
     // [in][out] f16 copies: the "weights" operand of the dgrad GEMMs (training path)
     f16 *w_inT = nullptr, *w_outT = nullptr, *w1T = nullptr, *w2T = nullptr;
+    f16* wtail = nullptr;           // W_out | W1 | W2 as the fused layer tail's slab stream (mst_tail.h, k_pack_tail)
 };
 
 // engine-owned scratch of the backward pass, allocated on the first training call
@@ -153,9 +155,10 @@ struct TrainWS {
     size_t split_cap = 0;
 };
 
-enum Family { FAM_COND = 0, FAM_EMBED_IN, FAM_QKV, FAM_ATTN, FAM_OUTPROJ_LN, FAM_FFN1, FAM_FFN2_LN, FAM_EMBED_OUT, FAM_QKV_ATTN, FAM_COUNT };
+enum Family { FAM_COND = 0, FAM_EMBED_IN, FAM_QKV, FAM_ATTN, FAM_OUTPROJ_LN, FAM_FFN1, FAM_FFN2_LN, FAM_EMBED_OUT, FAM_QKV_ATTN, FAM_TAIL, FAM_COUNT };
 static const char* kFamilyNames[FAM_COUNT] = {"cond_token", "embed_in", "qkv_gemm", "attention", "outproj_ln_gemm",
-                                              "ffn1_gelu_gemm", "ffn2_ln_gemm", "embed_out_step", "qkv_attention_fused"};
+                                              "ffn1_gelu_gemm", "ffn2_ln_gemm", "embed_out_step", "qkv_attention_fused",
+                                              "layer_tail_fused"};
 
 struct ProfPoint { int fam; hipEvent_t a, b; };
 
@@ -171,6 +174,7 @@ struct mst_engine {
     // workspace
     f16* hl = nullptr;        // lo half of the stream (hx is the hi half)
     f16 *hx = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr, *xt = nullptr;
+    f16 *x1h = nullptr, *x1l = nullptr;   // fused layer tail: LayerNorm1 output (hi = FFN1 operand, hi + lo = LayerNorm2 residual)
     float *temb_hid = nullptr, *temb = nullptr, *textproj = nullptr;
     int temb_cap = 0;
     std::vector<std::string> loaded;
@@ -178,6 +182,7 @@ struct mst_engine {
     TrainWS tw;
     int dbg_layer = -1, dbg_stage = -1;   // stop the trunk after (layer, stage); -1 = run everything
     int fuse_qkv_attn = 1;                // K4 + K5 as one kernel per (clip, head); MST_FUSE_QKV_ATTN=0 keeps them apart
+    int fuse_tail = 1;                    // K6 + K7 + K8 as one kernel per 64-token tile (mst_tail.h); MST_FUSE_TAIL=0 keeps them apart
     int small_m = 2048;                   // launches of at most this many token rows take the small-tile path (MST_SMALL_M, 0 = never);
                                           // tools/small_m_sweep.sh: 8 clips (1576 rows) 722 -> 417 us/step, 11-clip slices (2167 rows) 766 vs 796
     float* zacc = nullptr;                // fp32 GEMM result feeding k_ln_rows on that path
@@ -270,6 +275,7 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
         CHECK(dmalloc(&w.w_outT, (size_t)MST_D * MST_D));
         CHECK(dmalloc(&w.w1T, (size_t)MST_FF * MST_D));
         CHECK(dmalloc(&w.w2T, (size_t)MST_D * MST_FF));
+        CHECK(dmalloc(&w.wtail, TailCfg::LAYER_BYTES / 2));
     }
     CHECK(dmalloc(&e->w_pose_in, (size_t)MST_D * e->kin_pad));
     CHECK(dmalloc(&e->b_pose_in, MST_D));
@@ -289,6 +295,8 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     CHECK(dmalloc(&e->qkv, (size_t)e->M_pad * 3 * MST_D));
     CHECK(dmalloc(&e->att, (size_t)e->M_pad * MST_D));
     CHECK(dmalloc(&e->hid, (size_t)e->M_pad * MST_FF));
+    CHECK(dmalloc(&e->x1h, (size_t)e->M_pad * MST_D));
+    CHECK(dmalloc(&e->x1l, (size_t)e->M_pad * MST_D));
     CHECK(dmalloc(&e->xt, ((size_t)c->max_rows * c->max_frames + 128) * e->kin_pad));
     e->temb_cap = c->max_rows > 1024 ? c->max_rows : 1024;
     CHECK(dmalloc(&e->temb_hid, (size_t)e->temb_cap * MST_D));
@@ -304,6 +312,7 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
         e->nsplit = n < 1 ? 1 : (n > mst_engine::MAX_SLICES ? mst_engine::MAX_SLICES : n);
     }
     if (const char* v = getenv("MST_FUSE_QKV_ATTN")) e->fuse_qkv_attn = atoi(v) != 0;
+    if (const char* v = getenv("MST_FUSE_TAIL")) e->fuse_tail = atoi(v) != 0;
     if (const char* v = getenv("MST_WGRAD_STREAM")) e->wgrad_stream_on = atoi(v) != 0;
     if (const char* v = getenv("MST_SMALL_M")) e->small_m = atoi(v);
     if (const char* v = getenv("MST_LN128_M")) e->ln128_min_m = atoi(v);
@@ -317,7 +326,7 @@ extern "C" void mst_engine_destroy(mst_engine* e) {
     for (int l = 0; l < e->cfg.num_layers; l++) {
         LayerW& w = e->L[l];
         void* p[] = {w.w_in, w.w_out, w.w1, w.w2, w.b_in, w.b_out, w.b1, w.b2, w.g1, w.be1, w.g2, w.be2,
-                     w.w_inT, w.w_outT, w.w1T, w.w2T};
+                     w.w_inT, w.w_outT, w.w1T, w.w2T, w.wtail};
         for (void* q : p) (void)hipFree(q);
     }
     {
@@ -330,7 +339,8 @@ extern "C" void mst_engine_destroy(mst_engine* e) {
         for (void* q : p) (void)hipFree(q);
     }
     void* p[] = {e->w_pose_in, e->b_pose_in, e->w_pose_out, e->b_pose_out, e->w_pose_inT, e->w_pose_outT, e->w_t0, e->b_t0, e->w_t2, e->b_t2,
-                 e->w_text, e->b_text, e->pe, e->hl, e->hx, e->qkv, e->att, e->hid, e->xt, e->temb_hid, e->temb, e->textproj, e->zacc};
+                 e->w_text, e->b_text, e->pe, e->hl, e->hx, e->qkv, e->att, e->hid, e->xt, e->temb_hid, e->temb, e->textproj, e->zacc,
+                 e->x1h, e->x1l};
     for (void* q : p) (void)hipFree(q);
     for (int i = 0; i < mst_engine::MAX_SLICES - 1; i++) {
         if (e->aux_stream[i]) (void)hipStreamDestroy(e->aux_stream[i]);
@@ -379,7 +389,8 @@ extern "C" int mst_load_weight(mst_engine* e, const char* name, const float* src
         if (layer < 0 || layer >= e->cfg.num_layers) return fail("mst_load_weight: layer %d out of range", layer);
         LayerW& w = e->L[layer];
         std::string r(rest);
-#define MAT(key, N_, K_, dst) if (r == key) { if (!shape_is(shape, ndim, N_, K_)) return fail("mst_load_weight: %s: bad shape", name); rc = put_matrix(src, N_, K_, dst, N_, K_, st); if (!rc) rc = put_matrix_t(src, N_, K_, dst##T, st); }
+#define MAT(key, N_, K_, dst) if (r == key) { if (!shape_is(shape, ndim, N_, K_)) return fail("mst_load_weight: %s: bad shape", name); rc = put_matrix(src, N_, K_, dst, N_, K_, st); if (!rc) rc = put_matrix_t(src, N_, K_, dst##T, st); repack = dst != w.w_in; }
+        bool repack = false;
 #define VEC(key, N_, dst) if (r == key) { if (!shape_is(shape, ndim, N_)) return fail("mst_load_weight: %s: bad shape", name); rc = put_vector(src, N_, dst, N_, st); }
         MAT("self_attn.in_proj_weight", 3 * MST_D, MST_D, w.w_in)
         VEC("self_attn.in_proj_bias", 3 * MST_D, w.b_in)
@@ -395,6 +406,10 @@ extern "C" int mst_load_weight(mst_engine* e, const char* name, const float* src
         VEC("norm2.bias", MST_D, w.be2)
 #undef MAT
 #undef VEC
+        if (rc == 0 && repack) {      // the fused layer tail reads W_out | W1 | W2 as one pre-packed slab stream (same stream: ordered behind the conversion)
+            hipLaunchKernelGGL(k_pack_tail, dim3(640), dim3(256), 0, st, w.w_out, w.w1, w.w2, w.wtail);
+            HIPCHECK(hipGetLastError());
+        }
     } else if (n == "input_process.poseEmbedding.weight") {
         if (!shape_is(shape, ndim, MST_D, F)) return fail("mst_load_weight: %s: bad shape", name);
         rc = put_matrix(src, MST_D, F, e->w_pose_in, MST_D, e->kin_pad, st);
@@ -611,12 +626,24 @@ extern "C" int mst_set_text(mst_engine* e, const float* text_emb, const float* k
 // A slice of the workspace: clips [r0, r0 + n) of the batch get their own rows of every buffer, so slices can
 // run concurrently on different streams (tiles may over-READ into a neighbour's rows; they never write them).
 struct WS {
-    f16 *hl, *hx, *qkv, *att, *hid, *xt; float* textproj; float* zacc;
+    f16 *hl, *hx, *qkv, *att, *hid, *xt; float* textproj; float* zacc; f16 *x1h, *x1l;
 };
 static WS ws_slice(const mst_engine* e, int r0, int T) {
     const size_t row = (size_t)r0 * (T + 1);
     return WS{e->hl + row * MST_D, e->hx + row * MST_D, e->qkv + row * 3 * MST_D, e->att + row * MST_D, e->hid + row * MST_FF,
-              e->xt + (size_t)r0 * T * e->kin_pad, e->textproj + (size_t)r0 * MST_D, e->zacc + row * MST_D};
+              e->xt + (size_t)r0 * T * e->kin_pad, e->textproj + (size_t)r0 * MST_D, e->zacc + row * MST_D,
+              e->x1h + row * MST_D, e->x1l + row * MST_D};
+}
+
+// K6 + K7 + K8 of one layer as one launch (mst_tail.h): one workgroup per 64-token tile
+static int launch_tail(const LayerW& w, const WS& ws, int M, hipStream_t st) {
+    static_assert(TailCfg::SMEM <= 163840, "fused layer tail exceeds the 160 KiB LDS");
+    static_assert(DEpiResidLN::smem_bytes<64, 512>() <= TailCfg::OFF_B, "LayerNorm scratch must not reach the staged FFN1 bias");
+    CHECK(ensure_dyn_lds((const void*)k_layer_tail, TailCfg::SMEM));
+    hipLaunchKernelGGL(k_layer_tail, dim3((M + TailCfg::BT - 1) / TailCfg::BT), dim3(512), TailCfg::SMEM, st, ws.att, w.wtail,
+                       w.b_out, w.g1, w.be1, w.b1, w.b2, w.g2, w.be2, ws.hx, ws.hl, ws.x1h, ws.x1l, M);
+    HIPCHECK(hipGetLastError());
+    return 0;
 }
 
 // K3 .. K8: token stream through the encoder stack.  rows = clips through the transformer.
@@ -706,6 +733,12 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
             }
         }
         DBG_STOP(2)
+        if (e->fuse_tail && !(e->dbg_layer == l && (e->dbg_stage == 3 || e->dbg_stage == 4))) {
+            ProfScope ps(e, FAM_TAIL, st);
+            CHECK(launch_tail(w, ws, M, st));
+            DBG_STOP(5)
+            continue;
+        }
         {
             ProfScope ps(e, FAM_OUTPROJ_LN, st);
             DEpiResidLN epi{w.b_out, w.g1, w.be1, ws.hx, ws.hl, M};

@@ -311,11 +311,19 @@ struct DEpiPlainF32 {
 struct DEpiResidLN {
     const float* bias; const float* gamma; const float* beta;
     f16* hi; f16* lo; int M;                 // the stream (read as residual, rewritten in place): hi + lo pair
+    const f16* rhi = nullptr; const f16* rlo = nullptr;     // residual source when it is not the output (fused layer tail)
     __device__ __forceinline__ int rows() const { return M; }
     template <int BT, int BF> static constexpr int smem_bytes() { return 64 * (MST_D * 4 + 16); }     // 64 rows per pass
     template <int BT, int BF, int MT, int NT>
     __device__ __forceinline__ void run(f32x16 (&acc)[1][MT][NT], int tok0, int f0, char* smem) const {
         static_assert(BF == MST_D, "LayerNorm needs the whole row in one block");
+        run_map<BT, MT, NT>(acc, DLane<BT, BF, MT, NT>(), tok0, smem);
+    }
+    // LM: accumulator -> (token, feature) map of the calling kernel: tok(m), feat(n, g) = first of 4 consecutive features
+    template <int BT, int MT, int NT, class LM>
+    __device__ __forceinline__ void run_map(f32x16 (&acc)[1][MT][NT], const LM& lc, int tok0, char* smem) const {
+        const f16* const rh = rhi ? rhi : hi;
+        const f16* const rl = rlo ? rlo : lo;
 #if defined(ABL_LN) && ABL_LN == 1      // ablation build: no epilogue (keep the accumulators alive)
         {
             float keep = 0.f;
@@ -326,7 +334,6 @@ struct DEpiResidLN {
 #endif
         constexpr int LD = MST_D * 4 + 16;                    // 2064-B rows: conflict-free b128 writes and reads
         constexpr int PR = 64, PASSES = BT / PR;              // 128-token tiles (large launches) go through LDS in two halves
-        DLane<BT, BF, MT, NT> lc;
         const int tok0_tile = tok0;
 #pragma unroll
         for (int pass = 0; pass < PASSES; pass++) {
@@ -360,8 +367,8 @@ struct DEpiResidLN {
         for (int r = 0; r < RPW; r++) {
             int tok = tok0 + row0 + r;
             size_t off = (size_t)(tok < M ? tok : 0) * MST_D;
-            xa[r] = join4_f16(*reinterpret_cast<const uint2*>(hi + off + fa), *reinterpret_cast<const uint2*>(lo + off + fa));
-            xb[r] = join4_f16(*reinterpret_cast<const uint2*>(hi + off + fb), *reinterpret_cast<const uint2*>(lo + off + fb));
+            xa[r] = join4_f16(*reinterpret_cast<const uint2*>(rh + off + fa), *reinterpret_cast<const uint2*>(rl + off + fa));
+            xb[r] = join4_f16(*reinterpret_cast<const uint2*>(rh + off + fb), *reinterpret_cast<const uint2*>(rl + off + fb));
         }
         // row sums for ALL rows first, then the shuffle ladders step by step across rows: RPW
         // independent ds_bpermutes per step instead of RPW serial 6-deep dependency chains

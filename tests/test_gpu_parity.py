@@ -29,13 +29,17 @@ def _dev():
 _ENGINES = {}
 
 
-@pytest.fixture(autouse=True, params=["default", "0", "ln128"], ids=["small-tiles", "large-tiles", "large-tiles-ln128"])
+@pytest.fixture(autouse=True, params=["default", "0", "unfused", "ln128"],
+                ids=["small-tiles", "large-tiles", "large-tiles-unfused-tail", "large-tiles-unfused-ln128"])
 def tile_path(request, monkeypatch):
-    """Every test of this module runs three times: launches of a few clips (all the golden comparisons) take the small-tile
-    path by default; MST_SMALL_M=0 sends the same inputs through the batch-64 kernels; MST_LN128_M=1 additionally through the
-    optional 128-token LayerNorm tiles (off by default: no gain in the pipeline)."""
+    """Every test of this module runs four times: launches of a few clips (all the golden comparisons) take the small-tile
+    path by default; MST_SMALL_M=0 sends the same inputs through the batch-64 kernels (fused QKV+attention and the fused
+    layer tail); MST_FUSE_TAIL=0 keeps out-proj+LN / FFN1 / FFN2+LN as three launches (the training path's kernels);
+    MST_LN128_M=1 additionally takes the optional 128-token LayerNorm tiles on that path."""
     if request.param != "default":
         monkeypatch.setenv("MST_SMALL_M", "0")
+    if request.param in ("unfused", "ln128"):
+        monkeypatch.setenv("MST_FUSE_TAIL", "0")
     if request.param == "ln128":
         monkeypatch.setenv("MST_LN128_M", "1")
     return request.param
@@ -44,7 +48,7 @@ def tile_path(request, monkeypatch):
 def engine_for(tag, prior=False, max_rows=4):
     import os
     from mst_amd.engine import DenoiserEngine
-    key = (tag, prior, max_rows, os.environ.get("MST_SMALL_M"), os.environ.get("MST_LN128_M"))
+    key = (tag, prior, max_rows, os.environ.get("MST_SMALL_M"), os.environ.get("MST_LN128_M"), os.environ.get("MST_FUSE_TAIL"))
     if key not in _ENGINES:
         F, T = SHAPES[tag]
         eng = DenoiserEngine(F, T, max_rows, device=_dev())

@@ -90,6 +90,7 @@ def test_fused_adamw_rebuilt_on_the_same_model_equals_torch_adamw():
     """build, step, delete and rebuild an optimizer on the same tensors (the caching allocator hands the second
     one the same workspace address, and small tensors reuse that block in between): the device-side tables are re-uploaded
     because the OWNER of the workspace tracks them, not a process-global cache keyed by address."""
+    import copy
     import gc
     from mst_amd.optim import FusedAdamW
     dev = torch.device("cuda:0")
@@ -100,7 +101,8 @@ def test_fused_adamw_rebuilt_on_the_same_model_equals_torch_adamw():
     ref = torch.optim.AdamW(b, lr=1e-3, weight_decay=0.01)
     for round_ in range(3):
         fused = FusedAdamW(a, lr=1e-3, weight_decay=0.01)
-        fused.load_state_dict(ref.state_dict())                 # carry the moments over, as a resumed run does
+        fused.load_state_dict(copy.deepcopy(ref.state_dict()))   # carry the moments over, as a resumed run does (torch's
+        #                                                          load_state_dict aliases tensors that need no cast)
         for it in range(2):
             for p, q in zip(a, b):
                 g = torch.randn_like(p)
