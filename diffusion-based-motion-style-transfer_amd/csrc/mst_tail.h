@@ -19,12 +19,13 @@
 // straight from its LDS image).  Waves: wave w owns weight rows [32 w, 32 w + 32) of every slab and both 32-token tiles.
 //
 //   phase P   16 steps: slab (ks, nh) = W_out rows [256 nh, +256), k [64 ks, +64)          acc[nh][m] += W . att^T
-//   LN1       accumulators -> LDS transpose -> + b_out + x -> LayerNorm -> x1 hi/lo (global scratch)
+//   LN1       accumulators -> LDS transpose -> + b_out + x (requested before phase P) -> LayerNorm -> x1: fp32 rows stay in
+//             registers (LayerNorm2's residual), the f16 operand copy goes to a global scratch for the activation ring
 //   phase F   4 chunks of 256 hidden features, 16 steps each:
 //               8 steps  slab = W1 rows of the chunk, k [64 ks, +64)                        acch[m] += W1 . x1^T
 //               GELU(acch + b1) -> H image (LDS, 4 activation slabs)
 //               8 steps  slab (ks2, nh) = W2 rows [256 nh, +256), k = chunk's [64 ks2, +64)  acc[nh][m] += W2 . H^T
-//   LN2       + b2 + x1 -> LayerNorm -> the stream (hi/lo), in place for the next layer
+//   LN2       + b2 + x1 (registers) -> LayerNorm -> the stream (hi/lo), in place for the next layer
 #pragma once
 #include "mst_common.h"
 #include "mst_gemm_dma.h"
@@ -98,12 +99,83 @@ __device__ __forceinline__ void tail_glds1(unsigned voff, unsigned long long sba
                  : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
 }
 
+
+// LayerNorm of a 64 x 512 accumulator tile in ROW layout.  The accumulators (lane = token) are transposed through `scratch`
+// (64 rows of 2064 B, conflict-free for 16-B accesses); afterwards wave w owns rows [8 w, 8 w + 8) and a lane holds features
+// [4 lane, +4) and [256 + 4 lane, +4) of each: statistics are wave-level shuffles.  `ra` / `rb` carry the residual in and the
+// normalised rows out -- in the same registers, so LayerNorm1's output stays on chip as LayerNorm2's residual.
+struct TailRows { f32x4 a[8], b[8]; };
+
+__device__ __forceinline__ void tail_layernorm(f32x16 (&acc)[1][2][2], const TailLane& lc, char* scratch, const float* __restrict__ bias,
+                                               const float* __restrict__ gamma, const float* __restrict__ beta, TailRows& rv) {
+    constexpr int LD = MST_D * 4 + 16;
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        char* trow = scratch + lc.tok(m) * LD;
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const f32x4 v = {acc[0][m][n][4 * g], acc[0][m][n][4 * g + 1], acc[0][m][n][4 * g + 2], acc[0][m][n][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(trow + lc.feat(n, g) * 4) = v;
+            }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fa = lane * 4, fb = 256 + lane * 4;
+    const f32x4 ba = *reinterpret_cast<const f32x4*>(bias + fa), bb = *reinterpret_cast<const f32x4*>(bias + fb);
+    float s[8], s2[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int row = wave * 8 + r;
+        const f32x4 ta = *reinterpret_cast<const f32x4*>(scratch + row * LD + fa * 4);
+        const f32x4 tb = *reinterpret_cast<const f32x4*>(scratch + row * LD + fb * 4);
+        s[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            rv.a[r][i] = ta[i] + ba[i] + rv.a[r][i];
+            rv.b[r][i] = tb[i] + bb[i] + rv.b[r][i];
+            s[r] += rv.a[r][i] + rv.b[r][i];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < 8; r++) s[r] += __shfl_xor(s[r], o);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const float mean = s[r] * (1.0f / MST_D);
+        s2[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            rv.a[r][i] -= mean;
+            rv.b[r][i] -= mean;
+            s2[r] += rv.a[r][i] * rv.a[r][i] + rv.b[r][i] * rv.b[r][i];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < 8; r++) s2[r] += __shfl_xor(s2[r], o);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + fa), gb = *reinterpret_cast<const f32x4*>(gamma + fb);
+    const f32x4 ea = *reinterpret_cast<const f32x4*>(beta + fa), eb = *reinterpret_cast<const f32x4*>(beta + fb);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const float rstd = 1.0f / sqrtf(s2[r] * (1.0f / MST_D) + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            rv.a[r][i] = rv.a[r][i] * rstd * ga[i] + ea[i];
+            rv.b[r][i] = rv.b[r][i] * rstd * gb[i] + eb[i];
+        }
+    }
+}
+
 __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att, const f16* __restrict__ wt,
                                                     const float* __restrict__ b_out, const float* __restrict__ g1, const float* __restrict__ be1,
                                                     const float* __restrict__ b1, const float* __restrict__ b2,
                                                     const float* __restrict__ g2, const float* __restrict__ be2,
                                                     f16* __restrict__ hx, f16* __restrict__ hl,
-                                                    f16* __restrict__ x1h, f16* __restrict__ x1l, int M) {
+                                                    f16* __restrict__ x1h, int M) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using C = TailCfg;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -171,6 +243,20 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
             if (((s + 2) & 1) == 0) issue_a(att, (s + 2) >> 1, ((s + 2) >> 1) % C::NA);
         }
     };
+    // LayerNorm1's residual (the stream rows of this tile, hi + lo) is requested NOW, as raw f16 pairs, and first touched after
+    // the out-proj loop: its HBM latency and its 128 KB per tile hide behind the weight stream of phase P.
+    const int row_lane = threadIdx.x & 63;
+    const int fa = row_lane * 4, fb = 256 + row_lane * 4;
+    uint2 rh_a[8], rl_a[8], rh_b[8], rl_b[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int tok = tok0 + 8 * wave + r;
+        const size_t off = (size_t)(tok < M ? tok : M - 1) * MST_D;
+        rh_a[r] = *reinterpret_cast<const uint2*>(hx + off + fa);
+        rl_a[r] = *reinterpret_cast<const uint2*>(hl + off + fa);
+        rh_b[r] = *reinterpret_cast<const uint2*>(hx + off + fb);
+        rl_b[r] = *reinterpret_cast<const uint2*>(hl + off + fb);
+    }
     issue_w(0); issue_a(att, 0, 0);
     issue_w(1);
 #pragma unroll 1
@@ -184,9 +270,23 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
     __syncthreads();                                       // ring dead (no DMA in flight): LayerNorm scratch overlays it
 
     const TailLane lm;
-    {
-        DEpiResidLN ln1{b_out, g1, be1, x1h, x1l, M, hx, hl};          // residual = the stream, result -> x1 scratch
-        ln1.run_map<C::BT, 2, 2>(acc, lm, tok0, smem);
+    TailRows rv;                                           // residual in, x1 = LayerNorm1 output out; lives through phase F
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        rv.a[r] = join4_f16(rh_a[r], rl_a[r]);
+        rv.b[r] = join4_f16(rh_b[r], rl_b[r]);
+    }
+    tail_layernorm(acc, lm, smem, b_out, g1, be1, rv);
+    // x1's f16 operand copy -> global scratch: phase F re-reads it through the activation ring (L2-hot; the LDS has no room
+    // for a resident 64 KB image beside the weight ring).  The fp32 rows stay in `rv` as LayerNorm2's residual.
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int tok = tok0 + 8 * wave + r;
+        if (tok < M) {
+            const size_t off = (size_t)tok * MST_D;
+            *reinterpret_cast<uint2*>(x1h + off + fa) = pack4_f16(rv.a[r][0], rv.a[r][1], rv.a[r][2], rv.a[r][3]);
+            *reinterpret_cast<uint2*>(x1h + off + fb) = pack4_f16(rv.b[r][0], rv.b[r][1], rv.b[r][2], rv.b[r][3]);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's x1 stores have reached L2 ...
     __syncthreads();                                       // ... and everybody's: the ring may re-read x1h, the scratch is dead
@@ -248,9 +348,20 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
         }
     }
     __syncthreads();
-    {
-        DEpiResidLN ln2{b2, g2, be2, hx, hl, M, x1h, x1l};             // residual = x1, result -> the stream
-        ln2.run_map<C::BT, 2, 2>(acc, lm, tok0, smem);
+    tail_layernorm(acc, lm, smem, b2, g2, be2, rv);        // residual = x1 (still in registers), result = the stream rows
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int tok = tok0 + 8 * wave + r;
+        if (tok < M) {
+            const size_t off = (size_t)tok * MST_D;
+            uint2 h, l;
+            split4_f16(rv.a[r], h, l);
+            *reinterpret_cast<uint2*>(hx + off + fa) = h;
+            *reinterpret_cast<uint2*>(hl + off + fa) = l;
+            split4_f16(rv.b[r], h, l);
+            *reinterpret_cast<uint2*>(hx + off + fb) = h;
+            *reinterpret_cast<uint2*>(hl + off + fb) = l;
+        }
     }
 }
 
