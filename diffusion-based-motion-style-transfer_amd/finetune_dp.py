@@ -31,7 +31,8 @@ _LAYER = re.compile(r"seqTransEncoder\.layers\.(\d+)\.")
 
 
 class LayerBucketReducer:
-    def __init__(self, model, process_group=None):
+    def __init__(self, model, process_group=None, native=None):
+        """native: None = decide (an engine-backed model on the GPU), False = per-parameter hooks (any torch-op model)."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.enabled = True                  # False: fill the buckets but skip the collective (timing the exchange away)
@@ -40,7 +41,7 @@ class LayerBucketReducer:
             raise ValueError("LayerBucketReducer: the model has no trainable parameter")
         # native training node (GPU): gradients are written by the kernels, autograd still runs (empty) AccumulateGrad nodes
         # for the parameters, so per-parameter hooks must NOT be used there
-        self.native = getattr(model, "train_backend", "torch") == "native" and all(p.is_cuda for _, p in named)
+        self.native = (hasattr(model, "mst_engine") and all(p.is_cuda for _, p in named)) if native is None else bool(native)
         by_layer = {}
         for n, p in named:
             m = _LAYER.match(n)

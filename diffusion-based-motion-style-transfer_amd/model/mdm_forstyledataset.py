@@ -3,15 +3,14 @@
 arguments, attributes and state-dict key layout (so reference checkpoints load and fine-tuned
 checkpoints save in the reference's 96-tensor layout, train/training_loop.py:312-348).
 
-Two execution paths per module:
+The arithmetic has ONE implementation, the HIP library; the nn.Module containers below exist for the state-dict layout.
   * inference (no autograd graph needed): `forward` hands x, t and the text embedding to the native
     engine (csrc/, one HIP launch sequence); sampling loops bypass even that and run whole loops
     natively (see diffusion/gaussian_diffusion.py).  Weights are re-uploaded when parameters change.
-  * autograd (fine-tuning, model.train()): the trainable encoder stack is ONE autograd node backed by
-    the engine's training kernels (model/native_stack.py: activation tape + dropout forward, HIP
-    backward); the frozen projections around it are a handful of torch ops.  `train_backend = "torch"`
-    on an instance evaluates the stack with torch ops instead (the tests' fp32 reference, and the
-    CPU-only gloo tests of the gradient reducer).
+  * autograd (fine-tuning, model.train()): the whole model call is ONE autograd node backed by the engine's training
+    kernels (model/native_stack.py: activation tape + dropout forward, HIP backward).
+There is no torch-op evaluation of the stacks here: CPU tensors raise.  (The tests carry their own fp32 reference,
+tests/torch_reference.py, and install it on an instance when they need one.)
 CLIP stays third-party: `encode_text` uses the `clip` package when it is installed, a callable set
 with `set_text_encoder`, or a precomputed `y['text_embed']` ([B, clip_dim]).
 """
@@ -149,35 +148,29 @@ class _EngineHost:
         self.mst_prepare(eng, y, False)
         return eng.forward(x, timesteps)
 
-    train_backend = "native"          # or "torch" (explicit opt-in; see the module docstring)
-
-    def __setattr__(self, name, value):
-        super().__setattr__(name, value)
-        if name == "train_backend":               # one switch for the module and the engine hosts inside it
-            for child in self.modules():
-                if child is not self and isinstance(child, _EngineHost):
-                    nn.Module.__setattr__(child, name, value)
-
     def _encoder_stack(self, seq, key_keep=None):
-        """seqTransEncoder(seq) inside an autograd graph; seq: [S, B, d]; key_keep: None or bool [B, S]."""
-        if self.train_backend == "torch":
-            if key_keep is None:
-                return self.seqTransEncoder(seq)
-            return self.seqTransEncoder(seq, src_key_padding_mask=~key_keep)
-        if self.train_backend != "native":
-            raise ValueError(f"train_backend must be 'native' or 'torch', not {self.train_backend!r}")
+        """seqTransEncoder(seq) as the native training node; seq: [S, B, d]; key_keep: None or bool [B, S].
+        Inside an autograd graph it is one node (input gradient, parameter gradients when they are trainable); without one
+        the same kernels run with dropout off and the activation tape is dropped."""
         if seq.device.type != "cuda":
-            raise RuntimeError("the native training path runs on the GPU only; call .to('cuda') "
-                               "(set train_backend = 'torch' explicitly to evaluate the stack with torch ops)")
+            raise RuntimeError("the native encoder stack runs on the GPU only; call .to('cuda') (there is no CPU fallback)")
         from .native_stack import EncoderStackFn, stack_parameters
-        p = self.seqTransEncoder.layers[0].dropout.p if self.seqTransEncoder.training else 0.0
-        return EncoderStackFn.apply(seq, self, float(p), key_keep, *stack_parameters(self.seqTransEncoder))
+        if torch.is_grad_enabled() and (seq.requires_grad or any(p.requires_grad for p in self.seqTransEncoder.parameters())):
+            p = self.seqTransEncoder.layers[0].dropout.p if self.seqTransEncoder.training else 0.0
+            return EncoderStackFn.apply(seq, self, float(p), key_keep, *stack_parameters(self.seqTransEncoder))
+        S, B, d = seq.shape
+        eng = self.mst_engine(B, S - 1)
+        keep = None if key_keep is None else key_keep.to(torch.uint8).contiguous()
+        out, _tape = eng.train_forward(seq.detach().permute(1, 0, 2).contiguous(), 0.0, 0, key_keep=keep)
+        return out.permute(1, 0, 2)
 
     def _native_train_call(self, x, timesteps, y):
-        """model(x, t, y) inside an autograd graph as ONE native node (DenoiserTrainFn); None when this module cannot use it
-        (CPU tensors, train_backend 'torch', no text conditioning) and the caller should assemble the graph from torch ops."""
-        if self.train_backend != "native" or not x.is_cuda or 'text' not in getattr(self, "cond_mode", ""):
-            return None
+        """model(x, t, y) inside an autograd graph as ONE native node (DenoiserTrainFn)."""
+        if not x.is_cuda:
+            raise RuntimeError("the native training path runs on the GPU only; call .to('cuda') (there is no CPU fallback)")
+        if 'text' not in getattr(self, "cond_mode", ""):
+            raise NotImplementedError("the native training node is built for the text-conditioned models the scripts create "
+                                      "(utils/parser_util.py get_cond_mode)")
         from .native_stack import DenoiserTrainFn, stack_parameters
         prior = self._prior()
         enc = y['text_embed'] if y.get('text_embed') is not None else prior.encode_text(y['text'])
@@ -280,12 +273,7 @@ class MDM(nn.Module, _EngineHost):
     def forward(self, x, timesteps, y=None):
         if not self._wants_autograd(x):
             return self._native_forward(x, timesteps, y)
-        out = self._native_train_call(x, timesteps, y)
-        if out is not None:
-            return out
-        emb = self._condition(timesteps, y)
-        seq = self.sequence_pos_encoder(torch.cat((emb, self.input_process(x)), axis=0))
-        return self.output_process(self._encoder_stack(seq)[1:])
+        return self._native_train_call(x, timesteps, y)
 
     def train(self, mode=True):
         return super().train(mode)
@@ -293,9 +281,9 @@ class MDM(nn.Module, _EngineHost):
 
 class MotionEncoder(nn.Module, _EngineHost):
     """The frozen 'semantic discriminator' (:11-124): mu/sigma query tokens + frames through 8 masked
-    encoder layers; borrows the prior's input projection and positional table.  Inside an autograd graph
-    (the fine-tune objective needs its INPUT gradient) the masked stack runs as the native training node with a
-    key-padding mask and no parameter gradients; without a graph it is plain torch ops (not on the sampling path)."""
+    encoder layers; borrows the prior's input projection and positional table.  The masked stack runs natively with a
+    key-padding mask: inside an autograd graph (the fine-tune objective needs its INPUT gradient) as the training node with
+    no parameter gradients, without a graph through the same kernels with the tape dropped."""
 
     def __init__(self, modeltype, njoints, nfeats, num_actions, translation, pose_rep, glob, glob_rot,
                  latent_dim=256, ff_size=1024, num_layers=8, num_heads=4, dropout=0.1,
@@ -355,10 +343,7 @@ class MotionEncoder(nn.Module, _EngineHost):
         queries = torch.cat((self.muQuery[:1][None].repeat(1, bs, 1), self.sigmaQuery[:1][None].repeat(1, bs, 1)), axis=0)
         seq = self.mdm_model.sequence_pos_encoder(torch.cat((queries, frames), axis=0))
         keep = torch.cat((torch.ones((bs, 2), dtype=bool, device=x.device), keep), axis=1)
-        if torch.is_grad_enabled() and seq.requires_grad and seq.is_cuda and self.train_backend == "native":
-            final = self._encoder_stack(seq, key_keep=keep)
-        else:
-            final = self.seqTransEncoder(seq, src_key_padding_mask=~keep)
+        final = self._encoder_stack(seq, key_keep=keep)        # native, with or without an autograd graph
         return final[0], enc_text
 
     # ---- engine plumbing: own (frozen) encoder layers + the prior's projections
@@ -435,12 +420,4 @@ class StyleDiffusion(nn.Module, _EngineHost):
     def forward(self, x, timesteps, y=None):
         if not self._wants_autograd(x):
             return self._native_forward(x, timesteps, y)
-        out = self._native_train_call(x, timesteps, y)
-        if out is not None:
-            return out
-        prior = self._prior()
-        emb = prior.embed_timestep(timesteps)
-        enc = y['text_embed'] if y.get('text_embed') is not None else prior.encode_text(y['text'])
-        emb = emb + prior.embed_text(self.mask_cond(enc, force_mask=y.get('uncond', False)))
-        seq = prior.sequence_pos_encoder(torch.cat((emb, prior.input_process(x)), axis=0))
-        return prior.output_process(self._encoder_stack(seq)[1:])
+        return self._native_train_call(x, timesteps, y)

@@ -86,8 +86,7 @@ class TrainInpaintingLoop:
         if diffusion is not None:
             self.schedule_sampler_type = 'uniform'
             self.schedule_sampler = create_named_schedule_sampler(self.schedule_sampler_type, diffusion)
-        opt_cls = FusedAdamW if self.device.type == "cuda" else torch.optim.AdamW
-        self.opt = opt_cls(self.mp_trainer.master_params, lr=self.lr, weight_decay=self.weight_decay)
+        self.opt = FusedAdamW(self.mp_trainer.master_params, lr=self.lr, weight_decay=self.weight_decay)
         if self.resume_step:
             self._load_optimizer_state()
         self.use_ddp = False

@@ -8,6 +8,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import mst_amd  # noqa: F401
+import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))      # spawned workers import tests/torch_reference.py too
 
 
 def _free_port():
@@ -25,7 +27,8 @@ def _model():
     sd = {k: torch.from_numpy(syn.tensor_for(3, k, tuple(v.shape)).copy()) for k, v in m.state_dict().items()
           if not k.endswith(".pe") and "clip_model" not in k}
     m.load_state_dict(sd, strict=False)
-    m.train_backend = "torch"      # CPU ranks: the subject here is the reducer, not the kernels
+    from torch_reference import use_torch_ops
+    use_torch_ops(m)               # CPU ranks: the subject here is the reducer, not the kernels
     return m.train()
 
 
@@ -110,7 +113,7 @@ def _worker_native_protocol(rank, ws, port, q):
         params = [p for p in m.parameters() if p.requires_grad]
         local = torch.autograd.grad(_loss(m, 2 * rank, 2 * rank + 2), params)
         red = LayerBucketReducer(m)
-        red.native = True                                   # as on GPU parameters with train_backend == "native"
+        red.native = True                                   # as with an engine-backed model on the GPU
         m.__dict__["_native_grads_ready"] = red._native_grads_ready
         red.zero_grad()
         torch._foreach_add_([p.grad for p in params], list(local))          # GradSink.flush, existing-gradient branch

@@ -21,6 +21,8 @@ from mst_amd import synthetic as syn
 from mst_amd.engine import LAYER_TENSORS
 from conftest import SEED, rel_l2
 
+from torch_reference import use_native, use_torch_ops
+
 pytestmark = pytest.mark.gpu
 
 TOL_FWD = 1e-3
@@ -220,12 +222,12 @@ def _model_batch(B=3, T=76):
 
 def test_model_autograd_native_vs_torch_ops():
     """StyleDiffusion.forward inside an autograd graph: the native stack node (default) against the same
-    module evaluated with torch ops (train_backend='torch'), eval mode (no dropout)."""
+    module evaluated with torch ops (tests/torch_reference.py), eval mode (no dropout)."""
     m = _style_model().eval()
     x, t, y, tgt = _model_batch()
     res = {}
     for backend in ("native", "torch"):
-        m.train_backend = backend
+        (use_torch_ops if backend == "torch" else use_native)(m)
         m.zero_grad()
         xin = x.clone().requires_grad_(True)
         out = m(xin, t, y=y)
@@ -233,7 +235,7 @@ def test_model_autograd_native_vs_torch_ops():
         loss.backward()
         res[backend] = (out.detach(), float(loss), xin.grad.clone(),
                         {n: p.grad.clone() for n, p in m.named_parameters() if p.requires_grad})
-    m.train_backend = "native"
+    use_native(m)
     assert rel_l2(res["native"][0].cpu().numpy(), res["torch"][0].cpu().numpy()) <= TOL_FWD
     assert abs(res["native"][1] - res["torch"][1]) <= 1e-3 * abs(res["torch"][1])
     assert rel_l2(res["native"][2].cpu().numpy(), res["torch"][2].cpu().numpy()) <= TOL_GRAD
@@ -309,13 +311,12 @@ def test_motion_encoder_masked_stack_native_vs_torch_ops():
     w = torch.from_numpy(syn.normal(3, "tr/w", (3, 512))).to(_dev())
     res = {}
     for backend in ("native", "torch"):
-        m.train_backend = backend
-        assert enc.train_backend == backend                   # one switch for the hosts inside
+        (use_torch_ops if backend == "torch" else use_native)(m)
         xin = x.clone().requires_grad_(True)
         mu, _ = enc(xin, y=yy)
         (mu * w).sum().backward()
         res[backend] = (mu.detach(), xin.grad.clone())
-    m.train_backend = "native"
+    use_native(m)
     assert rel_l2(res["native"][0].cpu().numpy(), res["torch"][0].cpu().numpy()) <= TOL_FWD
     assert rel_l2(res["native"][1].cpu().numpy(), res["torch"][1].cpu().numpy()) <= TOL_GRAD
     assert all(p.grad is None for p in enc.parameters())      # frozen: no parameter gradient is produced

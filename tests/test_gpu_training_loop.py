@@ -2,7 +2,7 @@
 the reference's own loop, against what the REFERENCE produced on the CPU for the same 12 seeded steps
 (tests/golden/train_loop.npz; dropout off, every draw recorded).
 
-Two runs: train_backend='torch' (fp32 torch ops on the GPU + the fused optimizer kernel: isolates the optimizer and the
+Two runs: tests/torch_reference.py installed on the model (fp32 torch ops on the GPU + the fused optimizer kernel: isolates the optimizer and the
 loop) and the default native backend (f16 MFMA operands).  Bars: fp32 path 2e-4 on the loss curve; native path 2e-3
 (operand rounding, and AdamW's sign-like first steps amplify tiny gradient differences into lr-sized parameter
 differences)."""

@@ -22,14 +22,15 @@ class StandInDiffusion:
         return {"loss": reg, "rot_mse": reg.detach().expand(6), "text_cosine": reg.detach()}
 
 
-def test_loop_control_flow_matches_reference_run(golden, tmp_path):
+def test_loop_control_flow_matches_reference_run(golden, tmp_path, monkeypatch):
     from mst_amd.diffusion import logger
     from mst_amd.model.mdm_forstyledataset import StyleDiffusion
     from mst_amd.train.training_loop import TrainInpaintingLoop
     from mst_amd.utils import model_util
     g = golden["train_loop"]
+    import mst_amd.train.training_loop as tl
     model, _, _ = model_util.creat_serval_diffusion(lf.diffusion_args(), StyleDiffusion, "ddim20")
-    model.train_backend = "torch"
+    monkeypatch.setattr(tl, "FusedAdamW", torch.optim.AdamW)       # no GPU here: the product's optimizer kernel raises on CPU tensors
     diffusion = StandInDiffusion()
     diffusion.ts = []
     logger.configure(dir=str(tmp_path))
@@ -38,7 +39,7 @@ def test_loop_control_flow_matches_reference_run(golden, tmp_path):
     lrs = []
     platform = types.SimpleNamespace(report_scalar=lambda **k: None, close=lambda: None)
     loop = TrainInpaintingLoop(args, platform, model, data, diffusion=diffusion, style_data=style_data)
-    assert type(loop.opt) is torch.optim.AdamW                      # CPU parameters: plain torch optimizer
+    assert type(loop.opt) is torch.optim.AdamW                      # the stand-in installed above
     step = loop.opt.step
     loop.opt.step = lambda *a, **k: (lrs.append(loop.opt.param_groups[0]["lr"]), step(*a, **k))[1]
     np.random.seed(SEED % (2 ** 31))

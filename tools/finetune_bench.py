@@ -9,7 +9,7 @@ import time
 import types
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]       # tests/torch_reference.py: the fp32 torch-op evaluation compared against
 import numpy as np
 import torch
 
@@ -44,8 +44,11 @@ from mst_amd.optim import FusedAdamW
 opts = {"native": FusedAdamW(model.parameters_wo_enc(), lr=1e-5), "torch": torch.optim.AdamW(model.parameters_wo_enc(), lr=1e-5)}
 
 
+backend = "native"
+
+
 def iteration(autocast=False):
-    opt = opts[model.train_backend]
+    opt = opts[backend]
     opt.zero_grad(set_to_none=True)
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
         terms = d_ddim.few_shot_style_finetune_losses(model, t2m, tt, content, style, skip_steps=700, model_kwargs=y1,
@@ -67,11 +70,12 @@ def timed(fn, iters, warm=1):
 
 
 res = {"batch": B, "shape": [F, 1, T], "objective": "few_shot_style_finetune_losses ddim20 skip700 + AdamW step"}
-model.train_backend = "native"
 res["native_ms"] = timed(iteration, int(os.environ.get("FB_ITERS", 3)))
 res["native_loss"] = iteration()
 if not os.environ.get("FB_NATIVE_ONLY"):
-    model.train_backend = "torch"
+    from torch_reference import use_torch_ops
+    use_torch_ops(model)
+    backend = "torch"
     res["torch_fp32_ms"] = timed(iteration, 2)
     res["torch_fp32_loss"] = iteration()
     res["torch_bf16_ms"] = timed(lambda: iteration(True), 2)

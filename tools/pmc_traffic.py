@@ -3,7 +3,7 @@
 /opt/skills/guides/MI355X_MICROARCH.md: both counters are in KiB; FETCH_SIZE under-counts wide coalesced reads 2x on gfx950."""
 import collections, csv, glob, json, sys
 
-FAMILIES = (("k_qkv_attention", "qkv_attention_fused"), ("DEpiResidLNE", "ln_gemm"), ("DEpiBiasF16ILb1E", "ffn1_gelu_gemm"),
+FAMILIES = (("k_qkv_attention", "qkv_attention_fused"), ("k_layer_tail", "layer_tail_fused"), ("DEpiResidLNE", "ln_gemm"), ("DEpiBiasF16ILb1E", "ffn1_gelu_gemm"),
             ("DEpiEmbedInE", "embed_in"), ("DEpiEmbedOut", "embed_out_step"))
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sys.argv[1:]:
