@@ -51,6 +51,11 @@ SIGNATURES = {
     "mst_step_epilogue": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_int32, C.c_int32,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mst_step_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64,
+                                    C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+    "mst_masked_l2": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mst_text_cosine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mst_philox_normal": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_uint32, C.c_void_p]),
     "mst_train_tape_bytes": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32]),
     "mst_train_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_uint64, C.c_void_p,

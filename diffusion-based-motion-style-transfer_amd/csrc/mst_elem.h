@@ -191,6 +191,111 @@ __global__ void k_step_epilogue(const float* __restrict__ tab, int nsteps, float
     }
 }
 
+// Backward of the fused step for the `*_with_grad` samplers (inpainting_gaussian_diffusion.py:66-123, :179-239): both
+// outputs are affine in the model output,
+//     pred   = out (1 - mask) + motion mask
+//     sample = c1 pred + c2 x + sigma noise                                   (ancestral, gaussian_diffusion.py:404-412)
+//     sample = sqrt(abar_prev) pred + dir (srac x - pred) / srm1ac + ...      (DDIM, :157-177)
+// so d out = (g_pred + g_sample d sample/d pred) (1 - mask).  One launch instead of autograd's chain of elementwise nodes.
+template <int SAMPLER>
+__global__ void k_step_backward(const float* __restrict__ tab, int nsteps, float eta, const float* __restrict__ g_sample,
+                                const float* __restrict__ g_pred, const float* __restrict__ mask, int has_blend,
+                                const long long* __restrict__ t, long long per_clip, float* __restrict__ d_out) {
+    const int clip = blockIdx.y;
+    const StepCoef sc = step_coef(tab, nsteps, (int)t[clip], eta);
+    const float dsdp = SAMPLER == 0 ? sc.c1 : sc.sq_abp - sc.dir / sc.srm1ac;
+    const size_t base = (size_t)clip * per_clip;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per_clip; i += (long long)gridDim.x * blockDim.x) {
+        const size_t idx = base + i;
+        float g = g_pred ? g_pred[idx] : 0.f;
+        if (g_sample) g += g_sample[idx] * dsdp;
+        if (has_blend) g *= 1.0f - mask[idx];
+        d_out[idx] = g;
+    }
+}
+
+// K13a: masked_l2 (gaussian_diffusion.py:223-235): loss[n] = sum_{f,t} (a - b)^2 mask[n, t] / (sum_t mask[n, t] * F), one
+// workgroup per sample; a / mask may be broadcast over n (stride 0: `x_style_start.expand(num_step, ...)`, :1380).
+__global__ __launch_bounds__(256) void k_masked_l2_fwd(const float* __restrict__ a, long long a_stride, const float* __restrict__ b,
+                                                       const float* __restrict__ mask, long long m_stride, int F, int T,
+                                                       float* __restrict__ loss) {
+    __shared__ float red[2][4];
+    const int n = blockIdx.x;
+    const float* an = a + (size_t)n * a_stride;
+    const float* bn = b + (size_t)n * F * T;
+    const float* mn = mask + (size_t)n * m_stride;
+    float s = 0.f, ms = 0.f;
+    for (int i = threadIdx.x; i < F * T; i += 256) {
+        const int tt = i % T;
+        const float d = an[i] - bn[i];
+        s += d * d * mn[tt];
+    }
+    for (int tt = threadIdx.x; tt < T; tt += 256) ms += mn[tt];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); ms += __shfl_xor(ms, o); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = ms; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float st = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);      // fixed order: run-to-run deterministic
+        const float mt = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        loss[n] = st / (mt * (float)F);
+    }
+}
+// d b[n, f, t] = -2 (a - b) mask[t] / (sum mask * F) * g[n]   (d a is its negative)
+__global__ __launch_bounds__(256) void k_masked_l2_bwd(const float* __restrict__ a, long long a_stride, const float* __restrict__ b,
+                                                       const float* __restrict__ mask, long long m_stride, int F, int T,
+                                                       const float* __restrict__ g, float* __restrict__ d_b) {
+    __shared__ float red[4];
+    const int n = blockIdx.y;
+    const float* mn = mask + (size_t)n * m_stride;
+    float ms = 0.f;
+    for (int tt = threadIdx.x; tt < T; tt += 256) ms += mn[tt];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ms += __shfl_xor(ms, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ms;
+    __syncthreads();
+    const float k = -2.0f * g[n] / (((red[0] + red[1]) + (red[2] + red[3])) * (float)F);
+    const float* an = a + (size_t)n * a_stride;
+    const float* bn = b + (size_t)n * F * T;
+    float* dn = d_b + (size_t)n * F * T;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < F * T; i += gridDim.x * 256) dn[i] = k * (an[i] - bn[i]) * mn[i % T];
+}
+
+// K13b: text_cosine (gaussian_diffusion.py:1384-1388): mean_b (1 - cos(f_b / |f_b|, m_b / |m_b|)) with torch's
+// cosine_similarity(eps = 1e-6) on the already normalised rows.  One wave per row, one workgroup in all (B <= a few hundred
+// rows of 512: latency, not bandwidth); rows are summed in index order.  mode 0: loss[0]; mode 1: d m (g = dL/dloss).
+__global__ __launch_bounds__(256) void k_text_cosine(const float* __restrict__ f, const float* __restrict__ m, int B, int D,
+                                                     int mode, const float* __restrict__ g, float* __restrict__ out) {
+    __shared__ float rowv[1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int b = wave; b < B; b += 4) {
+        const float* fb = f + (size_t)b * D;
+        const float* mb = m + (size_t)b * D;
+        float ff = 0.f, mm = 0.f, fm = 0.f;
+        for (int i = lane; i < D; i += 64) { ff += fb[i] * fb[i]; mm += mb[i] * mb[i]; fm += fb[i] * mb[i]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { ff += __shfl_xor(ff, o); mm += __shfl_xor(mm, o); fm += __shfl_xor(fm, o); }
+        const float nf = sqrtf(ff), nm = sqrtf(mm);
+        // cosine of the unit rows f / nf and m / nm; cosine_similarity's own eps clamp acts on norms that are 1 here
+        const float c = fm / (nf * nm);
+        if (mode == 0) {
+            if (lane == 0 && b < 1024) rowv[b] = 1.0f - c;
+        } else {
+            // d(1 - c)/d m = -(fh / nm - c m / nm^2) with fh = f / nf; mean over B and the upstream gradient g[0]
+            const float k = -g[0] / (float)B;
+            for (int i = lane; i < D; i += 64) out[(size_t)b * D + i] = k * (fb[i] / (nf * nm) - c * mb[i] / (nm * nm));
+        }
+    }
+    if (mode == 0) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float s = 0.f;
+            for (int b = 0; b < B; b++) s += rowv[b];
+            out[0] = s / (float)B;
+        }
+    }
+}
+
 // same counter mapping as the fused epilogue: element (clip, f, t) <- component t & 3 of counter (t >> 2, f, clip, step)
 __global__ void k_philox_normal(float* __restrict__ out, int F, int T, unsigned long long seed, unsigned step) {
     const int clip = blockIdx.y;

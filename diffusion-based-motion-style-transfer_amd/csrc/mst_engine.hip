@@ -953,6 +953,49 @@ extern "C" int mst_step_epilogue(const mst_schedule* s, const float* model_out, 
     return 0;
 }
 
+extern "C" int mst_step_backward(const mst_schedule* s, const float* g_sample, const float* g_pred, const float* mask,
+                                 int32_t has_blend, const int64_t* t, int32_t batch, int64_t per_clip, int32_t sampler, float eta,
+                                 float* d_model_out, void* stream) {
+    if (!s || !t || !d_model_out || batch < 1 || per_clip < 1 || (!g_sample && !g_pred) || (has_blend && !mask))
+        return fail("mst_step_backward: bad arguments");
+    ON_DEVICE(s->device);
+    int gx = (int)((per_clip + 255) / 256);
+    if (gx > 2048) gx = 2048;
+    if (sampler == MST_SAMPLER_DDPM)
+        hipLaunchKernelGGL(k_step_backward<0>, dim3(gx, batch), dim3(256), 0, (hipStream_t)stream, s->tab, s->n, eta, g_sample, g_pred, mask,
+                           has_blend, (const long long*)t, (long long)per_clip, d_model_out);
+    else if (sampler == MST_SAMPLER_DDIM)
+        hipLaunchKernelGGL(k_step_backward<1>, dim3(gx, batch), dim3(256), 0, (hipStream_t)stream, s->tab, s->n, eta, g_sample, g_pred, mask,
+                           has_blend, (const long long*)t, (long long)per_clip, d_model_out);
+    else
+        return fail("mst_step_backward: bad sampler %d", sampler);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mst_masked_l2(const float* a, int64_t a_stride, const float* b, const float* mask, int64_t mask_stride, int32_t n,
+                             int32_t feats, int32_t frames, const float* g, float* out, void* stream) {
+    if (!a || !b || !mask || !out || n < 1 || feats < 1 || frames < 1) return fail("mst_masked_l2: bad arguments");
+    if (!g)
+        hipLaunchKernelGGL(k_masked_l2_fwd, dim3(n), dim3(256), 0, (hipStream_t)stream, a, (long long)a_stride, b, mask, (long long)mask_stride,
+                           feats, frames, out);
+    else {
+        int gx = (feats * frames + 255) / 256;
+        if (gx > 64) gx = 64;
+        hipLaunchKernelGGL(k_masked_l2_bwd, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, a, (long long)a_stride, b, mask,
+                           (long long)mask_stride, feats, frames, g, out);
+    }
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mst_text_cosine(const float* f, const float* m, int32_t batch, int32_t dim, const float* g, float* out, void* stream) {
+    if (!f || !m || !out || batch < 1 || batch > 1024 || dim < 1) return fail("mst_text_cosine: bad arguments (batch 1..1024)");
+    hipLaunchKernelGGL(k_text_cosine, dim3(1), dim3(256), 0, (hipStream_t)stream, f, m, batch, dim, g ? 1 : 0, g, out);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int mst_philox_normal(float* out, int32_t batch, int32_t feats, int32_t frames, uint64_t seed, uint32_t step,
                                  void* stream) {
     if (!out || batch < 1 || feats < 1 || frames < 1) return fail("mst_philox_normal: bad arguments");

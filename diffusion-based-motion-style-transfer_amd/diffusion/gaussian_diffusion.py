@@ -11,9 +11,10 @@ _extract_into_tensor :1605-1618, schedules :22-66), but the arithmetic runs in t
   * any other model callable
         -> the model runs as given; blend / posterior mean / noise add are one fused HIP kernel
            (mst_step_epilogue), q_sample another (mst_q_sample).
-  * `*_with_grad` variants (fine-tuning) keep x0-hat in the autograd graph, so
-    their few elementwise lines are torch ops on the GPU; the model call inside them runs the native training node
-    (model/native_stack.py).
+  * `*_with_grad` variants (fine-tuning) keep x0-hat in the autograd graph: the model call
+    inside them is the native training node (model/native_stack.py), the step algebra behind it ONE autograd node over the
+    fused step kernel and its backward kernel, the objective's reductions (masked L2, text cosine) one node each
+    (diffusion/fused_ops.py).
 
 Nothing here touches `oracle/`; CPU tensors are rejected instead of silently computed on the host.
 """
@@ -185,8 +186,12 @@ class GaussianDiffusion:
 
     # ------------------------------------------------------------------------------ small helpers
     def masked_l2(self, a, b, mask):
-        loss = (self.l2_loss(a, b) * mask.float()).flatten(1).sum(1)
-        return loss / (mask.flatten(1).sum(1) * (a.shape[1] * a.shape[2]))
+        """sum((a - b)^2 * mask) / (sum(mask) * njoints * nfeats) per sample (reference :223-235): one fused reduction
+        (fused_ops.MaskedL2Fn); a and mask may be expand()ed views of one sample."""
+        from .fused_ops import MaskedL2Fn
+        if mask.dim() != 4 or mask.shape[1] != 1 or mask.shape[2] != 1:
+            raise NotImplementedError("masked_l2: frame masks of shape [bs, 1, 1, nframes] (what every caller passes)")
+        return MaskedL2Fn.apply(a, b, mask)
 
     def q_mean_variance(self, x_start, t):
         s = x_start.shape
@@ -276,24 +281,31 @@ class GaussianDiffusion:
 
     # -- autograd-carrying variants (fine-tune loss): x0-hat may stay in the graph ---------------
     def _grad_step(self, ddim, model, x, t, clip_denoised, model_kwargs, pred_xstart_in_graph, const_noise=False, eta=0.0):
+        """One `*_with_grad` step (reference inpainting_gaussian_diffusion.py:66-123 / :179-239): the model call is the native
+        training node, everything behind it -- inpainting blend, x0-hat, posterior mean or DDIM update, masked noise -- ONE
+        autograd node over the fused step kernel (fused_ops.FusedStepFn) instead of ~20 elementwise torch ops.  As in the
+        reference the step input is cut from the previous step's graph (`x.detach()`); gradients reach the parameters through
+        every step's x0-hat."""
+        from .fused_ops import FusedStepFn
+        if self.model_mean_type != ModelMeanType.START_X:
+            raise NotImplementedError("this model family predicts x_start (utils/model_util.py:172)")
+        assert t.shape == (x.shape[0],)
         with th.enable_grad():
-            x = x.detach().requires_grad_()
-            out = self.p_mean_variance(model, x, t, clip_denoised=clip_denoised, model_kwargs=model_kwargs)
-        pred = out["pred_xstart"] if pred_xstart_in_graph else out["pred_xstart"].detach()
+            x = x.detach()
+            out = self._model_output(model, x, t, model_kwargs)
         noise = self._draw(x, const_noise)
+        mask, motion = self._inpaint_pair(model_kwargs)
+        if mask is not None:
+            assert out.shape == mask.shape == motion.shape
         nmask = self._noise_mask(model_kwargs)
-        if nmask is not None:
-            noise = noise * (1. - nmask).to(noise.dtype)
-        nz = (t != 0).float().view(-1, *([1] * (x.dim() - 1)))
-        if not ddim:
-            sample = out["mean"] + nz * th.exp(0.5 * out["log_variance"]) * noise
-        else:
-            eps = self._predict_eps_from_xstart(x, t, pred)
-            ab = _extract_into_tensor(self.alphas_cumprod, t, x.shape)
-            abp = _extract_into_tensor(self.alphas_cumprod_prev, t, x.shape)
-            sigma = eta * th.sqrt((1 - abp) / (1 - ab)) * th.sqrt(1 - ab / abp)
-            sample = pred * th.sqrt(abp) + th.sqrt(1 - abp - sigma ** 2) * eps + nz * sigma * noise
-        return {"sample": sample, "pred_xstart": pred}
+        sch = self._schedule(x.device)
+        with th.enable_grad():
+            sample, pred = FusedStepFn.apply(out, x.contiguous().float(), t, noise.contiguous().float(),
+                                             None if (mask if mask is not None else nmask) is None else
+                                             (mask if mask is not None else nmask).contiguous().float(),
+                                             None if motion is None else motion.contiguous().float(), sch,
+                                             _eng.SAMPLER_DDIM if ddim else _eng.SAMPLER_DDPM, eta, nmask is not None, clip_denoised)
+        return {"sample": sample, "pred_xstart": pred if pred_xstart_in_graph else pred.detach()}
 
     def p_sample_with_grad(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
                            pred_xstart_in_graph=False, const_noise=False):
@@ -481,9 +493,8 @@ class GaussianDiffusion:
         terms = {"rot_mse": self.masked_l2(x_style_start.expand(num_step, -1, -1, -1), sample,
                                            mask.expand(num_step, -1, -1, -1))}
         if semantic_guidance:
-            f = text_features / text_features.norm(dim=-1, keepdim=True)
-            m = mu / mu.norm(dim=-1, keepdim=True)
-            terms["text_cosine"] = (1 - th.nn.functional.cosine_similarity(f, m, dim=1, eps=1e-6)).mean()
+            from .fused_ops import TextCosineFn           # normalise both, cosine_similarity, 1 -, mean: one launch each way
+            terms["text_cosine"] = TextCosineFn.apply(text_features.detach(), mu)
             terms["loss"] = terms["rot_mse"].mean() + terms["text_cosine"] * Ls
         else:
             terms["loss"] = terms["rot_mse"].mean()

@@ -180,6 +180,27 @@ int mst_step_epilogue(const mst_schedule* s, const float* model_out_dev, const f
 /* Standard-normal fill with the engine's Philox stream (the generator MST_NOISE_PHILOX uses
  * inside the fused step), so a caller can reproduce in-loop noise: element (clip, f, t) of step
  * `step`.  Replaces th.randn / th.randn_like draws (gaussian_diffusion.py:754, :569). */
+/* Backward of mst_step_epilogue for the `*_with_grad` samplers (diffusion/inpainting_gaussian_diffusion.py:66-123,
+ * :179-239; the fine-tune objective keeps every x0-hat in the autograd graph, gaussian_diffusion.py:1364-1378):
+ *     d_model_out = (g_pred + g_sample * d sample / d pred) * (1 - mask)
+ * g_sample / g_pred: upstream gradients of the two outputs, either may be NULL (= zero).  has_blend: the forward blended
+ * with (mask, motion).  clip_denoised is not differentiated (no caller on this path clips: SURVEY section 9). */
+int mst_step_backward(const mst_schedule* s, const float* g_sample_dev, const float* g_pred_dev, const float* mask_dev,
+                      int32_t has_blend, const int64_t* t_dev, int32_t batch, int64_t per_clip, int32_t sampler, float eta,
+                      float* d_model_out_dev, void* stream);
+
+/* K13 of SURVEY section 2.1 -- the reductions of the fine-tune objective, one launch each way:
+ * mst_masked_l2: `masked_l2` (gaussian_diffusion.py:223-235) of a, b [n][feats][1][frames] with a frame mask
+ *   [n][1][1][frames]; a_stride / mask_stride = elements between consecutive samples (0 = broadcast, the
+ *   `.expand(num_step, ...)` of :1380).  g == NULL: out[n] = loss; g != NULL ([n] upstream gradient): out = dL/db
+ *   ([n][feats][1][frames]; dL/da is its negative).
+ * mst_text_cosine: `(1 - cosine_similarity(f / |f|, m / |m|, eps = 1e-6)).mean()` (:1384-1388) of two [batch][dim]
+ *   matrices.  g == NULL: out[0] = loss; g != NULL ([1]): out = dL/dm ([batch][dim]). */
+int mst_masked_l2(const float* a_dev, int64_t a_stride, const float* b_dev, const float* mask_dev, int64_t mask_stride,
+                  int32_t n, int32_t feats, int32_t frames, const float* g_dev, float* out_dev, void* stream);
+int mst_text_cosine(const float* f_dev, const float* m_dev, int32_t batch, int32_t dim, const float* g_dev, float* out_dev,
+                    void* stream);
+
 int mst_philox_normal(float* out_dev, int32_t batch, int32_t feats, int32_t frames, uint64_t seed,
                       uint32_t step, void* stream);
 

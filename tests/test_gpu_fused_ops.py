@@ -1,0 +1,120 @@
+"""The fine-tune objective's fused glue nodes (diffusion/fused_ops.py) against the reference's torch-op formulas and
+torch autograd: the with-grad step (inpainting_gaussian_diffusion.py:66-123, :179-239), masked_l2
+(gaussian_diffusion.py:223-235) and the text-cosine term (:1384-1388)."""
+import numpy as np
+import pytest
+import torch
+
+import mst_amd  # noqa: F401
+import mst_amd.synthetic as syn
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+SEED = 4242
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+def _extract(arr, t, shape):
+    return torch.from_numpy(np.asarray(arr)).to(dev())[t].float().view(-1, 1, 1, 1).expand(shape)
+
+
+@pytest.mark.parametrize("ddim,eta", [(False, 0.0), (True, 0.0), (True, 0.5)])
+def test_fused_step_node_matches_torch_autograd(ddim, eta):
+    from mst_amd.diffusion.fused_ops import FusedStepFn
+    from mst_amd.engine import SAMPLER_DDIM, SAMPLER_DDPM
+    from mst_amd.diffusion.inpainting_gaussian_diffusion import InpaintingGaussianDiffusion
+    from mst_amd.diffusion import gaussian_diffusion as gd
+    from mst_amd.diffusion.respace import space_timesteps
+    d = InpaintingGaussianDiffusion(use_timesteps=space_timesteps(1000, "ddim20"), betas=gd.get_named_beta_schedule("cosine", 1000),
+                                    model_mean_type=gd.ModelMeanType.START_X, model_var_type=gd.ModelVarType.FIXED_SMALL,
+                                    loss_type=gd.LossType.MSE)
+    B, F, T = 3, 181, 76
+    shape = (B, F, 1, T)
+    out0 = cu(syn.normal(SEED, "fs/out", shape))
+    x = cu(syn.normal(SEED, "fs/x", shape))
+    noise = cu(syn.normal(SEED, "fs/nz", shape))
+    motion = cu(syn.normal(SEED, "fs/motion", shape))
+    mask = cu(syn.root_horizontal_mask(B, F, T))
+    t = torch.tensor([0, 5, 19], device=dev())
+    ws, wp = cu(syn.normal(SEED, "fs/ws", shape)), cu(syn.normal(SEED, "fs/wp", shape))
+    # reference formulas with torch ops (what the fused node replaces)
+    o = out0.clone().requires_grad_(True)
+    pred = o * (1 - mask) + motion * mask
+    nz = noise * (1 - mask)
+    nonzero = (t != 0).float().view(-1, 1, 1, 1)
+    if not ddim:
+        mean = _extract(d.posterior_mean_coef1, t, shape) * pred + _extract(d.posterior_mean_coef2, t, shape) * x
+        sample = mean + nonzero * torch.exp(0.5 * _extract(d.posterior_log_variance_clipped, t, shape)) * nz
+    else:
+        eps = (_extract(d.sqrt_recip_alphas_cumprod, t, shape) * x - pred) / _extract(d.sqrt_recipm1_alphas_cumprod, t, shape)
+        ab, abp = _extract(d.alphas_cumprod, t, shape), _extract(d.alphas_cumprod_prev, t, shape)
+        sigma = eta * torch.sqrt((1 - abp) / (1 - ab)) * torch.sqrt(1 - ab / abp)
+        sample = pred * torch.sqrt(abp) + torch.sqrt(1 - abp - sigma ** 2) * eps + nonzero * sigma * nz
+    ((sample * ws).sum() + (pred * wp).sum()).backward()
+    # fused node
+    o2 = out0.clone().requires_grad_(True)
+    s2, p2 = FusedStepFn.apply(o2, x, t, noise, mask, motion, d._schedule(dev()), SAMPLER_DDIM if ddim else SAMPLER_DDPM, eta, True, False)
+    ((s2 * ws).sum() + (p2 * wp).sum()).backward()
+    assert rel_l2(s2.detach().cpu().numpy(), sample.detach().cpu().numpy()) < 2e-5
+    assert torch.equal(p2.detach(), pred.detach())
+    assert rel_l2(o2.grad.cpu().numpy(), o.grad.cpu().numpy()) < 2e-5
+    assert float(o2.grad[:, :3].abs().max()) == 0.0                 # masked rows take no gradient
+    # only one of the two outputs used
+    o3 = out0.clone().requires_grad_(True)
+    _, p3 = FusedStepFn.apply(o3, x, t, noise, mask, motion, d._schedule(dev()), SAMPLER_DDIM if ddim else SAMPLER_DDPM, eta, True, False)
+    (p3 * wp).sum().backward()
+    assert rel_l2(o3.grad.cpu().numpy(), (wp * (1 - mask)).cpu().numpy()) < 1e-6
+
+
+def test_masked_l2_node_matches_torch():
+    from mst_amd.diffusion.fused_ops import MaskedL2Fn
+    n, F, T = 6, 263, 196
+    style = cu(syn.normal(SEED, "l2/style", (1, F, 1, T)))
+    preds = cu(syn.normal(SEED, "l2/preds", (n, F, 1, T)))
+    fm = torch.ones(1, 1, 1, T, device=dev())
+    fm[..., T - 23:] = 0
+    g = cu(syn.normal(SEED, "l2/g", (n,)))
+    b = preds.clone().requires_grad_(True)
+    a, m = style.expand(n, -1, -1, -1), fm.expand(n, -1, -1, -1)
+    ref = (((a - b) ** 2) * m.float()).flatten(1).sum(1) / (m.flatten(1).sum(1) * (F * 1))
+    (ref * g).sum().backward()
+    b2 = preds.clone().requires_grad_(True)
+    got = MaskedL2Fn.apply(a, b2, m)
+    (got * g).sum().backward()
+    assert rel_l2(got.detach().cpu().numpy(), ref.detach().cpu().numpy()) < 1e-6
+    assert rel_l2(b2.grad.cpu().numpy(), b.grad.cpu().numpy()) < 1e-6
+    assert float(b2.grad[..., T - 23:].abs().max()) == 0.0
+    # per-sample (non-broadcast) operands and a float64 mask (the training loader attaches one, finetune:266)
+    a3 = cu(syn.normal(SEED, "l2/a3", (n, F, 1, T))).requires_grad_(True)
+    m3 = (torch.rand(n, 1, 1, T, device=dev()) > 0.3).double()
+    got3 = MaskedL2Fn.apply(a3, preds, m3)
+    ref3 = (((a3 - preds) ** 2) * m3.float()).flatten(1).sum(1) / (m3.flatten(1).sum(1) * F)
+    assert rel_l2(got3.detach().cpu().numpy(), ref3.detach().cpu().numpy()) < 1e-6
+    got3.sum().backward()
+    assert rel_l2(a3.grad.cpu().numpy(), torch.autograd.grad(ref3.sum(), a3)[0].cpu().numpy()) < 1e-6
+
+
+def test_text_cosine_node_matches_torch():
+    from mst_amd.diffusion.fused_ops import TextCosineFn
+    B, D = 64, 512
+    f = cu(syn.normal(SEED, "cos/f", (B, D)))
+    mu0 = cu(syn.normal(SEED, "cos/mu", (B, D))) * 3.0
+    mu = mu0.clone().requires_grad_(True)
+    fn = f / f.norm(dim=-1, keepdim=True)
+    mn = mu / mu.norm(dim=-1, keepdim=True)
+    ref = (1 - torch.nn.functional.cosine_similarity(fn, mn, dim=1, eps=1e-6)).mean()
+    (ref * 10.0).backward()
+    mu2 = mu0.clone().requires_grad_(True)
+    got = TextCosineFn.apply(f, mu2)
+    (got * 10.0).backward()
+    assert abs(float(got) - float(ref)) < 1e-6
+    assert rel_l2(mu2.grad.cpu().numpy(), mu.grad.cpu().numpy()) < 1e-5
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        TextCosineFn.apply(f.cpu(), mu0.cpu())
