@@ -6,13 +6,15 @@ train/training_loop.py:249-263) issued against this package's `utils.model_util`
 import contextlib
 import types
 
+import os
+
 import numpy as np
 import pytest
 import torch
 
 import mst_amd  # noqa: F401
 import mst_amd.synthetic as syn
-from conftest import SEED, rel_l2
+from conftest import GOLDEN, SEED, rel_l2
 from mst_amd.model.cfg_sampler import ClassifierFreeSampleModel
 from mst_amd.model.mdm_forstyledataset import StyleDiffusion
 from mst_amd.utils import model_util
@@ -57,7 +59,7 @@ def recorded_noise(tag):
     torch.randn_like = lambda x, **kw: draw(x.shape, x.device)
     torch.rand_like = draw_u
     try:
-        yield
+        yield state
     finally:
         torch.randn, torch.randn_like, torch.rand_like = orig
 
@@ -283,3 +285,30 @@ def test_finetune_objective_matches_reference(golden):
         bias.copy_(saved)
         again = model(x, t, y=y)
     assert not torch.equal(before, after) and torch.equal(before, again)
+
+
+def test_neutralisation_prepass_all_100_xstarts_vs_reference():
+    """SURVEY 8 f-2, exactly as train/finetune_style_diffusion.py:195-212 issues it: the frozen prior as the denoiser,
+    `stop_timesteps=900`, `dump_all_xstart=True` -> 100 x0-hat tensors.  The fixture (tests/golden/make_golden_gen.py, the
+    reference run on CPU) holds 4 of them in full and of all 100 the norm and a fixed 64-d random projection."""
+    c = build()
+    g = np.load(os.path.join(GOLDEN, "gen.npz"))
+    x, t, y, mask, motion = inputs()
+    shp = (1, F, 1, T)
+    y_n = {"y": {"text": PROMPTS[:1], "mask": torch.ones(1, 1, 1, T, device=dev()),
+                 "inpainting_mask": torch.zeros(shp, device=dev()), "inpainted_motion": motion[:1]}}
+    with torch.no_grad(), recorded_noise("xia/neutral900"):
+        dump = c["full"].p_sample_loop(c["m"].motion_enc.mdm_model, shp, clip_denoised=False, model_kwargs=y_n, skip_timesteps=0,
+                                       init_image=motion[:1], progress=False, dump_steps=None, noise=None, const_noise=False,
+                                       stop_timesteps=900, dump_all_xstart=True)
+    assert len(dump) == int(g["neutral900|n"]) == 100
+    allx = torch.cat(dump).cpu().numpy().reshape(100, -1).astype(np.float64)
+    for k, i in enumerate(g["neutral900|sel"]):
+        e = rel_l2(allx[i].reshape(F, 1, T), g["neutral900|xstart_sel"][k])
+        assert e < TOL, (int(i), e)
+    proj = syn.normal(SEED, "gen/projection", (64, F * T)).astype(np.float64)
+    e_norm = np.abs(np.linalg.norm(allx, axis=1) - g["neutral900|norm"]) / g["neutral900|norm"]
+    # a 64-d random projection of a 13 756-d error vector keeps ~sqrt(64 / 13756) of its norm: compare on the tensor's scale
+    e_proj = np.linalg.norm(allx @ proj.T - g["neutral900|proj"], axis=1) / (g["neutral900|norm"] * np.sqrt(64.0))
+    print("neutral900: worst norm error", e_norm.max(), "worst projection error", e_proj.max())
+    assert e_norm.max() < TOL and e_proj.max() < TOL

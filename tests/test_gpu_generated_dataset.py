@@ -96,3 +96,42 @@ def test_sample_limit_and_sharded_walk():
     assert [d["batch"] for d in parts[0].generated_motion] == [0, 0, 2, 2]
     assert [d["batch"] for d in parts[1].generated_motion] == [1, 1]
     assert parts[0].all_generated.__self__.shard == (0, 2)
+
+
+class GoldenLoader(Loader):
+    """The loader tests/golden/make_golden_gen.py fed the REFERENCE's CompMDMGeneratedDataset: prompts only (the models
+    encode them), no precomputed embedding."""
+
+    def __iter__(self):
+        for motion, kw in Loader.__iter__(self):
+            del kw["y"]["text_embed"]
+            yield motion, kw
+
+
+def test_generated_dataset_matches_the_reference_class():
+    """SURVEY 8 f-4 pinned to the reference: its `CompMDMGeneratedDataset` (comp_v6_model_dataset.py:146-240) was run on
+    CPU over this loader with recorded noise (tests/golden/gen.npz); ours must produce the same clips, multimodality
+    repeats, bookkeeping -- and consume the same number of RNG draws in the same order."""
+    import os
+    from conftest import GOLDEN, rel_l2
+    from mst_amd.data_loaders.comp_v6_model_dataset import CompMDMGeneratedDataset
+    from mst_amd.model.cfg_sampler import ClassifierFreeSampleModel
+    from test_gpu_boundary import recorded_noise
+    g = np.load(os.path.join(GOLDEN, "gen.npz"))
+    c = build()
+    np.random.seed(5)
+    with recorded_noise("gen") as st:
+        ds = CompMDMGeneratedDataset(ClassifierFreeSampleModel(c["m"]), plain100(), GoldenLoader(), 2, 3, T, None, scale=2.5)
+    assert st["k"] == int(g["gen|draws"])                                   # same RNG call pattern as the reference
+    assert len(ds) == int(g["gen|len"])
+    assert [d["caption"] for d in ds.generated_motion] == list(g["gen|captions"])
+    assert [int(d["length"]) for d in ds.generated_motion] == list(g["gen|lengths"])
+    assert [d["cap_len"] for d in ds.generated_motion] == list(g["gen|cap_len"])
+    assert [d["caption"] for d in ds.mm_generated_motion] == list(g["gen|mm_captions"])
+    got = np.stack([d["motion"] for d in ds.generated_motion])
+    errs = [rel_l2(got[i], g["gen|motions"][i]) for i in range(len(got))]
+    mm = np.stack([np.stack([r["motion"] for r in d["mm_motions"]]) for d in ds.mm_generated_motion])
+    assert mm.shape == g["gen|mm_motions"].shape
+    mm_err = rel_l2(mm, g["gen|mm_motions"])
+    print("generated dataset vs reference: per-clip", errs, "mm", mm_err)
+    assert max(errs) < 1e-3 and mm_err < 1e-3
