@@ -50,46 +50,34 @@ def log_loss_dict(diffusion, ts, losses):
 
 
 class TrainInpaintingLoop:
+    # attributes the reference's constructor copies from `args` one by one (:44-75), and the ones only a style fine-tune run has
+    _FROM_ARGS = ("dataset", "batch_size", "lr", "log_interval", "save_interval", "resume_checkpoint", "weight_decay",
+                  "lr_anneal_steps", "num_steps", "save_dir", "overwrite")
+    _FINETUNE_ARGS = ("style_finetune", "semantic_guidance", "skip_steps")
+
     def __init__(self, args, train_platform, model, data, diffusion=None, style_data=None, reducer=None):
-        self.args = args
-        self.dataset = args.dataset
-        self.train_platform = train_platform
-        self.model = model
-        self.data = data
-        self.style_data = style_data
-        self.batch_size = args.batch_size
-        self.microbatch = args.batch_size
-        self.lr = args.lr
-        self.log_interval = args.log_interval
-        self.save_interval = args.save_interval
-        self.resume_checkpoint = args.resume_checkpoint
-        self.use_fp16 = False
-        self.weight_decay = args.weight_decay
-        self.lr_anneal_steps = args.lr_anneal_steps
-        self.style_finetune = args.style_finetune if hasattr(args, "style_finetune") else 0
-        self.semantic_guidance = args.semantic_guidance if hasattr(args, "style_finetune") else 0
-        self.skip_steps = args.skip_steps if hasattr(args, "skip_steps") else 0
+        self.args, self.train_platform, self.model, self.data, self.style_data = args, train_platform, model, data, style_data
+        self.diffusion, self.reducer = diffusion, reducer
+        for name in self._FROM_ARGS:
+            setattr(self, name, getattr(args, name))
+        finetune = hasattr(args, "style_finetune")            # the reference keys all three on `style_finetune` being present
+        for name in self._FINETUNE_ARGS:
+            setattr(self, name, getattr(args, name, 0) if (finetune or name == "skip_steps") else 0)
         self.style_example = hasattr(args, "skip_steps")
-        self.step = 0
-        self.resume_step = 0
-        self.global_batch = self.batch_size
-        self.num_steps = args.num_steps
+        self.microbatch = self.global_batch = self.batch_size  # no gradient accumulation; single-device batch (:73)
+        self.use_fp16 = self.use_ddp = False
+        self.step = self.resume_step = 0
         self.num_epochs = self.num_steps // len(self.data) + 1
         self.sync_cuda = torch.cuda.is_available()
-        self.save_dir = args.save_dir
         self.device = next(model.parameters()).device
         self._load_and_sync_parameters()
         self.mp_trainer = MixedPrecisionTrainer(model=self.model, use_fp16=False)
-        self.overwrite = args.overwrite
-        self.diffusion = diffusion
-        self.reducer = reducer
         if diffusion is not None:
             self.schedule_sampler_type = 'uniform'
             self.schedule_sampler = create_named_schedule_sampler(self.schedule_sampler_type, diffusion)
         self.opt = FusedAdamW(self.mp_trainer.master_params, lr=self.lr, weight_decay=self.weight_decay)
         if self.resume_step:
             self._load_optimizer_state()
-        self.use_ddp = False
 
     # ------------------------------------------------------------------------------ resume (:108-141)
     def _load_and_sync_parameters(self):
@@ -121,32 +109,39 @@ class TrainInpaintingLoop:
     def _annealing_done(self):
         return not (not self.lr_anneal_steps or self.step + self.resume_step < self.lr_anneal_steps)
 
+    def _next_style_example(self, it):
+        """One (content clip, style conditioning) pair per epoch, cycling over `style_data` (:146-156)."""
+        try:
+            content, cond = next(it)
+        except StopIteration:
+            it = iter(self.style_data)
+            content, cond = next(it)
+        return it, content.to(self.device), self._to_device(cond)
+
+    def _report(self):
+        """Console line for the loss, every other logged scalar to the train platform (:167-176): step counters and the
+        per-quartile `*_q*` entries stay in the logger only."""
+        shown = self.step + self.resume_step
+        for name, value in logger.get_current().name2val.items():
+            if name == 'loss':
+                print('step[{}]: loss[{:0.5f}]'.format(shown, value))
+            if name in ('step', 'samples') or '_q' in name:
+                continue
+            self.train_platform.report_scalar(name=name, value=value, iteration=self.step, group_name='Loss')
+
     def run_loop(self):
-        if self.style_finetune:
-            iter_styledata = iter(self.style_data)
+        style_it = iter(self.style_data) if self.style_finetune else None
         for epoch in range(self.num_epochs):
             print(f'Starting epoch {epoch}')
+            content_motion = cond_style = None
             if self.style_finetune:
-                try:
-                    content_motion, cond_style = next(iter_styledata)
-                except StopIteration:
-                    iter_styledata = iter(self.style_data)
-                    content_motion, cond_style = next(iter_styledata)
-                content_motion = content_motion.to(self.device)
-                cond_style = self._to_device(cond_style)
-            else:
-                content_motion = cond_style = None
+                style_it, content_motion, cond_style = self._next_style_example(style_it)
             for motion, cond in self.data:
                 if self._annealing_done():
                     break
                 self.run_step(motion.to(self.device), self._to_device(cond), content_motion, cond_style)
                 if self.step % self.log_interval == 0:
-                    for k, v in logger.get_current().name2val.items():
-                        if k == 'loss':
-                            print('step[{}]: loss[{:0.5f}]'.format(self.step + self.resume_step, v))
-                        if k in ['step', 'samples'] or '_q' in k:
-                            continue
-                        self.train_platform.report_scalar(name=k, value=v, iteration=self.step, group_name='Loss')
+                    self._report()
                 if self.step % self.save_interval == 0:
                     self.save()
                     if os.environ.get("DIFFUSION_TRAINING_TEST", "") and self.step > 0:
@@ -154,7 +149,7 @@ class TrainInpaintingLoop:
                 self.step += 1
             if self._annealing_done():
                 break
-        if (self.step - 1) % self.save_interval != 0:
+        if (self.step - 1) % self.save_interval != 0:          # the final save is named after the post-increment step (:198-199)
             self.save()
 
     def run_step(self, batch, cond, style_batch=None, style_cond=None):
