@@ -75,6 +75,7 @@ SIGNATURES = {
     "mst_recover_from_ric": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_void_p, C.c_void_p]),
     "mst_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mst_profile_event_overhead_us": (C.c_float, [C.c_void_p]),
     "mst_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int32),
                                    C.c_int32]),
     "mst_debug_stop_after": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),

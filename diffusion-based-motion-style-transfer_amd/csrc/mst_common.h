@@ -156,6 +156,14 @@ __device__ __forceinline__ float step_update(const StepCoef& c, float model_out,
     }
 }
 
+// Per-call arguments of a sampling loop, kept in DEVICE memory: a captured step graph reads its tensors and its position in
+// the loop through this block, so one instantiated graph serves every later call with the same shapes (new clip tensors, new
+// seed) and every replay (the step counter `jbase` is advanced on the device at the end of each replay).
+struct LoopDev {
+    float* x; const float* mask; const float* motion; const float* noise; const float* scale; float* xstart;
+    unsigned long long seed; float eta; int t_start; int nrun; int jbase; int pad;
+};
+
 // arguments of the fused diffusion step (output-projection epilogue)
 struct StepArgs {
     const float* tab; int nsteps; int t;          // schedule tables (device) and the diffusion index
@@ -167,4 +175,26 @@ struct StepArgs {
     float* sample; float* xstart;                 // outputs (xstart may be null)
     unsigned long long seed; unsigned step; unsigned clip0;   // clip0: batch index of the slice's first clip (Philox counter)
     int mask_noise, clip, philox;
+    // loop mode: the pointer fields above are PRESENCE flags (null / non-null) and are resolved in the kernel from *ld:
+    // step j = ld->jbase + joff visits index t_start - j; tensors start `eo` elements into the caller's, per-step buffers
+    // (noise, x0-hat dump) advance by `step_stride` elements per step; the slice's scales start at clip `clip0`.
+    const LoopDev* ld; int joff; unsigned long long eo, step_stride;
 };
+
+__device__ __forceinline__ StepArgs step_resolve(StepArgs sa) {
+    if (!sa.ld) return sa;
+    const LoopDev d = *sa.ld;
+    const int j = d.jbase + sa.joff;
+    sa.t = d.t_start - j;
+    sa.eta = d.eta;
+    sa.seed = d.seed;
+    sa.step = (unsigned)j;
+    sa.x = d.x + sa.eo;
+    sa.sample = d.x + sa.eo;
+    sa.mask = sa.mask ? d.mask + sa.eo : nullptr;
+    sa.motion = sa.motion ? d.motion + sa.eo : nullptr;
+    sa.noise = sa.noise ? d.noise + (size_t)j * sa.step_stride + sa.eo : nullptr;
+    sa.xstart = sa.xstart ? d.xstart + (size_t)j * sa.step_stride + sa.eo : nullptr;
+    sa.scale = sa.scale ? d.scale + sa.clip0 : nullptr;
+    return sa;
+}

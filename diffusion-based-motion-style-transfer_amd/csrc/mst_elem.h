@@ -25,8 +25,9 @@ __global__ void k_copy_pad_f32(const float* __restrict__ src, int n, float* __re
 // gscale != null: values are multiplied by gscale[0] first (backward of the output projection: the incoming gradient
 // is brought into f16 range by the device-side scale of the training path).
 __global__ __launch_bounds__(256) void k_frames_f16(const float* __restrict__ x, int F, int T, int Kpad, f16* __restrict__ xt,
-                                                    const float* __restrict__ gscale) {
+                                                    const float* __restrict__ gscale, const LoopDev* __restrict__ ld, unsigned long long eo) {
     __shared__ float tile[32][33];
+    if (ld) x = ld->x + eo;                          // sampling loop: the clip tensor of THIS call (captured graphs are replayed across calls)
     const float sc = gscale ? gscale[0] : 1.0f;
     const int clip = blockIdx.z, f0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -81,9 +82,10 @@ __global__ __launch_bounds__(256) void k_rowwise_linear(const float* __restrict_
 __global__ void k_cond_token(const float* __restrict__ temb, int uniform_row, int temb_mod,
                              const float* __restrict__ textproj, int tp_half, int tp_uncond,
                              const float* __restrict__ pe, int S, int rows,
-                             f16* __restrict__ hi, f16* __restrict__ lo) {
+                             f16* __restrict__ hi, f16* __restrict__ lo, const LoopDev* __restrict__ ld, int joff) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * MST_D) return;
+    if (ld) uniform_row = ld->nrun - 1 - (ld->jbase + joff);      // sampling loop: the timestep row of step jbase + joff
     int clip = i / MST_D, f = i - clip * MST_D;
     int tr = uniform_row >= 0 ? uniform_row : clip % temb_mod;
     int tp = (tp_half > 0 && clip >= tp_half) ? clip - tp_half + tp_uncond : clip;
@@ -312,6 +314,8 @@ __global__ void k_philox_normal(float* __restrict__ out, int F, int T, unsigned 
     }
 }
 
+
+__global__ void k_loop_advance(LoopDev* ld, int n) { ld->jbase += n; }
 
 // Post-sampling: normalised hml_vec clip [B][F][T] -> joint positions [B][T][J][3] in one launch
 // (sample.permute(0,2,3,1) * std + mean, then recover_from_ric: root yaw = running sum of the yaw velocities, root

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <set>
@@ -194,10 +195,27 @@ struct mst_engine {
     static constexpr int MAX_SLICES = 4;
     hipStream_t aux_stream[MAX_SLICES - 1] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[MAX_SLICES - 1] = {nullptr, nullptr, nullptr};
+    // sampling-loop state in device memory + the captured step graph (mst_sample_loop)
+    LoopDev* ld_dev = nullptr;
+    LoopDev* ld_pin = nullptr;            // pinned staging ring for the per-call upload
+    static constexpr int LD_SLOTS = 8;
+    hipEvent_t ld_ev[LD_SLOTS] = {nullptr};
+    int ld_next = 0;
+    int graph_on = 0;                     // MST_GRAPH=1: long loops replay a captured hipGraph of graph_steps steps (host enqueue ~0).
+                                          // Off by default: on ROCm 7.2 the replay is not faster than host-enqueued launches
+                                          // (same box, batch 64: 73.7 vs 74.1 clips/s; batch 1: 381 vs 367 us per step) -- the loop
+                                          // is GPU-bound either way (tools/host_bound.py)
+    int graph_steps = 20;                 // denoise steps per captured graph (MST_GRAPH_STEPS)
+    hipStream_t loop_stream = nullptr;    // the loop runs on the engine's own streams (a caller's legacy default stream cannot be
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;   //  captured); it is ordered behind / before the caller's stream by these two events
+    hipGraphExec_t gexec = nullptr;
+    std::vector<long long> gkey;          // what the instantiated graph was captured for
+    std::vector<long long> warm_key;      // configuration whose kernels have all been launched eagerly once (per-kernel LDS opt-ins done)
     // profiling
     int prof_on = 0, prof_now = 0, prof_period = 16;
     std::vector<ProfPoint> prof_pts;
     size_t prof_used = 0;
+    float prof_overhead_us = -1.f;        // median duration an empty event pair reports (calibrated at mst_profile_enable)
     double prof_ms[FAM_COUNT] = {0};
     int prof_n[FAM_COUNT] = {0};
 };
@@ -316,6 +334,14 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     if (const char* v = getenv("MST_SMALL_M")) e->small_m = atoi(v);
     if (const char* v = getenv("MST_LN128_M")) e->ln128_min_m = atoi(v);
     CHECK(dmalloc(&e->zacc, (size_t)e->M_pad * MST_D));
+    CHECK(dmalloc(&e->ld_dev, 1));
+    HIPCHECK(hipStreamCreateWithFlags(&e->loop_stream, hipStreamNonBlocking));
+    HIPCHECK(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming));
+    HIPCHECK(hipHostMalloc((void**)&e->ld_pin, sizeof(LoopDev) * mst_engine::LD_SLOTS, hipHostMallocDefault));
+    for (int i = 0; i < mst_engine::LD_SLOTS; i++) HIPCHECK(hipEventCreateWithFlags(&e->ld_ev[i], hipEventDisableTiming));
+    if (const char* v = getenv("MST_GRAPH")) e->graph_on = atoi(v) != 0;
+    if (const char* v = getenv("MST_GRAPH_STEPS")) { int n = atoi(v); e->graph_steps = n < 2 ? 2 : (n > 100 ? 100 : n); }
     *out = e;
     return 0;
 }
@@ -346,6 +372,13 @@ extern "C" void mst_engine_destroy(mst_engine* e) {
         if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]);
     }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
+    if (e->loop_stream) (void)hipStreamDestroy(e->loop_stream);
+    if (e->ev_in) (void)hipEventDestroy(e->ev_in);
+    if (e->ev_out) (void)hipEventDestroy(e->ev_out);
+    (void)hipFree(e->ld_dev);
+    if (e->ld_pin) (void)hipHostFree(e->ld_pin);
+    for (int i = 0; i < mst_engine::LD_SLOTS; i++) if (e->ld_ev[i]) (void)hipEventDestroy(e->ld_ev[i]);
     for (auto& pp : e->prof_pts) {
         (void)hipEventDestroy(pp.a);
         (void)hipEventDestroy(pp.b);
@@ -476,8 +509,24 @@ extern "C" int mst_profile_enable(mst_engine* e, int32_t on) {
     }
     e->prof_used = 0;
     for (int i = 0; i < FAM_COUNT; i++) { e->prof_ms[i] = 0; e->prof_n[i] = 0; }
+    if (e->prof_on && e->prof_overhead_us < 0.f) {
+        // what an event pair measures around NOTHING on an otherwise busy-free stream: the fixed part of every timed launch
+        // (rocprofv3's kernel durations are shorter than event-bracketed ones by about this much)
+        ON_DEVICE(e->cfg.device);
+        float v[16];
+        for (int i = 0; i < 16; i++) {
+            HIPCHECK(hipEventRecord(e->prof_pts[0].a, e->loop_stream));
+            HIPCHECK(hipEventRecord(e->prof_pts[0].b, e->loop_stream));
+            HIPCHECK(hipEventSynchronize(e->prof_pts[0].b));
+            HIPCHECK(hipEventElapsedTime(&v[i], e->prof_pts[0].a, e->prof_pts[0].b));
+        }
+        std::sort(v, v + 16);
+        e->prof_overhead_us = 1e3f * v[8];
+    }
     return 0;
 }
+
+extern "C" float mst_profile_event_overhead_us(const mst_engine* e) { return e ? e->prof_overhead_us : -1.f; }
 
 extern "C" int mst_profile_read(mst_engine* e, const char** names, float* total_ms, int32_t* launches, int32_t cap) {
     if (!e) return -1;
@@ -647,13 +696,15 @@ static int launch_tail(const LayerW& w, const WS& ws, int M, hipStream_t st) {
 
 // K3 .. K8: token stream through the encoder stack.  rows = clips through the transformer.
 // K1-K3: conditioning token + pose embedding of the frames -> token stream rows (ws.hx / ws.hl)
+struct LoopRef { const LoopDev* ld = nullptr; int joff = 0; unsigned long long eo = 0; };   // loop mode of a step's kernels (see LoopDev)
+
 static int assemble_stream(mst_engine* e, const WS& ws, const float* x, int clips_x, int rows, int T, int temb_uniform_row, int temb_mod,
-                           hipStream_t st, int tp_uncond) {
+                           hipStream_t st, int tp_uncond, LoopRef lr = LoopRef()) {
     const int S = T + 1;
     {
         ProfScope ps(e, FAM_COND, st);
         hipLaunchKernelGGL(k_cond_token, dim3((rows * MST_D + 255) / 256), dim3(256), 0, st, e->temb, temb_uniform_row,
-                           temb_mod, ws.textproj, rows > clips_x ? clips_x : 0, rows > clips_x ? tp_uncond : 0, e->pe, S, rows, ws.hx, ws.hl);
+                           temb_mod, ws.textproj, rows > clips_x ? clips_x : 0, rows > clips_x ? tp_uncond : 0, e->pe, S, rows, ws.hx, ws.hl, lr.ld, lr.joff);
         HIPCHECK(hipGetLastError());
     }
     {
@@ -661,7 +712,7 @@ static int assemble_stream(mst_engine* e, const WS& ws, const float* x, int clip
         // CFG batch feeds the same x to both halves: embed once, store twice (dup).
         ProfScope ps(e, FAM_EMBED_IN, st);
         const int F = e->cfg.feats, tot = clips_x * T;
-        hipLaunchKernelGGL(k_frames_f16, dim3((T + 31) / 32, e->kin_pad / 32, clips_x), dim3(256), 0, st, x, F, T, e->kin_pad, ws.xt, (const float*)nullptr);
+        hipLaunchKernelGGL(k_frames_f16, dim3((T + 31) / 32, e->kin_pad / 32, clips_x), dim3(256), 0, st, x, F, T, e->kin_pad, ws.xt, (const float*)nullptr, lr.ld, lr.eo);
         HIPCHECK(hipGetLastError());
         DEpiEmbedIn epi{e->b_pose_in, e->pe, ws.hx, ws.hl, T, S, tot, rows > clips_x ? (size_t)clips_x * S * MST_D : 0};
         CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1>(dim3((tot + 63) / 64, 1), RowsDirect{ws.xt, e->kin_pad}, e->w_pose_in, e->kin_pad,
@@ -672,9 +723,9 @@ static int assemble_stream(mst_engine* e, const WS& ws, const float* x, int clip
 
 // K3 .. K8: token stream through the encoder stack.  rows = clips through the transformer.
 static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, int rows, int T, int temb_uniform_row, int temb_mod,
-                     hipStream_t st, int tp_uncond = 0) {
+                     hipStream_t st, int tp_uncond = 0, LoopRef lr = LoopRef()) {
     const int S = T + 1, M = rows * S;
-    CHECK(assemble_stream(e, ws, x, clips_x, rows, T, temb_uniform_row, temb_mod, st, tp_uncond));
+    CHECK(assemble_stream(e, ws, x, clips_x, rows, T, temb_uniform_row, temb_mod, st, tp_uncond, lr));
     if (e->dbg_stage == 0) return 0;
 #define DBG_STOP(stage) if (e->dbg_layer == l && e->dbg_stage == stage) return 0;
     const bool small = e->small_m > 0 && M <= e->small_m;
@@ -831,6 +882,66 @@ extern "C" int mst_loop_slices(const mst_engine* e, int32_t batch, int32_t cfg) 
     return n;
 }
 
+// One denoise step of every slice, enqueued (or captured): slice sl on streams[sl]; step = *ld.jbase + joff.
+struct LoopPlan {
+    const mst_schedule* s; const mst_loop_args* a; int nsl; size_t per_clip, clip_elems;
+    hipStream_t streams[mst_engine::MAX_SLICES];
+};
+static int enqueue_step(mst_engine* e, const LoopPlan& p, int joff, int nsj) {
+    const mst_loop_args* a = p.a;
+    for (int sl = 0; sl < nsj; sl++) {
+        const int per = (a->batch + nsj - 1) / nsj;          // clips per slice (last one may be short)
+        const int c0 = sl * per;
+        const int nb = (c0 + per <= a->batch) ? per : a->batch - c0;
+        if (nb <= 0) continue;
+        const size_t eo = (size_t)c0 * p.per_clip;
+        // workspace rows of the slice: its clips (cond + uncond twins under CFG); text projections are indexed
+        // in the full-batch layout [cond 0..B | uncond 0..B]
+        WS ws = ws_slice(e, a->cfg ? 2 * c0 : c0, a->frames);
+        ws.textproj = e->textproj + (size_t)c0 * MST_D;
+        hipStream_t ss = p.streams[sl];
+        LoopRef lr{e->ld_dev, joff, eo};
+        CHECK(run_trunk(e, ws, nullptr, nb, a->cfg ? 2 * nb : nb, a->frames, 0, 0, ss, a->batch, lr));
+        StepArgs sa{};
+        sa.tab = p.s->tab;
+        sa.nsteps = p.s->n;
+        // presence flags: the kernel resolves the pointers from *ld (step_resolve)
+        const float* const yes = reinterpret_cast<const float*>(1);
+        sa.mask = a->inpainting_mask_dev ? yes : nullptr;
+        sa.motion = a->inpainted_motion_dev ? yes : nullptr;
+        sa.noise = a->noise_mode == MST_NOISE_BUFFER ? yes : nullptr;
+        sa.scale = a->scale_dev ? yes : nullptr;
+        sa.xstart = a->xstart_dump_dev ? reinterpret_cast<float*>(1) : nullptr;
+        sa.clip0 = (unsigned)c0;
+        sa.mask_noise = a->mask_noise;
+        sa.clip = a->clip_denoised;
+        sa.philox = a->noise_mode == MST_NOISE_PHILOX;
+        sa.ld = e->ld_dev;
+        sa.joff = joff;
+        sa.eo = eo;
+        sa.step_stride = p.clip_elems;
+        if (a->sampler == MST_SAMPLER_DDPM) CHECK(launch_out_nt<1>(e, ws, a->cfg, nb, a->frames, nullptr, sa, ss));
+        else CHECK(launch_out_nt<2>(e, ws, a->cfg, nb, a->frames, nullptr, sa, ss));
+    }
+    return 0;
+}
+static int fork_slices(mst_engine* e, const LoopPlan& p) {
+    HIPCHECK(hipEventRecord(e->ev_fork, p.streams[0]));
+    for (int i = 1; i < p.nsl; i++) HIPCHECK(hipStreamWaitEvent(p.streams[i], e->ev_fork, 0));
+    return 0;
+}
+static int join_slices(mst_engine* e, const LoopPlan& p) {
+    for (int i = 1; i < p.nsl; i++) {
+        HIPCHECK(hipEventRecord(e->ev_join[i - 1], p.streams[i]));
+        HIPCHECK(hipStreamWaitEvent(p.streams[0], e->ev_join[i - 1], 0));
+    }
+    return 0;
+}
+
+// The reference's per-step Python loop (gaussian_diffusion.py:775-794) as ONE call.  Steps are either enqueued from the host
+// (short loops, instrumented runs) or replayed from a captured hipGraph of `graph_steps` steps: every kernel reads its
+// tensors and its step index through the LoopDev block in device memory, which a one-thread kernel at the end of the graph
+// advances, so the instantiated graph is reused by every replay and by every later call with the same shapes.
 extern "C" int mst_sample_loop(mst_engine* e, const mst_schedule* s, const mst_loop_args* a, void* stream) {
     if (!s || !a) return fail("mst_sample_loop: null argument");
     CHECK(check_ready(e, a->batch, a->frames, a->cfg));
@@ -839,84 +950,102 @@ extern "C" int mst_sample_loop(mst_engine* e, const mst_schedule* s, const mst_l
     if (!a->x_dev || (a->cfg && !a->scale_dev)) return fail("mst_sample_loop: null x / scale");
     if (a->noise_mode == MST_NOISE_BUFFER && !a->noise_dev) return fail("mst_sample_loop: noise buffer missing");
     if (a->sampler != MST_SAMPLER_DDPM && a->sampler != MST_SAMPLER_DDIM) return fail("mst_sample_loop: bad sampler");
-    hipStream_t st = (hipStream_t)stream;
+    hipStream_t caller = (hipStream_t)stream;
     ON_DEVICE(e->cfg.device);
+    // The loop runs on engine-owned streams: behind everything the caller has enqueued (ev_in), and the caller's stream
+    // continues behind the loop (ev_out).  A captured graph needs that: torch's current stream is normally the legacy
+    // default stream, which cannot be captured.
+    hipStream_t st = e->loop_stream;
+    HIPCHECK(hipEventRecord(e->ev_in, caller));
+    HIPCHECK(hipStreamWaitEvent(st, e->ev_in, 0));
     const int nrun = a->t_start - a->t_end + 1;
-    const int rows = a->cfg ? 2 * a->batch : a->batch;
-    const size_t clip_elems = (size_t)a->batch * e->cfg.feats * a->frames;
     // K1 hoisted: the timestep MLP for every index this loop visits (row j <-> index t_end + j)
     e->prof_now = 0;
     CHECK(timestep_rows(e, s->tmap + a->t_end, nrun, st));
     // Clips are independent, so the batch runs as `nsplit` slices on separate streams: one slice's kernels fill
     // the CUs the other leaves idle in its prologues, tails and launch gaps (per-launch time is per-CU bound and
     // flat in the block count at this size).  CFG batches are sliced the same way (cond + uncond twins stay together).
-    const int nsl = mst_loop_slices(e, a->batch, a->cfg);
-    const size_t per_clip = (size_t)e->cfg.feats * a->frames;
-    hipStream_t streams[mst_engine::MAX_SLICES] = {st, e->aux_stream[0], e->aux_stream[1], e->aux_stream[2]};
+    LoopPlan p{s, a, mst_loop_slices(e, a->batch, a->cfg), (size_t)e->cfg.feats * a->frames, (size_t)a->batch * e->cfg.feats * a->frames,
+               {st, e->aux_stream[0], e->aux_stream[1], e->aux_stream[2]}};
+    // per-call arguments -> device (pinned staging slot; the slot's previous upload has long completed when it comes round again)
+    {
+        const int slot = e->ld_next;
+        e->ld_next = (slot + 1) % mst_engine::LD_SLOTS;
+        HIPCHECK(hipEventSynchronize(e->ld_ev[slot]));
+        LoopDev& h = e->ld_pin[slot];
+        h = LoopDev{a->x_dev, a->inpainting_mask_dev, a->inpainted_motion_dev, a->noise_dev, a->scale_dev, a->xstart_dump_dev,
+                    a->seed, a->eta, a->t_start, nrun, 0, 0};
+        HIPCHECK(hipMemcpyAsync(e->ld_dev, &h, sizeof(LoopDev), hipMemcpyHostToDevice, st));
+        HIPCHECK(hipEventRecord(e->ld_ev[slot], st));
+    }
+    // what a captured graph depends on (everything else reaches the kernels through LoopDev)
+    const int U = e->graph_steps;
+    std::vector<long long> key = {a->batch, a->frames, a->cfg, a->sampler, a->noise_mode, a->mask_noise, a->clip_denoised,
+                                  a->inpainting_mask_dev != nullptr, a->inpainted_motion_dev != nullptr, a->xstart_dump_dev != nullptr,
+                                  a->scale_dev != nullptr, p.nsl, U, (long long)(size_t)s->tab, s->n, e->small_m, e->fuse_tail,
+                                  e->fuse_qkv_attn, e->ln128_min_m};
+    const bool use_graph = e->graph_on && !e->prof_on && e->dbg_stage < 0 && nrun >= 2 * U;
     bool forked = false;
     auto steps = [&]() -> int {
-    for (int j = 0; j < nrun; j++) {
-        const int ti = a->t_start - j;
-        e->prof_now = e->prof_on && (j % e->prof_period == 0);
-        // instrumented steps run as ONE full-batch slice so the HIP-event durations are those of isolated
-        // full-batch launches (the roofline figures); all other steps use the concurrent slices
-        const int nsj = e->prof_now ? 1 : nsl;
-        if (nsj > 1 && !forked) {
-            HIPCHECK(hipEventRecord(e->ev_fork, st));
-            for (int i = 1; i < nsl; i++) HIPCHECK(hipStreamWaitEvent(streams[i], e->ev_fork, 0));
-            forked = true;
-        } else if (nsj == 1 && forked) {
-            for (int i = 1; i < nsl; i++) {
-                HIPCHECK(hipEventRecord(e->ev_join[i - 1], streams[i]));
-                HIPCHECK(hipStreamWaitEvent(st, e->ev_join[i - 1], 0));
+        int j = 0;
+        if (use_graph) {
+            // head of the loop from the host: the remainder, plus one graph's worth of steps the first time a configuration is
+            // seen (every kernel's per-device LDS opt-in must have happened before a capture)
+            int pre = nrun % U;
+            if (e->warm_key != key) pre += U;
+            if (p.nsl > 1) { CHECK(fork_slices(e, p)); forked = true; }
+            for (; j < pre; j++) CHECK(enqueue_step(e, p, j, p.nsl));
+            if (forked) { CHECK(join_slices(e, p)); forked = false; }
+            e->warm_key = key;
+            if (pre > 0) {
+                hipLaunchKernelGGL(k_loop_advance, dim3(1), dim3(1), 0, st, e->ld_dev, pre);
+                HIPCHECK(hipGetLastError());
             }
-            forked = false;
+            if (e->gkey != key || !e->gexec) {
+                if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
+                e->gkey.clear();
+                HIPCHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+                int rc = 0;
+                if (p.nsl > 1) rc = fork_slices(e, p);
+                for (int k = 0; k < U && !rc; k++) rc = enqueue_step(e, p, k, p.nsl);
+                if (!rc && p.nsl > 1) rc = join_slices(e, p);
+                if (!rc) {
+                    hipLaunchKernelGGL(k_loop_advance, dim3(1), dim3(1), 0, st, e->ld_dev, U);
+                    if (hipGetLastError() != hipSuccess) rc = fail("mst_sample_loop: capture of the step-counter kernel failed");
+                }
+                hipGraph_t graph = nullptr;
+                const hipError_t ce = hipStreamEndCapture(st, &graph);          // always end the capture: the stream must come back
+                if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+                if (ce != hipSuccess || !graph) return fail("mst_sample_loop: stream capture failed: %s", hipGetErrorString(ce));
+                const hipError_t ie = hipGraphInstantiate(&e->gexec, graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);
+                if (ie != hipSuccess) { e->gexec = nullptr; return fail("mst_sample_loop: hipGraphInstantiate failed: %s", hipGetErrorString(ie)); }
+                e->gkey = key;
+            }
+            for (; j < nrun; j += U) HIPCHECK(hipGraphLaunch(e->gexec, st));
+            return 0;
         }
-        for (int sl = 0; sl < nsj; sl++) {
-            const int per = (a->batch + nsj - 1) / nsj;          // clips per slice (last one may be short)
-            const int c0 = sl * per;
-            const int nb = (c0 + per <= a->batch) ? per : a->batch - c0;
-            if (nb <= 0) continue;
-            const size_t eo = (size_t)c0 * per_clip;
-            // workspace rows of the slice: its clips (cond + uncond twins under CFG); text projections are indexed
-            // in the full-batch layout [cond 0..B | uncond 0..B]
-            WS ws = ws_slice(e, a->cfg ? 2 * c0 : c0, a->frames);
-            ws.textproj = e->textproj + (size_t)c0 * MST_D;
-            hipStream_t ss = streams[sl];
-            CHECK(run_trunk(e, ws, a->x_dev + eo, nb, a->cfg ? 2 * nb : nb, a->frames, ti - a->t_end, 0, ss, a->batch));
-            StepArgs sa{};
-            sa.tab = s->tab;
-            sa.nsteps = s->n;
-            sa.t = ti;
-            sa.eta = a->eta;
-            sa.mask = a->inpainting_mask_dev ? a->inpainting_mask_dev + eo : nullptr;
-            sa.motion = a->inpainted_motion_dev ? a->inpainted_motion_dev + eo : nullptr;
-            sa.noise = a->noise_mode == MST_NOISE_BUFFER ? a->noise_dev + (size_t)j * clip_elems + eo : nullptr;
-            sa.scale = a->scale_dev ? a->scale_dev + c0 : nullptr;
-            sa.x = a->x_dev + eo;
-            sa.sample = a->x_dev + eo;
-            sa.xstart = a->xstart_dump_dev ? a->xstart_dump_dev + (size_t)j * clip_elems + eo : nullptr;
-            sa.seed = a->seed;
-            sa.step = (unsigned)j;
-            sa.clip0 = (unsigned)c0;
-            sa.mask_noise = a->mask_noise;
-            sa.clip = a->clip_denoised;
-            sa.philox = a->noise_mode == MST_NOISE_PHILOX;
-            if (a->sampler == MST_SAMPLER_DDPM) CHECK(launch_out_nt<1>(e, ws, a->cfg, nb, a->frames, nullptr, sa, ss));
-            else CHECK(launch_out_nt<2>(e, ws, a->cfg, nb, a->frames, nullptr, sa, ss));
+        for (; j < nrun; j++) {
+            e->prof_now = e->prof_on && (j % e->prof_period == 0);
+            // instrumented steps run as ONE full-batch slice so the HIP-event durations are those of isolated
+            // full-batch launches (the roofline figures); all other steps use the concurrent slices
+            const int nsj = e->prof_now ? 1 : p.nsl;
+            if (nsj > 1 && !forked) { CHECK(fork_slices(e, p)); forked = true; }
+            else if (nsj == 1 && forked) { CHECK(join_slices(e, p)); forked = false; }
+            CHECK(enqueue_step(e, p, j, nsj));
         }
-    }
-    return 0;
+        return 0;
     };
     const int rc = steps();
     // join the slice streams whatever happened: after an error mid-loop the slices' work is still in flight on the
     // caller's tensors, so the caller's stream must not run ahead of it (best effort: errors here are not reported twice)
     if (forked) {
-        for (int i = 1; i < nsl; i++) {
-            if (hipEventRecord(e->ev_join[i - 1], streams[i]) == hipSuccess) (void)hipStreamWaitEvent(st, e->ev_join[i - 1], 0);
+        for (int i = 1; i < p.nsl; i++) {
+            if (hipEventRecord(e->ev_join[i - 1], p.streams[i]) == hipSuccess) (void)hipStreamWaitEvent(st, e->ev_join[i - 1], 0);
         }
     }
     e->prof_now = 0;
+    if (hipEventRecord(e->ev_out, st) == hipSuccess) (void)hipStreamWaitEvent(caller, e->ev_out, 0);
     return rc;
 }
 
@@ -1421,7 +1550,7 @@ extern "C" int mst_train_model_backward(mst_engine* e, const void* tape, const f
     CHECK(grad_scale_from(e, d_out, n_out, st));
     // output projection backward: token-stream gradient rows = (scaled d_out as frame rows) x W_out; token 0 gets none
     hipLaunchKernelGGL(k_frames_f16, dim3((frames + 31) / 32, e->kin_pad / 32, batch), dim3(256), 0, st, d_out, F, frames, e->kin_pad, e->xt,
-                       (const float*)w_.gscale);
+                       (const float*)w_.gscale, (const LoopDev*)nullptr, 0ull);
     hipLaunchKernelGGL(k_zero_token0, dim3((batch * MST_D + 255) / 256), dim3(256), 0, st, w_.g1, S, batch);
     HIPCHECK(hipGetLastError());
     {

@@ -504,7 +504,7 @@ struct DEpiEmbedOut {
     __device__ __forceinline__ int rows() const { return total; }
     template <int BT, int BF> static constexpr int smem_bytes() { return BF * (BT + 4) * 4; }
 
-    __device__ __forceinline__ void one(const StepCoef& sc, float mo, size_t idx, float nz, bool blend, bool use_mask) const {
+    __device__ __forceinline__ void one(const StepArgs& sa, const StepCoef& sc, float mo, size_t idx, float nz, bool blend, bool use_mask) const {
         if (MODE == 0) { out[idx] = mo; return; }
         const float mk = use_mask ? sa.mask[idx] : 0.f, mot = blend ? sa.motion[idx] : 0.f;
         float pred;
@@ -517,6 +517,7 @@ struct DEpiEmbedOut {
     __device__ __forceinline__ void run(f32x16 (&acc)[NX][MT][NT], int tok0, int f0, char* smem) const {
         constexpr int LDT = BT + 4;                          // floats per feature row of the tile
         DLane<BT, BF, MT, NT> lc;
+        const StepArgs sa = step_resolve(this->sa);          // loop mode: tensors and step index come from device memory
         float* tile = reinterpret_cast<float*>(smem);
 #pragma unroll
         for (int m = 0; m < MT; m++) {
@@ -586,7 +587,7 @@ struct DEpiEmbedOut {
                         philox_normal4((unsigned)(t >> 2), (unsigned)f, (unsigned)clip + sa.clip0, sa.step, sa.seed, nrm);
                         nz = nrm[t & 3];
                     }
-                    one(sc, acc4[j] + b, idx, nz, blend, use_mask);
+                    one(sa, sc, acc4[j] + b, idx, nz, blend, use_mask);
                 }
             }
         }

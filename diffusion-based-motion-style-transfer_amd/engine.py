@@ -295,6 +295,10 @@ class DenoiserEngine:
     def profile(self, on=True, period=16):
         N.check(N.lib().mst_profile_enable(self.handle, (period if period > 1 else 1) if on else 0))
 
+    def profile_event_overhead_us(self):
+        """Median duration an EMPTY event pair reports on the loop stream (calibrated when profiling is switched on)."""
+        return float(N.lib().mst_profile_event_overhead_us(self.handle))
+
     def profile_read(self):
         torch.cuda.current_stream(self.device).synchronize()
         names = (C.c_char_p * 16)()

@@ -296,6 +296,7 @@ int mst_recover_from_ric(const float* sample_dev, const float* mean_dev, const f
  * enabled: HIP events recorded around every launch on the caller's stream.  names/ms are arrays
  * of `cap` entries filled with per-kernel-family totals; returns the number of families. */
 int mst_profile_enable(mst_engine* e, int32_t on);
+float mst_profile_event_overhead_us(const mst_engine* e);   /* what an empty HIP-event pair reports: the fixed part of every event-timed launch */
 int mst_profile_read(mst_engine* e, const char** names, float* total_ms, int32_t* launches,
                      int32_t cap);
 

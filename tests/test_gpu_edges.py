@@ -162,3 +162,45 @@ def test_cfg_loop_in_slices_equals_clipwise_runs():
         parts.append(eng.sample_loop(sch, x0[i:i + 1].clone(), 3, 0, SAMPLER_DDPM, cfg=True, scale=scale[i:i + 1],
                                      mask=mask[i:i + 1], motion=motion[i:i + 1], noise=nz[:, i:i + 1].contiguous()))
     assert rel_l2(torch.cat(parts).cpu().numpy(), whole[[0, 6, 12]].cpu().numpy()) < 1e-6
+
+
+def test_graph_replayed_loop_equals_host_enqueued_loop(monkeypatch):
+    """MST_GRAPH=1: long loops replay a captured hipGraph of `MST_GRAPH_STEPS` denoise steps (tensors and the step index reach
+    the kernels through device memory); the default enqueues every step from the host.  Same kernels, same arithmetic: bit-identical
+    results, also when the instantiated graph is re-used by a second call with OTHER tensors and another seed, with recorded
+    noise + x0-hat dump (per-step buffers indexed by the device-side step counter), and under CFG."""
+    from mst_amd.engine import Schedule, SAMPLER_DDPM, SAMPLER_DDIM
+    from oracle import schedule
+    F, T, B, NS = 181, 76, 17, 53                  # 2 slices; 53 steps = 13 from the host + 2 replays of 20 (after the warm-up pass)
+    tab, tmap = schedule.make("cosine", 1000, "")
+    sch = Schedule(tab, tmap, dev())
+    shape = (B, F, 1, T)
+    txt = cu(syn.normal(SEED, "txtg", (B, 512)))
+    mask = cu(syn.root_horizontal_mask(B, F, T))
+    scale = cu(np.linspace(1.0, 3.0, B).astype(np.float32))
+    monkeypatch.setenv("MST_GRAPH", "0")
+    host, _, _ = make(F, T, 2 * B)
+    monkeypatch.setenv("MST_GRAPH", "1")
+    graph, _, _ = make(F, T, 2 * B)
+    for rnd in range(3):                            # round 0 warms + captures, rounds 1-2 re-use the instantiated graph
+        x0 = cu(syn.normal(SEED, f"xg/{rnd}", shape))
+        motion = cu(syn.normal(SEED, f"mg/{rnd}", shape))
+        outs = []
+        for eng in (host, graph):
+            eng.set_text(txt)
+            outs.append(eng.sample_loop(sch, x0.clone(), NS - 1, 0, SAMPLER_DDPM, mask=mask, motion=motion, seed=100 + rnd))
+        assert torch.equal(outs[0], outs[1]), rnd
+        assert torch.equal(outs[1][:, :3], motion[:, :3])
+    # recorded noise + x0-hat dump, DDIM with eta (other kernels, other flags -> a new capture)
+    nz = cu(np.stack([syn.normal(SEED, f"nzg/{k}", (B, F, 1, T)) for k in range(NS)]))
+    res = []
+    for eng in (host, graph):
+        eng.set_text(txt)
+        res.append(eng.sample_loop(sch, x0.clone(), NS - 1, 0, SAMPLER_DDIM, eta=0.3, mask=mask, motion=motion, noise=nz, dump_xstart=True))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    # classifier-free guidance (doubled batch, per-clip scales read through the device block)
+    res = []
+    for eng in (host, graph):
+        eng.set_text(txt, cfg=True)
+        res.append(eng.sample_loop(sch, x0.clone(), NS - 1, 0, SAMPLER_DDPM, cfg=True, scale=scale, mask=mask, motion=motion, seed=9))
+    assert torch.equal(res[0], res[1])
