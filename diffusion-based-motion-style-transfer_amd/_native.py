@@ -66,6 +66,10 @@ SIGNATURES = {
                                           C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mst_train_model_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float,
                                            C.c_uint64, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
+    "mst_motion_encoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                             C.c_float, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mst_motion_encoder_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float,
+                                              C.c_float, C.c_uint64, C.c_void_p, C.c_void_p]),
     "mst_train_wait_layer_grads": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "mst_dropout_mask": (C.c_int, [C.c_uint64, C.c_int32, C.c_int32, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p]),
     "mst_adamw_workspace_bytes": (C.c_int64, [C.c_int32, C.POINTER(C.c_int64)]),

@@ -179,6 +179,10 @@ struct StepArgs {
     // step j = ld->jbase + joff visits index t_start - j; tensors start `eo` elements into the caller's, per-step buffers
     // (noise, x0-hat dump) advance by `step_stride` elements per step; the slice's scales start at clip `clip0`.
     const LoopDev* ld; int joff; unsigned long long eo, step_stride;
+    // per (clip, feature) row of the inpainting mask: 0 = all zeros, 1 = all ones, 2 = mixed (k_mask_rowflags, once per loop).
+    // Rows flagged 0 / 1 skip the mask load, rows flagged 0 the motion load too: with the root_horizontal pattern (3 of 263
+    // rows masked) the step kernel stops re-reading two full fp32 tensors every step (26 MB of 66 MB per 64-clip launch).
+    const unsigned char* rowflag;
 };
 
 __device__ __forceinline__ StepArgs step_resolve(StepArgs sa) {

@@ -317,6 +317,46 @@ __global__ void k_philox_normal(float* __restrict__ out, int F, int T, unsigned 
 
 __global__ void k_loop_advance(LoopDev* ld, int n) { ld->jbase += n; }
 
+// MotionEncoder.forward (mdm_forstyledataset.py:104-110): tokens 0 / 1 of every clip = muQuery + pe[0] / sigmaQuery + pe[1]
+__global__ void k_query_tokens(const float* __restrict__ muq, const float* __restrict__ sigq, const float* __restrict__ pe, int S, int rows,
+                               f16* __restrict__ hi, f16* __restrict__ lo) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * 2 * MST_D) return;
+    const int clip = i / (2 * MST_D), r = i - clip * 2 * MST_D, tok = r / MST_D, f = r - tok * MST_D;
+    const float v = (tok == 0 ? muq[f] : sigq[f]) + pe[tok * MST_D + f];
+    const size_t o = ((size_t)clip * S + tok) * MST_D + f;
+    const f16 h = (f16)v;
+    hi[o] = h;
+    lo[o] = (f16)(v - (float)h);
+}
+// token 0 of every clip of an f16 hi/lo stream -> fp32 [rows][512]   (`final[0]`, :122)
+__global__ void k_gather_token0(const f16* __restrict__ hi, const f16* __restrict__ lo, int S, int rows, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * MST_D) return;
+    const size_t o = (size_t)(i / MST_D) * S * MST_D + (i % MST_D);
+    out[i] = (float)hi[o] + (float)lo[o];
+}
+// backward seed: g[clip][0][:] = scale[0] * d_mu[clip][:] (g zeroed by the caller)
+__global__ void k_scatter_token0(const float* __restrict__ d, const float* __restrict__ scale, int S, int rows, float* __restrict__ g) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * MST_D) return;
+    g[(size_t)(i / MST_D) * S * MST_D + (i % MST_D)] = d[i] * scale[0];
+}
+
+// one wave per (clip, feature) row of a [rows][T] 0/1 mask: 0 = all zeros, 1 = all ones, 2 = anything else
+__global__ __launch_bounds__(256) void k_mask_rowflags(const float* __restrict__ mask, int rows, int T, unsigned char* __restrict__ flags) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    bool z = true, o = true;
+    for (int t = lane; t < T; t += 64) {
+        const float v = mask[(size_t)row * T + t];
+        z &= v == 0.f;
+        o &= v == 1.f;
+    }
+    const bool az = __all(z), ao = __all(o);
+    if (lane == 0) flags[row] = az ? 0 : (ao ? 1 : 2);
+}
+
 // Post-sampling: normalised hml_vec clip [B][F][T] -> joint positions [B][T][J][3] in one launch
 // (sample.permute(0,2,3,1) * std + mean, then recover_from_ric: root yaw = running sum of the yaw velocities, root
 // XZ = running sum of the yaw-rotated XZ velocities, local joints rotated by the same yaw and moved to the root;

@@ -197,6 +197,7 @@ struct mst_engine {
     hipEvent_t ev_fork = nullptr, ev_join[MAX_SLICES - 1] = {nullptr, nullptr, nullptr};
     // sampling-loop state in device memory + the captured step graph (mst_sample_loop)
     LoopDev* ld_dev = nullptr;
+    unsigned char* rowflag = nullptr;     // [max_rows][feats] summary of the loop's inpainting mask (k_mask_rowflags)
     LoopDev* ld_pin = nullptr;            // pinned staging ring for the per-call upload
     static constexpr int LD_SLOTS = 8;
     hipEvent_t ld_ev[LD_SLOTS] = {nullptr};
@@ -335,6 +336,7 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     if (const char* v = getenv("MST_LN128_M")) e->ln128_min_m = atoi(v);
     CHECK(dmalloc(&e->zacc, (size_t)e->M_pad * MST_D));
     CHECK(dmalloc(&e->ld_dev, 1));
+    CHECK(dmalloc(&e->rowflag, (size_t)c->max_rows * c->feats));
     HIPCHECK(hipStreamCreateWithFlags(&e->loop_stream, hipStreamNonBlocking));
     HIPCHECK(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
     HIPCHECK(hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming));
@@ -377,6 +379,7 @@ extern "C" void mst_engine_destroy(mst_engine* e) {
     if (e->ev_in) (void)hipEventDestroy(e->ev_in);
     if (e->ev_out) (void)hipEventDestroy(e->ev_out);
     (void)hipFree(e->ld_dev);
+    (void)hipFree(e->rowflag);
     if (e->ld_pin) (void)hipHostFree(e->ld_pin);
     for (int i = 0; i < mst_engine::LD_SLOTS; i++) if (e->ld_ev[i]) (void)hipEventDestroy(e->ld_ev[i]);
     for (auto& pp : e->prof_pts) {
@@ -826,24 +829,24 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
 // output projection tiles: 64 frames x (256 * NTO) features, 8 waves as 1 x 8 with 2 x NTO MFMA tiles each
 template <int MODE, int NTO, int NX>
 static int launch_out(mst_engine* e, const WS& ws, int batch, int T, float* out, const StepArgs& sa, hipStream_t st,
-                      const f16* w_override = nullptr, const float* b_override = nullptr) {
-    const int S = T + 1;
-    RowsFrames xs{ws.hx, MST_D, T, S, batch * T, 64, (size_t)batch * S};
+                      const f16* w_override = nullptr, const float* b_override = nullptr, int tok_off = 1) {
+    const int S = T + tok_off;
+    RowsFrames xs{ws.hx, MST_D, T, S, batch * T, 64, (size_t)batch * S, tok_off};
     DEpiEmbedOut<MODE> epi{b_override ? b_override : e->b_pose_out, e->cfg.feats, T, batch * T, out, sa};
     return launch_gemm_dma<64, 256 * NTO, 2, NTO, 4, NX>(dim3((batch * T + 63) / 64, 1), xs, w_override ? w_override : e->w_pose_out, MST_D, MST_D, epi, st);
 }
 template <int MODE, int NTO>
 static int launch_out_nx(mst_engine* e, const WS& ws, int cfg, int batch, int T, float* out, const StepArgs& sa, hipStream_t st,
-                         const f16* wo = nullptr, const float* bo = nullptr) {
-    return cfg ? launch_out<MODE, NTO, 2>(e, ws, batch, T, out, sa, st, wo, bo) : launch_out<MODE, NTO, 1>(e, ws, batch, T, out, sa, st, wo, bo);
+                         const f16* wo = nullptr, const float* bo = nullptr, int tok_off = 1) {
+    return cfg ? launch_out<MODE, NTO, 2>(e, ws, batch, T, out, sa, st, wo, bo, tok_off) : launch_out<MODE, NTO, 1>(e, ws, batch, T, out, sa, st, wo, bo, tok_off);
 }
 template <int MODE>
 static int launch_out_nt(mst_engine* e, const WS& ws, int cfg, int batch, int T, float* out, const StepArgs& sa, hipStream_t st,
-                         const f16* wo = nullptr, const float* bo = nullptr) {
+                         const f16* wo = nullptr, const float* bo = nullptr, int tok_off = 1) {
     ProfScope ps(e, FAM_EMBED_OUT, st);
     switch (e->nt_out) {
-        case 1: return launch_out_nx<MODE, 1>(e, ws, cfg, batch, T, out, sa, st, wo, bo);
-        case 2: return launch_out_nx<MODE, 2>(e, ws, cfg, batch, T, out, sa, st, wo, bo);
+        case 1: return launch_out_nx<MODE, 1>(e, ws, cfg, batch, T, out, sa, st, wo, bo, tok_off);
+        case 2: return launch_out_nx<MODE, 2>(e, ws, cfg, batch, T, out, sa, st, wo, bo, tok_off);
     }
     return fail("output projection: feats %d unsupported", e->cfg.feats);
 }
@@ -920,6 +923,7 @@ static int enqueue_step(mst_engine* e, const LoopPlan& p, int joff, int nsj) {
         sa.joff = joff;
         sa.eo = eo;
         sa.step_stride = p.clip_elems;
+        sa.rowflag = (a->inpainting_mask_dev && a->inpainted_motion_dev) ? e->rowflag + (size_t)c0 * e->cfg.feats : nullptr;
         if (a->sampler == MST_SAMPLER_DDPM) CHECK(launch_out_nt<1>(e, ws, a->cfg, nb, a->frames, nullptr, sa, ss));
         else CHECK(launch_out_nt<2>(e, ws, a->cfg, nb, a->frames, nullptr, sa, ss));
     }
@@ -977,6 +981,11 @@ extern "C" int mst_sample_loop(mst_engine* e, const mst_schedule* s, const mst_l
                     a->seed, a->eta, a->t_start, nrun, 0, 0};
         HIPCHECK(hipMemcpyAsync(e->ld_dev, &h, sizeof(LoopDev), hipMemcpyHostToDevice, st));
         HIPCHECK(hipEventRecord(e->ld_ev[slot], st));
+    }
+    if (a->inpainting_mask_dev && a->inpainted_motion_dev) {      // once per loop: which mask rows the step kernel may skip
+        const int rows_m = a->batch * e->cfg.feats;
+        hipLaunchKernelGGL(k_mask_rowflags, dim3((rows_m + 3) / 4), dim3(256), 0, st, a->inpainting_mask_dev, rows_m, a->frames, e->rowflag);
+        HIPCHECK(hipGetLastError());
     }
     // what a captured graph depends on (everything else reaches the kernels through LoopDev)
     const int U = e->graph_steps;
@@ -1574,6 +1583,82 @@ extern "C" int mst_train_model_backward(mst_engine* e, const void* tape, const f
         hipLaunchKernelGGL(k_scale_f32, dim3(1024), dim3(256), 0, st, d_x, n_out, w_.gscale, 1, d_x);
         HIPCHECK(hipGetLastError());
     }
+    return 0;
+}
+
+// ---- MotionEncoder.forward (mdm_forstyledataset.py:90-124) as one native call: [muQuery | sigmaQuery | pose embedding of the
+// frames] + positional rows (+ its dropout), the 8 key-padding-masked layers of THIS engine, token 0 of the result.
+// key_keep: [batch][frames + 2] (1 = real key; the two query tokens are always 1).  The engine holds the encoder's own layers
+// and the prior's input projection / positional table (engine.load_state_dict with prior_prefix "mdm_model.").
+static int menc_check(mst_engine* e, int batch, int frames, float p_drop, float p_pe) {
+    if (!e) return fail("null engine");
+    const int S = frames + 2;
+    if (frames < 1 || S > e->S_max) return fail("motion encoder: %d frames + 2 query tokens exceed the engine's %d tokens", frames, e->S_max);
+    CHECK(train_check(e, batch, S, p_drop));
+    if (!(p_pe >= 0.f && p_pe < 1.f)) return fail("motion encoder: positional-encoding dropout %g outside [0, 1)", (double)p_pe);
+    return 0;
+}
+
+extern "C" int mst_motion_encoder_forward(mst_engine* e, const float* x, const float* mu_query, const float* sigma_query,
+                                          const uint8_t* key_keep, int32_t batch, int32_t frames, float p_drop, float p_pe,
+                                          uint64_t seed, void* tape, float* mu_out, void* stream) {
+    CHECK(menc_check(e, batch, frames, p_drop, p_pe));
+    if (!x || !mu_query || !sigma_query || !tape || !mu_out) return fail("mst_motion_encoder_forward: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    ON_DEVICE(e->cfg.device);
+    const int S = frames + 2, M = batch * S, nl = e->cfg.num_layers, F = e->cfg.feats, tot = batch * frames;
+    Tape t;
+    tape_layout((char*)tape, nl, tape_rows(M), &t);
+    e->prof_now = 0;
+    hipLaunchKernelGGL(k_query_tokens, dim3((batch * 2 * MST_D + 255) / 256), dim3(256), 0, st, mu_query, sigma_query, e->pe, S, batch, t.sh[0], t.sl[0]);
+    hipLaunchKernelGGL(k_frames_f16, dim3((frames + 31) / 32, e->kin_pad / 32, batch), dim3(256), 0, st, x, F, frames, e->kin_pad, e->xt,
+                       (const float*)nullptr, (const LoopDev*)nullptr, 0ull);
+    HIPCHECK(hipGetLastError());
+    {
+        DEpiEmbedIn epi{e->b_pose_in, e->pe, t.sh[0], t.sl[0], frames, S, tot, 0, 2};
+        CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1>(dim3((tot + 63) / 64, 1), RowsDirect{e->xt, e->kin_pad}, e->w_pose_in, e->kin_pad, e->kin_pad, epi, st)));
+    }
+    if (p_pe > 0.f) {
+        hipLaunchKernelGGL(k_dropout_stream, dim3(1024), dim3(256), 0, st, t.sh[0], t.sl[0], (size_t)M * MST_D, pe_drop(seed, p_pe));
+        HIPCHECK(hipGetLastError());
+    }
+    CHECK(train_stack_forward(e, t, batch, S, p_drop, seed, key_keep, st));
+    hipLaunchKernelGGL(k_gather_token0, dim3((batch * MST_D + 255) / 256), dim3(256), 0, st, t.sh[nl], t.sl[nl], S, batch, mu_out);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mst_motion_encoder_backward(mst_engine* e, const void* tape, const float* d_mu, const uint8_t* key_keep, int32_t batch,
+                                           int32_t frames, float p_drop, float p_pe, uint64_t seed, float* d_x, void* stream) {
+    CHECK(menc_check(e, batch, frames, p_drop, p_pe));
+    if (!tape || !d_mu || !d_x) return fail("mst_motion_encoder_backward: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    ON_DEVICE(e->cfg.device);
+    CHECK(train_ws(e));
+    TrainWS& w_ = e->tw;
+    const int S = frames + 2, M = batch * S, nl = e->cfg.num_layers, F = e->cfg.feats;
+    Tape t;
+    tape_layout((char*)const_cast<void*>(tape), nl, tape_rows(M), &t);
+    const size_t n = (size_t)M * MST_D, n_out = (size_t)batch * F * frames;
+    e->prof_now = 0;
+    CHECK(grad_scale_from(e, d_mu, (size_t)batch * MST_D, st));
+    HIPCHECK(hipMemsetAsync(w_.g1, 0, n * sizeof(float), st));                  // only token 0 of every clip carries a gradient
+    hipLaunchKernelGGL(k_scatter_token0, dim3((batch * MST_D + 255) / 256), dim3(256), 0, st, d_mu, (const float*)w_.gscale, S, batch, w_.g1);
+    HIPCHECK(hipGetLastError());
+    CHECK(train_stack_backward(e, t, batch, S, p_drop, seed, key_keep, nullptr, st));      // frozen stack: input gradient only
+    if (p_pe > 0.f) {
+        hipLaunchKernelGGL(k_mask_f32, dim3(1024), dim3(256), 0, st, w_.g1, n, pe_drop(seed, p_pe));
+        HIPCHECK(hipGetLastError());
+    }
+    // pose embedding backward on the frame tokens (rows 2..): d x[b][f][t] = sum_k W_in[k][f] g[b, 2 + t, k]
+    hipLaunchKernelGGL(k_f32_to_f16, dim3(1024), dim3(256), 0, st, w_.g1, n, w_.datt);
+    HIPCHECK(hipGetLastError());
+    WS ws = ws_slice(e, 0, frames);
+    ws.hx = w_.datt;
+    StepArgs sa{};
+    CHECK(launch_out_nt<0>(e, ws, 0, batch, frames, d_x, sa, st, e->w_pose_inT, w_.zeros, 2));
+    hipLaunchKernelGGL(k_scale_f32, dim3(1024), dim3(256), 0, st, d_x, n_out, w_.gscale, 1, d_x);
+    HIPCHECK(hipGetLastError());
     return 0;
 }
 

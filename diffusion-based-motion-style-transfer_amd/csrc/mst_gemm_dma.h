@@ -129,13 +129,14 @@ struct RowsDirect {                       // tile row r = matrix row tok0 + r
 struct RowsFrames {                       // tile row r = frame (tok0 + r) of the token stream, conditioning token skipped;
     const f16* X; int ld; int T, S, total;   // rows >= BT (second group) come from the uncond half (+cfg_rows)
     int BT; size_t cfg_rows;
+    int tok_off = 1;                          // tokens in front of the frames: 1 (conditioning token) or 2 (the motion encoder's mu / sigma queries)
     __device__ __forceinline__ const char* base() const { return reinterpret_cast<const char*>(X); }
     __device__ __forceinline__ unsigned rowbyte(int tok0, int r) const {
         int half = r >= BT ? 1 : 0;
         int tok = tok0 + r - half * BT;
         if (tok >= total) tok = total - 1;
         int clip = tok / T, t = tok - clip * T;
-        return (unsigned)((size_t)clip * S + 1 + t + half * cfg_rows) * (unsigned)ld * 2u;
+        return (unsigned)((size_t)clip * S + tok_off + t + half * cfg_rows) * (unsigned)ld * 2u;
     }
 };
 
@@ -437,6 +438,7 @@ struct DEpiResidLN {
 // the CFG uncond half (identical frames, only the conditioning token differs).
 struct DEpiEmbedIn {
     const float* bias; const float* pe; f16* hi; f16* lo; int T, S, total; size_t dup;
+    int tok_off = 1;                          // frame t becomes token tok_off + t (positional row included)
     __device__ __forceinline__ int rows() const { return total; }
     template <int BT, int BF> static constexpr int smem_bytes() { return BT * (MST_D * 4 + 16); }
     template <int BT, int BF, int MT, int NT>
@@ -465,7 +467,7 @@ struct DEpiEmbedIn {
             const int row = wave * RPW + r, tok = tok0 + row;
             if (tok >= total) continue;
             const int clip = tok / T, t = tok - clip * T;
-            const float* perow = pe + (size_t)(t + 1) * MST_D;
+            const float* perow = pe + (size_t)(t + tok_off) * MST_D;
             f32x4 xa = *reinterpret_cast<const f32x4*>(smem + row * LD + fa * 4);
             f32x4 xb = *reinterpret_cast<const f32x4*>(smem + row * LD + fb * 4);
             const f32x4 pa = *reinterpret_cast<const f32x4*>(perow + fa), pb = *reinterpret_cast<const f32x4*>(perow + fb);
@@ -474,7 +476,7 @@ struct DEpiEmbedIn {
                 xa[i] = xa[i] + ba[i] + pa[i];
                 xb[i] = xb[i] + bb[i] + pb[i];
             }
-            size_t off = ((size_t)clip * S + 1 + t) * MST_D;
+            size_t off = ((size_t)clip * S + tok_off + t) * MST_D;
             uint2 ha, la, hb, lb;
             split4_f16(xa, ha, la);
             split4_f16(xb, hb, lb);
@@ -556,8 +558,12 @@ struct DEpiEmbedOut {
                 if (MODE == 0) { *reinterpret_cast<f32x4*>(out + idx) = mo; continue; }
                 const f32x4 xv = *reinterpret_cast<const f32x4*>(sa.x + idx);
                 f32x4 mk = {0.f, 0.f, 0.f, 0.f}, mot = mk, nz = mk;
-                if (use_mask) mk = *reinterpret_cast<const f32x4*>(sa.mask + idx);
-                if (blend) mot = *reinterpret_cast<const f32x4*>(sa.motion + idx);
+                const int rf = sa.rowflag ? sa.rowflag[clip * F + f] : 2;      // 0: mask row all zeros, 1: all ones, 2: read it
+                if (use_mask) {
+                    if (rf == 2) mk = *reinterpret_cast<const f32x4*>(sa.mask + idx);
+                    else if (rf == 1) mk = f32x4{1.f, 1.f, 1.f, 1.f};
+                }
+                if (blend && rf != 0) mot = *reinterpret_cast<const f32x4*>(sa.motion + idx);   // mask 0: motion * 0 is +-0 whatever it holds
                 if (use_noise) nz = *reinterpret_cast<const f32x4*>(sa.noise + idx);
                 if (sa.philox) {
                     float nrm[4];

@@ -236,6 +236,28 @@ class DenoiserEngine:
                                                  N.ptr(d_x), arr, N.stream_ptr(self.device)))
         return d_x
 
+    def motion_encoder_forward(self, x, mu_query, sigma_query, key_keep, p_drop, p_pe, seed):
+        """MotionEncoder.forward natively: x [B, F, 1, T], queries [512] (or [1, 512]), key_keep bool [B, T + 2] -> (mu [B, 512], tape)."""
+        x = _f32c(x, self.device, "x")
+        B, F, one, T = x.shape
+        assert F * one == self.feats, (F, one, self.feats)
+        mq, sq = _f32c(mu_query.reshape(-1), self.device, "muQuery"), _f32c(sigma_query.reshape(-1), self.device, "sigmaQuery")
+        kk = self._key_keep(key_keep, B, T + 2)
+        tape = self.train_tape(B, T + 2)
+        mu = torch.empty((B, mq.numel()), dtype=torch.float32, device=self.device)
+        N.check(N.lib().mst_motion_encoder_forward(self.handle, N.ptr(x), N.ptr(mq), N.ptr(sq), N.ptr(kk), B, T, float(p_drop), float(p_pe),
+                                                   int(seed), N.ptr(tape), N.ptr(mu), N.stream_ptr(self.device)))
+        return mu, tape
+
+    def motion_encoder_backward(self, tape, d_mu, key_keep, frames, p_drop, p_pe, seed):
+        d_mu = _f32c(d_mu, self.device, "d_mu")
+        B = d_mu.shape[0]
+        kk = self._key_keep(key_keep, B, frames + 2)
+        d_x = torch.empty((B, self.feats, 1, frames), dtype=torch.float32, device=self.device)
+        N.check(N.lib().mst_motion_encoder_backward(self.handle, N.ptr(tape), N.ptr(d_mu), N.ptr(kk), B, frames, float(p_drop), float(p_pe),
+                                                    int(seed), N.ptr(d_x), N.stream_ptr(self.device)))
+        return d_x
+
     def wait_layer_grads(self, layer, stream):
         """Make the torch stream `stream` wait for layer `layer`'s parameter gradients of the most recent backward call."""
         N.check(N.lib().mst_train_wait_layer_grads(self.handle, int(layer), C.c_void_p(stream.cuda_stream)))

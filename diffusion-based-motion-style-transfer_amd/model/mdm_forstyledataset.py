@@ -328,8 +328,10 @@ class MotionEncoder(nn.Module, _EngineHost):
         return mdm
 
     def forward(self, x, y=None):
+        """-> (mu [bs, latent_dim], text feature or None).  One native call: frames -> pose embedding, [muQuery | sigmaQuery |
+        frames] + positional rows, the masked stack, token 0 (native_stack.MotionEncoderFn inside an autograd graph, the same
+        kernels without one)."""
         bs, njoints, nfeats, nframes = x.shape
-        frames = self.mdm_model.input_process(x)
         if y is not None:
             keep = y.get("mask").squeeze(1).squeeze(1).bool()
             enc_text = None
@@ -340,11 +342,22 @@ class MotionEncoder(nn.Module, _EngineHost):
         else:
             keep = torch.ones((bs, nframes), dtype=bool, device=x.device)
             enc_text = None
-        queries = torch.cat((self.muQuery[:1][None].repeat(1, bs, 1), self.sigmaQuery[:1][None].repeat(1, bs, 1)), axis=0)
-        seq = self.mdm_model.sequence_pos_encoder(torch.cat((queries, frames), axis=0))
-        keep = torch.cat((torch.ones((bs, 2), dtype=bool, device=x.device), keep), axis=1)
-        final = self._encoder_stack(seq, key_keep=keep)        # native, with or without an autograd graph
-        return final[0], enc_text
+        if x.device.type != "cuda":
+            raise RuntimeError("the native motion encoder runs on the GPU only; call .to('cuda') (there is no CPU fallback)")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("the native motion encoder is the FROZEN semantic discriminator of the fine-tune objective "
+                                      "(load_motion_enc freezes it); training it is not on this path")
+        keep = torch.cat((torch.ones((bs, 2), dtype=bool, device=x.device), keep.to(x.device)), axis=1)
+        stack, pe = self.seqTransEncoder, self.mdm_model.sequence_pos_encoder
+        p = stack.layers[0].dropout.p if stack.training else 0.0
+        p_pe = pe.dropout.p if pe.training else 0.0
+        from .native_stack import MotionEncoderFn, _draw_seed
+        if torch.is_grad_enabled() and x.requires_grad:
+            return MotionEncoderFn.apply(x, self, float(p), float(p_pe), keep), enc_text
+        eng = self.mst_engine(bs, nframes + 1)
+        mu, _tape = eng.motion_encoder_forward(x.detach(), self.muQuery.detach(), self.sigmaQuery.detach(), keep, float(p), float(p_pe),
+                                               _draw_seed(max(p, p_pe)))
+        return mu, enc_text
 
     # ---- engine plumbing: own (frozen) encoder layers + the prior's projections
     def _prior(self):

@@ -215,3 +215,24 @@ class EncoderStackFn(torch.autograd.Function):
             raise
         gi = d_in.permute(1, 0, 2).contiguous() if need_in else None
         return (gi, None, None, None) + (None,) * len(ctx.params)
+
+
+class MotionEncoderFn(torch.autograd.Function):
+    """MotionEncoder.forward (reference mdm_forstyledataset.py:90-124) as one node: pose embedding of the frames, the mu / sigma
+    query tokens, positional rows (+ dropout), the 8 key-padding-masked layers and the pick of token 0
+    (mst_motion_encoder_forward / _backward).  Every parameter on this path is frozen in the fine-tune objective, so the node
+    returns dL/dx only."""
+
+    @staticmethod
+    def forward(ctx, x, host, p_drop, p_pe, key_keep):
+        B, F, one, T = x.shape
+        eng = host.mst_engine(B, T + 1)
+        seed = _draw_seed(max(p_drop, p_pe))
+        mu, tape = eng.motion_encoder_forward(x.detach(), host.muQuery.detach(), host.sigmaQuery.detach(), key_keep, p_drop, p_pe, seed)
+        ctx.eng, ctx.tape, ctx.keep, ctx.T, ctx.p, ctx.p_pe, ctx.seed = eng, tape, key_keep, T, p_drop, p_pe, seed
+        return mu
+
+    @staticmethod
+    def backward(ctx, d_mu):
+        d_x = ctx.eng.motion_encoder_backward(_take_tape(ctx), d_mu.contiguous(), ctx.keep, ctx.T, ctx.p, ctx.p_pe, ctx.seed)
+        return d_x, None, None, None, None

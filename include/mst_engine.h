@@ -248,6 +248,22 @@ int mst_train_model_forward(mst_engine* e, const float* x_dev, const int64_t* t_
 int mst_train_model_backward(mst_engine* e, const void* tape_dev, const float* d_out_dev, int32_t batch,
                              int32_t frames, float p_drop, float p_pe, uint64_t seed, float* d_x_dev,
                              float* const* grads_host_array, void* stream);
+/* MotionEncoder.forward (model/mdm_forstyledataset.py:90-124), the frozen "semantic discriminator" of the fine-tune
+ * objective (gaussian_diffusion.py:1340-1343), as one native call each way:
+ *     frames = mdm_model.input_process(x);  seq = pos_encoder(cat(muQuery, sigmaQuery, frames));
+ *     mu = seqTransEncoder(seq, src_key_padding_mask=~keep)[0]
+ * x_dev [batch][feats][1][frames]; mu_query / sigma_query [512]; key_keep_dev [batch][frames + 2] bytes (1 = real key,
+ * the two query tokens first); mu_out_dev [batch][512].  Dropout (p_drop in the layers, p_pe behind the positional rows) is
+ * counter-based from `seed` as in mst_train_forward.  The backward call returns dL/dx only: every parameter on this path
+ * is frozen (train/finetune_style_diffusion.py:256, load_motion_enc :579-588).  The engine must hold the encoder's own
+ * layers and the prior's pose embedding / positional table, with max_frames >= frames + 1. */
+int mst_motion_encoder_forward(mst_engine* e, const float* x_dev, const float* mu_query_dev, const float* sigma_query_dev,
+                               const uint8_t* key_keep_dev, int32_t batch, int32_t frames, float p_drop, float p_pe,
+                               uint64_t seed, void* tape_dev, float* mu_out_dev, void* stream);
+int mst_motion_encoder_backward(mst_engine* e, const void* tape_dev, const float* d_mu_dev, const uint8_t* key_keep_dev,
+                                int32_t batch, int32_t frames, float p_drop, float p_pe, uint64_t seed, float* d_x_dev,
+                                void* stream);
+
 /* Data-parallel fine-tuning (BASELINE.json configs[3]; the reference is single-device, train/training_loop.py:73).
  * Make `stream` wait until every kernel that writes layer `layer`'s 12 gradient tensors in the MOST RECENT
  * mst_train_backward / mst_train_model_backward call (grads != NULL) has finished.  The backward calls only ENQUEUE
