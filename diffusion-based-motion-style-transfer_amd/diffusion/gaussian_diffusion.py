@@ -220,6 +220,24 @@ class GaussianDiffusion:
         return (_extract_into_tensor(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t
                 - _extract_into_tensor(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape) * eps)
 
+    def _predict_xstart_from_xprev(self, x_t, t, xprev):
+        """(xprev - coef2 * x_t) / coef1 (reference :287-297)."""
+        assert x_t.shape == xprev.shape
+        return (_extract_into_tensor(1.0 / self.posterior_mean_coef1, t, x_t.shape) * xprev
+                - _extract_into_tensor(self.posterior_mean_coef2 / self.posterior_mean_coef1, t, x_t.shape) * x_t)
+
+    def _xstart_from_output(self, out, x, t):
+        """What the model predicts -> x0-hat (reference :398-412).  The shipped factories only build START_X models
+        (utils/model_util.py:172); the other two parameterisations are converted with the reference's formulas in front of
+        the fused step kernel, which works on x0-hat."""
+        if self.model_mean_type == ModelMeanType.START_X:
+            return out
+        if self.model_mean_type == ModelMeanType.EPSILON:
+            return self._predict_xstart_from_eps(x, t, out)
+        if self.model_mean_type == ModelMeanType.PREVIOUS_X:
+            return self._predict_xstart_from_xprev(x, t, out)
+        raise NotImplementedError(self.model_mean_type)
+
     def _predict_eps_from_xstart(self, x_t, t, pred_xstart):
         return ((_extract_into_tensor(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t - pred_xstart)
                 / _extract_into_tensor(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape))
@@ -243,12 +261,14 @@ class GaussianDiffusion:
             m = th.ones_like(mask, dtype=th.float) * mask
             out = out * (1 - m) + motion * m
         var, logvar = self._variance_tables()
-        if self.model_mean_type != ModelMeanType.START_X:
-            raise NotImplementedError("this model family predicts x_start (utils/model_util.py:172)")
+        prev_x = out if self.model_mean_type == ModelMeanType.PREVIOUS_X else None
+        out = self._xstart_from_output(out, x, t)
         if denoised_fn is not None:
             out = denoised_fn(out)
         pred = out.clamp(-1, 1) if clip_denoised else out
         mean, _, _ = self.q_posterior_mean_variance(pred, x, t)
+        if prev_x is not None:
+            mean = prev_x                                  # the model output IS the posterior mean (:399-403)
         return {"mean": mean, "variance": _extract_into_tensor(var, t, x.shape),
                 "log_variance": _extract_into_tensor(logvar, t, x.shape), "pred_xstart": pred}
 
@@ -262,7 +282,7 @@ class GaussianDiffusion:
         if cond_fn is not None or denoised_fn is not None:
             raise NotImplementedError("cond_fn / denoised_fn are never set by this code base (SURVEY.md section 9)")
         with th.no_grad():
-            out = self._model_output(model, x, t, model_kwargs)
+            out = self._xstart_from_output(self._model_output(model, x, t, model_kwargs), x, t)
         noise = self._draw(x, const_noise)
         mask, motion = self._inpaint_pair(model_kwargs)
         nmask = self._noise_mask(model_kwargs)
@@ -386,7 +406,8 @@ class GaussianDiffusion:
         with_grad = cond_fn_with_grad or pred_xstart_in_graph
         denoiser, cfg, _ = _unwrap(model)
         sampler = _eng.SAMPLER_DDIM if ddim else _eng.SAMPLER_DDPM
-        if denoiser is not None and not with_grad and cond_fn is None and denoised_fn is None and not denoiser.training:
+        if (denoiser is not None and not with_grad and cond_fn is None and denoised_fn is None and not denoiser.training
+                and self.model_mean_type == ModelMeanType.START_X):
             yield from self._engine_loop(sampler, denoiser, cfg, img, indices, clip_denoised, model_kwargs, const_noise, eta,
                                          progress, chunked, want_xstart)
             return

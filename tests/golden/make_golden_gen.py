@@ -113,6 +113,26 @@ def main():
     out["neutral900|xstart_sel"] = allx[[0, 9, 49, 99]].reshape(4, F, 1, T)
     out["neutral900|norm"] = np.linalg.norm(allx.astype(np.float64), axis=1)
     out["neutral900|proj"] = (allx.astype(np.float64) @ projection().astype(np.float64).T).astype(np.float32)
+    # ---------------------------------------------------------------- eps- / previous-x-predicting models (gaussian_diffusion.py:398-412)
+    gd = importlib.import_module("diffusion.gaussian_diffusion")
+    fake = torch.from_numpy(syn.normal(SEED, "fake/out", (2, F, 1, T)))
+    xx = torch.from_numpy(syn.normal(SEED, "xia/x", (2, F, 1, T)))
+    tt = torch.tensor([0, 19])
+
+    class Fake(torch.nn.Module):
+        def forward(self, x_, ts, **kw):
+            return fake
+
+    for tag, mean_type in (("eps", gd.ModelMeanType.EPSILON), ("prevx", gd.ModelMeanType.PREVIOUS_X)):
+        d = rs.SpacedDiffusion(use_timesteps=rs.space_timesteps(1000, "ddim20"), betas=gd.get_named_beta_schedule("cosine", 1000),
+                               model_mean_type=mean_type, model_var_type=gd.ModelVarType.FIXED_SMALL, loss_type=gd.LossType.MSE)
+        with torch.no_grad(), mg.recorded_noise(f"mt/{tag}/p"):
+            r = d.p_sample(Fake(), xx, tt, clip_denoised=False, model_kwargs={"y": {}})
+        out[f"{tag}|p_sample|sample"], out[f"{tag}|p_sample|pred_xstart"] = r["sample"].numpy(), r["pred_xstart"].numpy()
+        if mean_type == gd.ModelMeanType.EPSILON:
+            with torch.no_grad(), mg.recorded_noise(f"mt/{tag}/d"):
+                r = d.ddim_sample(Fake(), xx, tt, clip_denoised=False, model_kwargs={"y": {}}, eta=0.5)
+            out[f"{tag}|ddim_sample|sample"] = r["sample"].numpy()
     np.savez_compressed(os.path.join(HERE, "gen.npz"), **out)
     print("gen.npz", os.path.getsize(os.path.join(HERE, "gen.npz")) // 1024, "KiB")
 
