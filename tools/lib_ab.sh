@@ -1,5 +1,7 @@
-# A/B two full library builds in one box: tools/lib_ab.sh <pathA> <pathB>
-for r in 1 2; do for v in "$@"; do
-  MST_ENGINE_LIB=$PWD/$v timeout -k 10 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/libab.log 2>&1
-  tail -1 gpurun_out/libab.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', d['value'], {k:v for k,v in d['roofline']['kernel_avg_us'].items() if v>0})"
+# A/B two full library builds on one box, interleaved rounds: tools/lib_ab.sh <pathA> <pathB> ...  ("default" = the in-tree library)
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+for r in 1 2 3; do for v in "$@"; do
+  if [ "$v" = default ]; then unset MST_ENGINE_LIB; else export MST_ENGINE_LIB=$PWD/$v; fi
+  timeout -k 10 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-boundary > gpurun_out/libab.log 2>&1
+  tail -1 gpurun_out/libab.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', d['value'], {k:v['avg_launch_us'] for k,v in d['roofline']['families'].items() if v['avg_launch_us']>10})"
 done; done
