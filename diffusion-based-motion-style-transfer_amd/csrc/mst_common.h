@@ -60,11 +60,12 @@ __device__ __forceinline__ f32x4 join4_f16(uint2 hi, uint2 lo) {
 
 // erf-form GELU (nn.TransformerEncoderLayer activation="gelu", mdm_forstyledataset.py:539-543).
 // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 absolute): branch-free, ~14 VALU ops + one
-// v_exp + one v_rcp.  libm's erff inlines to ~50 ops with data-dependent branches per element, which
+// v_exp + one v_rcp (the hardware reciprocal, 1 ulp: a correctly rounded 1/x is a ten-instruction
+// div_scale / fma / div_fixup sequence per element, a third of this function).  libm's erff inlines to ~50 ops with data-dependent branches per element, which
 // measured ~15-20 us per FFN1 launch; its extra accuracy is invisible behind the f16 store (2^-11).
 __device__ __forceinline__ float erf_as(float x) {
     const float ax = fabsf(x);
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
     float p = fmaf(1.061405429f, t, -1.453152027f);
     p = fmaf(p, t, 1.421413741f);
     p = fmaf(p, t, -0.284496736f);
@@ -72,6 +73,10 @@ __device__ __forceinline__ float erf_as(float x) {
     const float y = 1.0f - p * t * __expf(-ax * ax);
     return copysignf(y, x);
 }
+// LayerNorm's 1 / sqrt(var + eps): v_rsq_f32 (1 ulp) instead of v_sqrt + the correctly rounded division sequence; every
+// LayerNorm in the engine (fused tail, GEMM epilogue, training rows) goes through here so the paths agree bit for bit.
+__device__ __forceinline__ float ln_rstd(float sum_sq) { return __builtin_amdgcn_rsqf(sum_sq * (1.0f / MST_D) + 1e-5f); }
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
 
 // ------------------------------------------------------------------------------------------

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_ln_rows(const float* __restrict__ acc, 
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
-    const float rstd = 1.0f / sqrtf(s2 * (1.0f / MST_D) + 1e-5f);
+    const float rstd = ln_rstd(s2);
     const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + fa), gb = *reinterpret_cast<const f32x4*>(gamma + fb);
     const f32x4 ea = *reinterpret_cast<const f32x4*>(beta + fa), eb = *reinterpret_cast<const f32x4*>(beta + fb);
     f32x4 ya, yb;

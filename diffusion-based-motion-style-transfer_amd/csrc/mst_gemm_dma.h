@@ -412,7 +412,7 @@ struct DEpiResidLN {
         for (int r = 0; r < RPW; r++) {
             const int tok = tok0 + row0 + r;
             if (tok >= M) continue;
-            const float rstd = 1.0f / sqrtf(s2[r] * (1.0f / MST_D) + 1e-5f);
+            const float rstd = ln_rstd(s2[r]);
             f32x4 ya, yb;
 #pragma unroll
             for (int i = 0; i < 4; i++) {

@@ -161,7 +161,7 @@ __device__ __forceinline__ void tail_layernorm(f32x16 (&acc)[1][2][2], const Tai
     const f32x4 ea = *reinterpret_cast<const f32x4*>(beta + fa), eb = *reinterpret_cast<const f32x4*>(beta + fb);
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        const float rstd = 1.0f / sqrtf(s2[r] * (1.0f / MST_D) + 1e-5f);
+        const float rstd = ln_rstd(s2[r]);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             rv.a[r][i] = rv.a[r][i] * rstd * ga[i] + ea[i];
@@ -183,6 +183,15 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
     const int hh = lane >> 5, l31 = lane & 31;
     const int tok0 = blockIdx.x * C::BT;
     const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+#if defined(TAIL_STAMP)                                 // diagnostic build (probes/tail_clock.hip): shader-clock / 100 MHz stamps per phase
+#define TAIL_MARK(i) if (tid == 0) { g_tail_stamp[blockIdx.x][2 * (i)] = __builtin_amdgcn_s_memtime(); g_tail_stamp[blockIdx.x][2 * (i) + 1] = __builtin_amdgcn_s_memrealtime(); }
+    unsigned long long tl_last = 0, tl_sum[3] = {0, 0, 0};   // FFN loop split: FFN1 steps / GELU + H image / FFN2 steps (shader cycles)
+#define TAIL_LAP(j) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tl_sum[j] += now_ - tl_last; tl_last = now_; }
+#else
+#define TAIL_MARK(i)
+#define TAIL_LAP(j)
+#endif
+    TAIL_MARK(0)
 
     // ---- DMA addressing.  Weight slab s: this wave's 4 pieces are bytes [4096 wave, +4096) of the slab, linear on both sides.
     const unsigned w_voff = (unsigned)lane * 16u;
@@ -194,23 +203,41 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
     const unsigned a_voff = (unsigned)a_tok * (unsigned)(MST_D * 2) + (unsigned)(((lane & 7) ^ ((a_row >> 1) & 7)) << 4);
 
     auto issue_w = [&](int s) {                                          // weight slab s of the layer -> ring slot s % 3
+#if defined(TAIL_NODMA)                                 // timing ablation: MFMA + LDS reads on whatever the ring holds
+        return;
+#endif
         const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + C::OFF_W + (s % C::NW) * C::WSLAB + 4096 * wave);
         tail_glds4(w_voff, (unsigned long long)(wbase + (size_t)s * C::WSLAB), dst);
     };
     auto issue_a = [&](const f16* X, int ks, int aslot) {               // activation slab ks of X -> A slot
+#if defined(TAIL_NODMA)
+        return;
+#endif
         const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + C::OFF_A + aslot * C::ASLAB + 1024 * wave);
         tail_glds1(a_voff, (unsigned long long)(reinterpret_cast<const char*>(X) + ks * 128), dst);
     };
     // one slab against one activation slab: 4 k-steps of 16, A operand = weight rows of this wave, B = the two token tiles
     auto mma_slab = [&](const char* wslot, const char* aslab, f32x16& a0, f32x16& a1) {
+#if defined(TAIL_NOMMA)                                 // timing ablation: DMA stream, waits and barriers only
+        return;
+#endif
 #pragma unroll
         for (int k16 = 0; k16 < 4; k16++) {
             const int c = 2 * k16 + hh;
-            const f16x8 wf = *reinterpret_cast<const f16x8*>(wslot + ring_off_rb<128>(32 * wave + l31, c));
-            const f16x8 x0 = *reinterpret_cast<const f16x8*>(aslab + ring_off_rb<128>(l31, c));
-            const f16x8 x1 = *reinterpret_cast<const f16x8*>(aslab + ring_off_rb<128>(32 + l31, c));
+            f16x8 wf, x0, x1;
+#if defined(TAIL_NOREAD)                                // timing ablation: MFMAs on register garbage, no LDS reads
+            asm volatile("" : "=v"(wf), "=v"(x0), "=v"(x1));
+#else
+            wf = *reinterpret_cast<const f16x8*>(wslot + ring_off_rb<128>(32 * wave + l31, c));
+            x0 = *reinterpret_cast<const f16x8*>(aslab + ring_off_rb<128>(l31, c));
+            x1 = *reinterpret_cast<const f16x8*>(aslab + ring_off_rb<128>(32 + l31, c));
+#endif
+#if defined(TAIL_READONLY)                              // timing ablation: LDS reads only
+            asm volatile("" :: "v"(wf), "v"(x0), "v"(x1));
+#else
             a0 = mfma_f16(wf, x0, a0);
             a1 = mfma_f16(wf, x1, a1);
+#endif
         }
     };
 
@@ -268,6 +295,7 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
         mma_slab(smem + C::OFF_W + ((2 * ks + 1) % C::NW) * C::WSLAB, aslab, acc[0][0][1], acc[0][1][1]);
     }
     __syncthreads();                                       // ring dead (no DMA in flight): LayerNorm scratch overlays it
+    TAIL_MARK(1)
 
     const TailLane lm;
     TailRows rv;                                           // residual in, x1 = LayerNorm1 output out; lives through phase F
@@ -290,6 +318,7 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's x1 stores have reached L2 ...
     __syncthreads();                                       // ... and everybody's: the ring may re-read x1h, the scratch is dead
+    TAIL_MARK(2)
 
     // =========================================================================================== phase F: FFN
     zero_acc();
@@ -308,8 +337,12 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
     };
     issue_f(0);
     issue_f(1);
+#if defined(TAIL_STAMP)
+    tl_last = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll 1
     for (int hc = 0; hc < 4; hc++) {
+        TAIL_LAP(2)
 #pragma unroll
         for (int r = 0; r < 16; r++) { acch0[r] = 0.f; acch1[r] = 0.f; }
 #pragma unroll 1
@@ -318,6 +351,7 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
             f_sync(u);
             mma_slab(smem + C::OFF_W + ((C::P_STEPS + u) % C::NW) * C::WSLAB, smem + C::OFF_A + ((hc * 8 + v) % C::NA) * C::ASLAB, acch0, acch1);
         }
+        TAIL_LAP(0)
         {
             // GELU(acch + b1) -> H image: hidden feature j = 32 wave + 8 g + 4 hh + i of the chunk lives in activation slab
             // j / 64 at k = j % 64.  The previous chunk's FFN2 steps finished 8 barriers ago; the barrier of the next step
@@ -337,6 +371,7 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the raw s_barrier below waits for no counter
         }
+        TAIL_LAP(1)
 #pragma unroll 1
         for (int q = 0; q < 4; q++) {
             const char* hsl = smem + C::OFF_H + q * C::ASLAB;
@@ -347,7 +382,9 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
             mma_slab(smem + C::OFF_W + ((C::P_STEPS + u + 1) % C::NW) * C::WSLAB, hsl, acc[0][0][1], acc[0][1][1]);
         }
     }
+    TAIL_LAP(2)
     __syncthreads();
+    TAIL_MARK(3)
     tail_layernorm(acc, lm, smem, b2, g2, be2, rv);        // residual = x1 (still in registers), result = the stream rows
 #pragma unroll
     for (int r = 0; r < 8; r++) {
@@ -363,6 +400,12 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
             *reinterpret_cast<uint2*>(hl + off + fb) = l;
         }
     }
+    TAIL_MARK(4)
+#if defined(TAIL_STAMP)
+    if (tid == 0) { g_tail_stamp[blockIdx.x][10] = tl_sum[0]; g_tail_stamp[blockIdx.x][11] = tl_sum[1]; g_tail_stamp[blockIdx.x][12] = tl_sum[2]; }
+#endif
+#undef TAIL_LAP
+#undef TAIL_MARK
 }
 
 }  // namespace mst

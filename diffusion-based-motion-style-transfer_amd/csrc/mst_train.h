@@ -272,7 +272,7 @@ struct DEpiResidLNTrain {
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
-            const float rstd = 1.0f / sqrtf(s2 * (1.0f / MST_D) + 1e-5f);
+            const float rstd = ln_rstd(s2);
             f32x4 ya, yb;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void k_ln_rows_train(const float* __restrict__
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
-    const float rstd = 1.0f / sqrtf(s2 * (1.0f / MST_D) + 1e-5f);
+    const float rstd = ln_rstd(s2);
     const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + fa), gb = *reinterpret_cast<const f32x4*>(gamma + fb);
     const f32x4 ea = *reinterpret_cast<const f32x4*>(beta + fa), eb = *reinterpret_cast<const f32x4*>(beta + fb);
     f32x4 ya, yb;
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ g, con
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
-        const float rstd = 1.0f / sqrtf(s2 * (1.0f / MST_D) + 1e-5f);
+        const float rstd = ln_rstd(s2);
         float c1 = 0.f, c2 = 0.f;
         f32x4 aa, ab;
 #pragma unroll
