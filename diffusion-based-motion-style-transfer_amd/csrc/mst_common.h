@@ -1,5 +1,6 @@
 // Shared device helpers for the gfx950 denoising kernels (wave64, MFMA 32x32x16 f16).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -45,11 +46,47 @@ __device__ __forceinline__ uint2 pack4_f16(float a, float b, float c, float d) {
 // anyway, lo = f16(y - hi) carries the next 11 mantissa bits, so hi + lo reproduces the fp32 value to
 // ~2^-22 relative.  Versus fp32 + a separate f16 copy this removes 12.9 MB of HBM writes from each of
 // the HBM-bound LayerNorm epilogues (64.5 -> 51.6 MB per launch at batch 64).
+// acc + (f16 half of a packed pair), one v_fma_mix_f32 (the f16 operand is converted inside the FMA): HI selects the upper half.
+template <int HI> __device__ __forceinline__ float add_half(unsigned packed, float acc) {
+    float d;
+    if constexpr (HI) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(packed), "v"(acc));
+    else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(packed), "v"(acc));
+    return d;
+}
+template <int HI> __device__ __forceinline__ float sub_half(unsigned packed, float acc) {      // acc - half
+    float d;
+    if constexpr (HI) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(packed), "v"(acc));
+    else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(packed), "v"(acc));
+    return d;
+}
+// y -> (hi, lo) f16 pairs with hi = f16(y), lo = f16(y - hi): the stream's storage format (~22 significant bits)
 __device__ __forceinline__ void split4_f16(const f32x4& y, uint2& hi, uint2& lo) {
     f16x4 h = {(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
-    f16x4 l = {(f16)(y[0] - (float)h[0]), (f16)(y[1] - (float)h[1]), (f16)(y[2] - (float)h[2]), (f16)(y[3] - (float)h[3])};
     hi = __builtin_bit_cast(uint2, h);
+    f16x4 l = {(f16)sub_half<0>(hi.x, y[0]), (f16)sub_half<1>(hi.x, y[1]), (f16)sub_half<0>(hi.y, y[2]), (f16)sub_half<1>(hi.y, y[3])};
     lo = __builtin_bit_cast(uint2, l);
+}
+// base + hi + lo, two mixed-precision FMAs per element (no separate conversions)
+__device__ __forceinline__ f32x4 add4_f16(uint2 hi, uint2 lo, const f32x4& base) {
+    f32x4 y = {add_half<0>(hi.x, add_half<0>(lo.x, base[0])), add_half<1>(hi.x, add_half<1>(lo.x, base[1])),
+               add_half<0>(hi.y, add_half<0>(lo.y, base[2])), add_half<1>(hi.y, add_half<1>(lo.y, base[3]))};
+    return y;
+}
+// Sum over the 64 lanes of a wave, returned wave-uniform (an SGPR): four row_shr steps inside the 16-lane rows, row_bcast:15 /
+// row_bcast:31 across them (six v_add_f32 with DPP operands; __shfl_xor is a ds_bpermute + add per step and lane).
+__device__ __forceinline__ float wave_sum(float v) {
+    auto step = [](float x, auto ctrl, auto rmask) {
+        constexpr int C = decltype(ctrl)::value, R = decltype(rmask)::value;
+        return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), C, R, 0xf, false));
+    };
+    using std::integral_constant;
+    v = step(v, integral_constant<int, 0x111>(), integral_constant<int, 0xf>());      // row_shr:1
+    v = step(v, integral_constant<int, 0x112>(), integral_constant<int, 0xf>());      // row_shr:2
+    v = step(v, integral_constant<int, 0x114>(), integral_constant<int, 0xf>());      // row_shr:4
+    v = step(v, integral_constant<int, 0x118>(), integral_constant<int, 0xf>());      // row_shr:8  -> lane 15 of a row = the row's sum
+    v = step(v, integral_constant<int, 0x142>(), integral_constant<int, 0xa>());      // row_bcast:15 into rows 1, 3
+    v = step(v, integral_constant<int, 0x143>(), integral_constant<int, 0xc>());      // row_bcast:31 into rows 2, 3 -> lane 63 = the total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ f32x4 join4_f16(uint2 hi, uint2 lo) {
     const f16x4 h = __builtin_bit_cast(f16x4, hi), l = __builtin_bit_cast(f16x4, lo);

@@ -106,8 +106,10 @@ __device__ __forceinline__ void tail_glds1(unsigned voff, unsigned long long sba
 // normalised rows out -- in the same registers, so LayerNorm1's output stays on chip as LayerNorm2's residual.
 struct TailRows { f32x4 a[8], b[8]; };
 
+// `resid(r, xa, xb)` adds row 8 wave + r's residual to (xa, xb) = this lane's two 4-feature groups.
+template <class Resid>
 __device__ __forceinline__ void tail_layernorm(f32x16 (&acc)[1][2][2], const TailLane& lc, char* scratch, const float* __restrict__ bias,
-                                               const float* __restrict__ gamma, const float* __restrict__ beta, TailRows& rv) {
+                                               const float* __restrict__ gamma, const float* __restrict__ beta, TailRows& rv, Resid resid) {
     constexpr int LD = MST_D * 4 + 16;
 #pragma unroll
     for (int m = 0; m < 2; m++) {
@@ -124,49 +126,31 @@ __device__ __forceinline__ void tail_layernorm(f32x16 (&acc)[1][2][2], const Tai
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fa = lane * 4, fb = 256 + lane * 4;
     const f32x4 ba = *reinterpret_cast<const f32x4*>(bias + fa), bb = *reinterpret_cast<const f32x4*>(bias + fb);
-    float s[8], s2[8];
+    float mean[8], rstd[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const int row = wave * 8 + r;
-        const f32x4 ta = *reinterpret_cast<const f32x4*>(scratch + row * LD + fa * 4);
-        const f32x4 tb = *reinterpret_cast<const f32x4*>(scratch + row * LD + fb * 4);
-        s[r] = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            rv.a[r][i] = ta[i] + ba[i] + rv.a[r][i];
-            rv.b[r][i] = tb[i] + bb[i] + rv.b[r][i];
-            s[r] += rv.a[r][i] + rv.b[r][i];
-        }
+        f32x4 xa = *reinterpret_cast<const f32x4*>(scratch + row * LD + fa * 4) + ba;
+        f32x4 xb = *reinterpret_cast<const f32x4*>(scratch + row * LD + fb * 4) + bb;
+        resid(r, xa, xb);
+        rv.a[r] = xa;
+        rv.b[r] = xb;
+        const f32x4 t = xa + xb;
+        mean[r] = wave_sum((t[0] + t[1]) + (t[2] + t[3])) * (1.0f / MST_D);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int r = 0; r < 8; r++) s[r] += __shfl_xor(s[r], o);
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        const float mean = s[r] * (1.0f / MST_D);
-        s2[r] = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            rv.a[r][i] -= mean;
-            rv.b[r][i] -= mean;
-            s2[r] += rv.a[r][i] * rv.a[r][i] + rv.b[r][i] * rv.b[r][i];
-        }
+        rv.a[r] -= mean[r];
+        rv.b[r] -= mean[r];
+        const f32x4 q = rv.a[r] * rv.a[r] + rv.b[r] * rv.b[r];
+        rstd[r] = ln_rstd(wave_sum((q[0] + q[1]) + (q[2] + q[3])));
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int r = 0; r < 8; r++) s2[r] += __shfl_xor(s2[r], o);
     const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + fa), gb = *reinterpret_cast<const f32x4*>(gamma + fb);
     const f32x4 ea = *reinterpret_cast<const f32x4*>(beta + fa), eb = *reinterpret_cast<const f32x4*>(beta + fb);
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        const float rstd = ln_rstd(s2[r]);
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            rv.a[r][i] = rv.a[r][i] * rstd * ga[i] + ea[i];
-            rv.b[r][i] = rv.b[r][i] * rstd * gb[i] + eb[i];
-        }
+        rv.a[r] = rv.a[r] * (ga * rstd[r]) + ea;
+        rv.b[r] = rv.b[r] * (gb * rstd[r]) + eb;
     }
 }
 
@@ -298,13 +282,11 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
     TAIL_MARK(1)
 
     const TailLane lm;
-    TailRows rv;                                           // residual in, x1 = LayerNorm1 output out; lives through phase F
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        rv.a[r] = join4_f16(rh_a[r], rl_a[r]);
-        rv.b[r] = join4_f16(rh_b[r], rl_b[r]);
-    }
-    tail_layernorm(acc, lm, smem, b_out, g1, be1, rv);
+    TailRows rv;                                           // x1 = LayerNorm1 output; lives through phase F as LayerNorm2's residual
+    tail_layernorm(acc, lm, smem, b_out, g1, be1, rv, [&](int r, f32x4& xa, f32x4& xb) {
+        xa = add4_f16(rh_a[r], rl_a[r], xa);
+        xb = add4_f16(rh_b[r], rl_b[r], xb);
+    });
     // x1's f16 operand copy -> global scratch: phase F re-reads it through the activation ring (L2-hot; the LDS has no room
     // for a resident 64 KB image beside the weight ring).  The fp32 rows stay in `rv` as LayerNorm2's residual.
 #pragma unroll
@@ -385,7 +367,11 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
     TAIL_LAP(2)
     __syncthreads();
     TAIL_MARK(3)
-    tail_layernorm(acc, lm, smem, b2, g2, be2, rv);        // residual = x1 (still in registers), result = the stream rows
+    {
+        TailRows x2;                                       // residual = x1 (still in registers), result = the stream rows
+        tail_layernorm(acc, lm, smem, b2, g2, be2, x2, [&](int r, f32x4& xa, f32x4& xb) { xa += rv.a[r]; xb += rv.b[r]; });
+        rv = x2;
+    }
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const int tok = tok0 + 8 * wave + r;

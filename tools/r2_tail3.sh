@@ -1,6 +1,6 @@
-# hardware rcp / rsq in GELU and LayerNorm: phase stamps (old header as the same-box reference), parity, library A/B
+# tail LayerNorm/GELU VALU work: phase stamps (previous header as the same-box reference), parity, library A/B
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-PROBES="tail_clock_v1 tail_clock" bash tools/r2_clock2.sh | grep "rep 2\|==" &&
+PROBES="tail_clock_prev tail_clock" bash tools/r2_clock2.sh | grep "rep 2\|==" &&
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r2_tests_tail3.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/r2_tests_tail3.log
 bash tools/lib_ab.sh lib_prev_tail.so default
