@@ -209,7 +209,8 @@ struct QATile {
     static constexpr int RING = NSTAGE * STAGE;
     static constexpr int XROWS = XR;
     static constexpr int KV = NKT * 32 * 256 * 2;       // K and V images afterwards (reuse the ring)
-    static constexpr int SMEM = RING > KV ? RING : KV;
+    static constexpr int OFF_BIAS = RING > KV ? RING : KV;   // q | k | v bias of the head (384 floats), staged once at kernel start
+    static constexpr int SMEM = OFF_BIAS + 3 * MST_HD * 4;
 };
 
 template <int NKT>
@@ -246,6 +247,10 @@ __global__ __launch_bounds__(512) void k_qkv_attention(const f16* __restrict__ h
     const int hh = lane >> 5, l31 = lane & 31;
     const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     const f16* xbase = hx + (size_t)clip * S * MST_D;
+    // The head's projection bias goes to LDS now: read from global memory in the epilogue, its ~1 us of load latency sat in
+    // front of the K / V image stores with every wave waiting (the barriers of the projection loop publish these writes).
+    float* bias_s = reinterpret_cast<float*>(smem + TL::OFF_BIAS);
+    if (tid < 3 * MST_HD) bias_s[tid] = b_in[(tid >> 7) * MST_D + head * MST_HD + (tid & 127)];
 
     // ---- DMA plan: tile rows [0, XR) = the clip's tokens (clamped), [XR, XR+384) = q|k|v weight rows of the head
     auto rowbyte = [&](int row) {
@@ -416,9 +421,9 @@ __global__ __launch_bounds__(512) void k_qkv_attention(const f16* __restrict__ h
     const int tok = wave * 32 + l31;                    // this lane's token = query = key row
     if (active) {
         const float scale = 0.08838834764831845f;       // 1/sqrt(128), applied to q in fp32 before rounding
-        const float* bq = b_in + head * MST_HD;
-        const float* bk = b_in + MST_D + head * MST_HD;
-        const float* bv = b_in + 2 * MST_D + head * MST_HD;
+        const float* bq = bias_s;
+        const float* bk = bias_s + MST_HD;
+        const float* bv = bias_s + 2 * MST_HD;
 #pragma unroll
         for (int n = 0; n < 4; n++)
 #pragma unroll
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(512) void k_qkv_attention(const f16* __restrict__ h
                 }
             }
     } else if (BAL && wave == 7) {
-        const float* bv = b_in + 2 * MST_D + head * MST_HD;
+        const float* bv = bias_s + 2 * MST_HD;
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             const int tk = (4 + j) * 32 + l31;

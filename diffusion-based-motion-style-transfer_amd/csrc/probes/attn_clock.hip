@@ -8,7 +8,10 @@
 #include <vector>
 #define QA_STAMP
 __device__ unsigned long long g_qa_stamp[1024][10];
-#include "../mst_attn.h"
+#ifndef ATTN_HEADER
+#define ATTN_HEADER "../mst_attn.h"
+#endif
+#include ATTN_HEADER
 using namespace mst;
 
 int main(int argc, char** argv) {
