@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-PROBES="tail_clock_prev tail_clock" bash tools/r2_clock2.sh | grep "rep 2\|==" &&
+PROBES="${KPROBES:-tail_clock_prev tail_clock}" bash tools/r2_clock2.sh | grep "rep 2\|==" &&
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r2_tests_tail5.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/r2_tests_tail5.log
 bash tools/lib_ab.sh lib_prev_tail.so default
