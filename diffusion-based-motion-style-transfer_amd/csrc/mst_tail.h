@@ -225,6 +225,41 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
         }
     };
 
+    // The two steps of a (k-slab, feature-half) pair -- out-proj and FFN2 -- multiply the SAME activation slab: its eight token
+    // fragments are read once, by the first step, and stay in registers for the second (8 + 4 fragment reads per pair instead
+    // of 12 + 12; fragment reads are one of the three ~0.5 kW consumers of DESIGN.md section 4 "Power").
+#ifndef TAIL_XREUSE
+#define TAIL_XREUSE 1
+#endif
+    f16x8 xk0[4], xk1[4];
+    auto mma_first = [&](const char* wslot, const char* aslab, f32x16& a0, f32x16& a1) {
+#if !TAIL_XREUSE || defined(TAIL_NOMMA) || defined(TAIL_NOREAD) || defined(TAIL_READONLY)
+        mma_slab(wslot, aslab, a0, a1);
+#else
+#pragma unroll
+        for (int k16 = 0; k16 < 4; k16++) {
+            const int c = 2 * k16 + hh;
+            const f16x8 wf = *reinterpret_cast<const f16x8*>(wslot + ring_off_rb<128>(32 * wave + l31, c));
+            xk0[k16] = *reinterpret_cast<const f16x8*>(aslab + ring_off_rb<128>(l31, c));
+            xk1[k16] = *reinterpret_cast<const f16x8*>(aslab + ring_off_rb<128>(32 + l31, c));
+            a0 = mfma_f16(wf, xk0[k16], a0);
+            a1 = mfma_f16(wf, xk1[k16], a1);
+        }
+#endif
+    };
+    auto mma_second = [&](const char* wslot, const char* aslab, f32x16& a0, f32x16& a1) {
+#if !TAIL_XREUSE || defined(TAIL_NOMMA) || defined(TAIL_NOREAD) || defined(TAIL_READONLY)
+        mma_slab(wslot, aslab, a0, a1);
+#else
+#pragma unroll
+        for (int k16 = 0; k16 < 4; k16++) {
+            const f16x8 wf = *reinterpret_cast<const f16x8*>(wslot + ring_off_rb<128>(32 * wave + l31, 2 * k16 + hh));
+            a0 = mfma_f16(wf, xk0[k16], a0);
+            a1 = mfma_f16(wf, xk1[k16], a1);
+        }
+#endif
+    };
+
     // b1 (1024 floats) into LDS once: the GELU step then needs no global load inside the DMA-counted loop (an ordinary load
     // there makes hipcc wait vmcnt(0), draining the ring: cdna guide section 5, "three .s-level traps" (b))
     float* b1s = reinterpret_cast<float*>(smem + C::OFF_B);
@@ -274,9 +309,9 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
     for (int ks = 0; ks < 8; ks++) {
         const char* aslab = smem + C::OFF_A + (ks % C::NA) * C::ASLAB;
         p_sync(2 * ks);
-        mma_slab(smem + C::OFF_W + ((2 * ks) % C::NW) * C::WSLAB, aslab, acc[0][0][0], acc[0][1][0]);
+        mma_first(smem + C::OFF_W + ((2 * ks) % C::NW) * C::WSLAB, aslab, acc[0][0][0], acc[0][1][0]);
         p_sync(2 * ks + 1);
-        mma_slab(smem + C::OFF_W + ((2 * ks + 1) % C::NW) * C::WSLAB, aslab, acc[0][0][1], acc[0][1][1]);
+        mma_second(smem + C::OFF_W + ((2 * ks + 1) % C::NW) * C::WSLAB, aslab, acc[0][0][1], acc[0][1][1]);
     }
     __syncthreads();                                       // ring dead (no DMA in flight): LayerNorm scratch overlays it
     TAIL_MARK(1)
@@ -359,9 +394,9 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
             const char* hsl = smem + C::OFF_H + q * C::ASLAB;
             const int u = 16 * hc + 8 + 2 * q;
             f_sync(u);
-            mma_slab(smem + C::OFF_W + ((C::P_STEPS + u) % C::NW) * C::WSLAB, hsl, acc[0][0][0], acc[0][1][0]);
+            mma_first(smem + C::OFF_W + ((C::P_STEPS + u) % C::NW) * C::WSLAB, hsl, acc[0][0][0], acc[0][1][0]);
             f_sync(u + 1);
-            mma_slab(smem + C::OFF_W + ((C::P_STEPS + u + 1) % C::NW) * C::WSLAB, hsl, acc[0][0][1], acc[0][1][1]);
+            mma_second(smem + C::OFF_W + ((C::P_STEPS + u + 1) % C::NW) * C::WSLAB, hsl, acc[0][0][1], acc[0][1][1]);
         }
     }
     TAIL_LAP(2)
