@@ -10,7 +10,7 @@ timeout -k 10 300 python bench.py --steps 1 --warmup 1 --cfg --no-cpu-baseline >
 timeout -k 10 300 python bench.py --steps 1 --warmup 1 --batch 128 --no-cpu-baseline > gpurun_out/r2f_bench_batch128.json 2>/dev/null; echo "b128 $(cut -c60-130 gpurun_out/r2f_bench_batch128.json)"
 timeout -k 10 300 python bench.py --mode finetune --steps 10 --warmup 3 > gpurun_out/r2f_bench_finetune.json 2>/dev/null; echo "ft $(cut -c1-200 gpurun_out/r2f_bench_finetune.json)"
 P=diffusion-based-motion-style-transfer_amd/csrc/probes/bin
-( for b in attn_clock attn_clock_NODMA attn_clock_NOMMA attn_clock_NOREAD attn_clock_READONLY attn_clock_NODMA_NOREAD attn_clock_NODMA_READONLY tail_clock tail_clock_NODMA tail_clock_NOMMA tail_clock_NODMA_NOREAD tail_clock_NODMA_READONLY; do echo "== $b"; timeout -k 10 100 $P/$b | tail -1 || exit 1; done ) > gpurun_out/r2f_phase_stamps.txt 2>&1
+( for b in attn_clock attn_clock_NODMA attn_clock_NOMMA attn_clock_NOREAD attn_clock_READONLY attn_clock_NODMA_NOREAD attn_clock_NODMA_READONLY attn_clock_PRODUCER tail_clock tail_clock_NODMA tail_clock_NOMMA tail_clock_NODMA_NOREAD tail_clock_NODMA_READONLY; do echo "== $b"; timeout -k 10 100 $P/$b | tail -1 || exit 1; done ) > gpurun_out/r2f_phase_stamps.txt 2>&1
 echo "stamps rc=$?"
 export MST_STREAMS=1
 B="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-boundary"
