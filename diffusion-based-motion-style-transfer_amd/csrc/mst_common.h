@@ -143,11 +143,13 @@ __device__ __forceinline__ void philox_normal4(uint32_t tq, uint32_t f, uint32_t
     float u1 = (float)(r[1] >> 8) * (1.0f / 16777216.0f);
     float u2 = ((float)(r[2] >> 8) + 1.0f) * (1.0f / 16777216.0f);
     float u3 = (float)(r[3] >> 8) * (1.0f / 16777216.0f);
-    float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
-    float sa, ca, sb, cb;
-    sincosf(6.283185307179586f * u1, &sa, &ca);
-    sincosf(6.283185307179586f * u3, &sb, &cb);
-    n[0] = ra * ca; n[1] = ra * sa; n[2] = rb * cb; n[3] = rb * sb;
+    // Box-Muller on the hardware transcendentals: v_log_f32 (log2, 1 ulp), v_sqrt_f32, v_sin_f32 / v_cos_f32 (argument in
+    // revolutions: u1 itself).  libm's logf / sqrtf / sincosf are ~170 instructions per four normals, half of this function and
+    // ~6 us of VALU per denoise step; the in-kernel draw and `mst_philox_normal` share this code, so they stay bit-identical.
+    const float ra = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));      // sqrt(-2 ln u0)
+    const float rb = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u2));
+    n[0] = ra * __builtin_amdgcn_cosf(u1); n[1] = ra * __builtin_amdgcn_sinf(u1);
+    n[2] = rb * __builtin_amdgcn_cosf(u3); n[3] = rb * __builtin_amdgcn_sinf(u3);
 }
 
 // ------------------------------------------------------------------------------------------
