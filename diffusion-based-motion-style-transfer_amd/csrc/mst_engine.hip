@@ -184,6 +184,7 @@ struct mst_engine {
     int dbg_layer = -1, dbg_stage = -1;   // stop the trunk after (layer, stage); -1 = run everything
     int fuse_qkv_attn = 1;                // K4 + K5 as one kernel per (clip, head); MST_FUSE_QKV_ATTN=0 keeps them apart
     int fuse_tail = 1;                    // K6 + K7 + K8 as one kernel per 64-token tile (mst_tail.h); MST_FUSE_TAIL=0 keeps them apart
+    int fuse_frames = 1;                  // sampling loop: a step's epilogue writes the next step's f16 frame rows; MST_FUSE_FRAMES=0 runs k_frames_f16 every step
     int small_m = 2048;                   // launches of at most this many token rows take the small-tile path (MST_SMALL_M, 0 = never);
                                           // tools/small_m_sweep.sh: 8 clips (1576 rows) 722 -> 417 us/step, 11-clip slices (2167 rows) 766 vs 796
     float* zacc = nullptr;                // fp32 GEMM result feeding k_ln_rows on that path
@@ -333,6 +334,7 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     }
     if (const char* v = getenv("MST_FUSE_QKV_ATTN")) e->fuse_qkv_attn = atoi(v) != 0;
     if (const char* v = getenv("MST_FUSE_TAIL")) e->fuse_tail = atoi(v) != 0;
+    if (const char* v = getenv("MST_FUSE_FRAMES")) e->fuse_frames = atoi(v) != 0;
     if (const char* v = getenv("MST_WGRAD_STREAM")) e->wgrad_stream_on = atoi(v) != 0;
     if (const char* v = getenv("MST_SMALL_M")) e->small_m = atoi(v);
     if (const char* v = getenv("MST_LN128_M")) e->ln128_min_m = atoi(v);
@@ -701,7 +703,7 @@ static int launch_tail(const LayerW& w, const WS& ws, int M, hipStream_t st) {
 
 // K3 .. K8: token stream through the encoder stack.  rows = clips through the transformer.
 // K1-K3: conditioning token + pose embedding of the frames -> token stream rows (ws.hx / ws.hl)
-struct LoopRef { const LoopDev* ld = nullptr; int joff = 0; unsigned long long eo = 0; };   // loop mode of a step's kernels (see LoopDev)
+struct LoopRef { const LoopDev* ld = nullptr; int joff = 0; unsigned long long eo = 0; bool frames_ready = false; };   // frames_ready: the previous step's epilogue already wrote ws.xt   // loop mode of a step's kernels (see LoopDev)
 
 static int assemble_stream(mst_engine* e, const WS& ws, const float* x, int clips_x, int rows, int T, int temb_uniform_row, int temb_mod,
                            hipStream_t st, int tp_uncond, LoopRef lr = LoopRef()) {
@@ -717,8 +719,10 @@ static int assemble_stream(mst_engine* e, const WS& ws, const float* x, int clip
         // CFG batch feeds the same x to both halves: embed once, store twice (dup).
         ProfScope ps(e, FAM_EMBED_IN, st);
         const int F = e->cfg.feats, tot = clips_x * T;
-        hipLaunchKernelGGL(k_frames_f16, dim3((T + 31) / 32, e->kin_pad / 32, clips_x), dim3(256), 0, st, x, F, T, e->kin_pad, ws.xt, (const float*)nullptr, lr.ld, lr.eo);
-        HIPCHECK(hipGetLastError());
+        if (!lr.frames_ready) {
+            hipLaunchKernelGGL(k_frames_f16, dim3((T + 31) / 32, e->kin_pad / 32, clips_x), dim3(256), 0, st, x, F, T, e->kin_pad, ws.xt, (const float*)nullptr, lr.ld, lr.eo);
+            HIPCHECK(hipGetLastError());
+        }
         DEpiEmbedIn epi{e->b_pose_in, e->pe, ws.hx, ws.hl, T, S, tot, rows > clips_x ? (size_t)clips_x * S * MST_D : 0};
         CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1>(dim3((tot + 63) / 64, 1), RowsDirect{ws.xt, e->kin_pad}, e->w_pose_in, e->kin_pad,
                                                    e->kin_pad, epi, st)));
@@ -831,24 +835,26 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
 // output projection tiles: 64 frames x (256 * NTO) features, 8 waves as 1 x 8 with 2 x NTO MFMA tiles each
 template <int MODE, int NTO, int NX>
 static int launch_out(mst_engine* e, const WS& ws, int batch, int T, float* out, const StepArgs& sa, hipStream_t st,
-                      const f16* w_override = nullptr, const float* b_override = nullptr, int tok_off = 1) {
+                      const f16* w_override = nullptr, const float* b_override = nullptr, int tok_off = 1, bool frames_next = false) {
     const int S = T + tok_off;
     RowsFrames xs{ws.hx, MST_D, T, S, batch * T, 64, (size_t)batch * S, tok_off};
     DEpiEmbedOut<MODE> epi{b_override ? b_override : e->b_pose_out, e->cfg.feats, T, batch * T, out, sa};
+    if (frames_next) { epi.xt_next = ws.xt; epi.kpad = e->kin_pad; }
     return launch_gemm_dma<64, 256 * NTO, 2, NTO, 4, NX>(dim3((batch * T + 63) / 64, 1), xs, w_override ? w_override : e->w_pose_out, MST_D, MST_D, epi, st);
 }
 template <int MODE, int NTO>
 static int launch_out_nx(mst_engine* e, const WS& ws, int cfg, int batch, int T, float* out, const StepArgs& sa, hipStream_t st,
-                         const f16* wo = nullptr, const float* bo = nullptr, int tok_off = 1) {
-    return cfg ? launch_out<MODE, NTO, 2>(e, ws, batch, T, out, sa, st, wo, bo, tok_off) : launch_out<MODE, NTO, 1>(e, ws, batch, T, out, sa, st, wo, bo, tok_off);
+                         const f16* wo = nullptr, const float* bo = nullptr, int tok_off = 1, bool frames_next = false) {
+    return cfg ? launch_out<MODE, NTO, 2>(e, ws, batch, T, out, sa, st, wo, bo, tok_off, frames_next)
+               : launch_out<MODE, NTO, 1>(e, ws, batch, T, out, sa, st, wo, bo, tok_off, frames_next);
 }
 template <int MODE>
 static int launch_out_nt(mst_engine* e, const WS& ws, int cfg, int batch, int T, float* out, const StepArgs& sa, hipStream_t st,
-                         const f16* wo = nullptr, const float* bo = nullptr, int tok_off = 1) {
+                         const f16* wo = nullptr, const float* bo = nullptr, int tok_off = 1, bool frames_next = false) {
     ProfScope ps(e, FAM_EMBED_OUT, st);
     switch (e->nt_out) {
-        case 1: return launch_out_nx<MODE, 1>(e, ws, cfg, batch, T, out, sa, st, wo, bo, tok_off);
-        case 2: return launch_out_nx<MODE, 2>(e, ws, cfg, batch, T, out, sa, st, wo, bo, tok_off);
+        case 1: return launch_out_nx<MODE, 1>(e, ws, cfg, batch, T, out, sa, st, wo, bo, tok_off, frames_next);
+        case 2: return launch_out_nx<MODE, 2>(e, ws, cfg, batch, T, out, sa, st, wo, bo, tok_off, frames_next);
     }
     return fail("output projection: feats %d unsupported", e->cfg.feats);
 }
@@ -892,7 +898,9 @@ struct LoopPlan {
     const mst_schedule* s; const mst_loop_args* a; int nsl; size_t per_clip, clip_elems;
     hipStream_t streams[mst_engine::MAX_SLICES];
 };
-static int enqueue_step(mst_engine* e, const LoopPlan& p, int joff, int nsj) {
+// frames_ready / frames_next: the step's frame rows (ws.xt) were written by the previous step's epilogue / this step's epilogue
+// writes them for the next one (mst_sample_loop decides; see DEpiEmbedOut::xt_next)
+static int enqueue_step(mst_engine* e, const LoopPlan& p, int joff, int nsj, bool frames_ready = false, bool frames_next = false) {
     const mst_loop_args* a = p.a;
     for (int sl = 0; sl < nsj; sl++) {
         const int per = (a->batch + nsj - 1) / nsj;          // clips per slice (last one may be short)
@@ -905,7 +913,7 @@ static int enqueue_step(mst_engine* e, const LoopPlan& p, int joff, int nsj) {
         WS ws = ws_slice(e, a->cfg ? 2 * c0 : c0, a->frames);
         ws.textproj = e->textproj + (size_t)c0 * MST_D;
         hipStream_t ss = p.streams[sl];
-        LoopRef lr{e->ld_dev, joff, eo};
+        LoopRef lr{e->ld_dev, joff, eo, frames_ready};
         CHECK(run_trunk(e, ws, nullptr, nb, a->cfg ? 2 * nb : nb, a->frames, 0, 0, ss, a->batch, lr));
         StepArgs sa{};
         sa.tab = p.s->tab;
@@ -926,8 +934,8 @@ static int enqueue_step(mst_engine* e, const LoopPlan& p, int joff, int nsj) {
         sa.eo = eo;
         sa.step_stride = p.clip_elems;
         sa.rowflag = (a->inpainting_mask_dev && a->inpainted_motion_dev) ? e->rowflag + (size_t)c0 * e->cfg.feats : nullptr;
-        if (a->sampler == MST_SAMPLER_DDPM) CHECK(launch_out_nt<1>(e, ws, a->cfg, nb, a->frames, nullptr, sa, ss));
-        else CHECK(launch_out_nt<2>(e, ws, a->cfg, nb, a->frames, nullptr, sa, ss));
+        if (a->sampler == MST_SAMPLER_DDPM) CHECK(launch_out_nt<1>(e, ws, a->cfg, nb, a->frames, nullptr, sa, ss, nullptr, nullptr, 1, frames_next));
+        else CHECK(launch_out_nt<2>(e, ws, a->cfg, nb, a->frames, nullptr, sa, ss, nullptr, nullptr, 1, frames_next));
     }
     return 0;
 }
@@ -1036,6 +1044,11 @@ extern "C" int mst_sample_loop(mst_engine* e, const mst_schedule* s, const mst_l
             for (; j < nrun; j += U) HIPCHECK(hipGraphLaunch(e->gexec, st));
             return 0;
         }
+        // Host-enqueued steps chain their frame rows: step j's epilogue writes the f16 rows step j + 1 embeds, so only step 0 runs
+        // the transpose kernel.  Not under CFG (there a slice's rows sit at 2 x its first clip, which changes when an instrumented
+        // step runs as one slice), not for frame counts the epilogue walks element-wise, not in captured graphs (their first
+        // step would have to differ from call to call).
+        const bool chain = e->fuse_frames && !a->cfg && (a->frames & 3) == 0 && e->dbg_stage < 0;
         for (; j < nrun; j++) {
             e->prof_now = e->prof_on && (j % e->prof_period == 0);
             // instrumented steps run as ONE full-batch slice so the HIP-event durations are those of isolated
@@ -1043,7 +1056,7 @@ extern "C" int mst_sample_loop(mst_engine* e, const mst_schedule* s, const mst_l
             const int nsj = e->prof_now ? 1 : p.nsl;
             if (nsj > 1 && !forked) { CHECK(fork_slices(e, p)); forked = true; }
             else if (nsj == 1 && forked) { CHECK(join_slices(e, p)); forked = false; }
-            CHECK(enqueue_step(e, p, j, nsj));
+            CHECK(enqueue_step(e, p, j, nsj, chain && j > 0, chain && j + 1 < nrun));
         }
         return 0;
     };

@@ -503,6 +503,9 @@ struct DEpiEmbedIn {
 template <int MODE>
 struct DEpiEmbedOut {
     const float* bias; int F, T, total; float* out; StepArgs sa;
+    // xt_next != null (sampling loop, T % 4 == 0): the updated clip is ALSO written as the f16 frame rows [token][kpad] the NEXT
+    // step's pose-embedding GEMM stages -- bit for bit what k_frames_f16 would make of it -- so that step needs no transpose launch
+    f16* xt_next = nullptr; int kpad = 0;
     __device__ __forceinline__ int rows() const { return total; }
     template <int BT, int BF> static constexpr int smem_bytes() { return BF * (BT + 4) * 4; }
 
@@ -580,6 +583,7 @@ struct DEpiEmbedOut {
                 }
                 *reinterpret_cast<f32x4*>(sa.sample + idx) = nx;
                 if (sa.xstart) *reinterpret_cast<f32x4*>(sa.xstart + idx) = pred;
+                if (MODE != 0 && xt_next) *reinterpret_cast<f32x4*>(tile + f * LDT + tg * 4) = nx;      // this item's own slot of the tile
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
@@ -595,6 +599,23 @@ struct DEpiEmbedOut {
                     }
                     one(sa, sc, acc4[j] + b, idx, nz, blend, use_mask);
                 }
+            }
+        }
+        if (MODE != 0 && xt_next && vec) {
+            // second pass over the tile, now holding x_{t-1}: lanes walk the frames of one 8-feature group (conflict-free LDS
+            // reads), each writing 16 bytes of its frame's row; columns [F, kpad) are the zero padding of the GEMM's K
+            __syncthreads();
+            const int groups = kpad / 8;
+            for (int it = threadIdx.x; it < BT * groups; it += 512) {
+                const int tl = it % BT, fg = it / BT, tok = tok0 + tl;
+                if (tok >= total) continue;
+                f16x8 v;
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int f = f0 + 8 * fg + q;
+                    v[q] = f < F ? (f16)tile[f * LDT + tl] : (f16)0.f;
+                }
+                *reinterpret_cast<f16x8*>(xt_next + (size_t)tok * kpad + f0 + 8 * fg) = v;
             }
         }
     }

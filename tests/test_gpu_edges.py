@@ -116,6 +116,34 @@ def test_philox_in_kernel_equals_the_same_numbers_injected():
     assert abs(float((n[:-1] * n[1:]).mean())) < 2e-3                     # neighbouring elements uncorrelated
 
 
+def test_chained_frame_rows_equal_the_transpose_kernel(monkeypatch):
+    """Host-enqueued loops let step j's epilogue write the f16 frame rows step j + 1 embeds (k_frames_f16 then runs for step 0
+    only); MST_FUSE_FRAMES=0 runs the transpose kernel every step.  The rows are the same conversion of the same numbers:
+    bit-identical loops, for both samplers, with inpainting, in-kernel noise and the x0-hat dump, over 3 concurrent slices."""
+    from mst_amd.engine import Schedule, SAMPLER_DDPM, SAMPLER_DDIM
+    from oracle import schedule
+    F, T, B = 263, 196, 25
+    tab, tmap = schedule.make("cosine", 1000, "")
+    sch = Schedule(tab, tmap, dev())
+    txt = cu(syn.normal(SEED, "txtc", (B, 512)))
+    x0 = cu(syn.normal(SEED, "xc", (B, F, 1, T)))
+    mask = cu(syn.root_horizontal_mask(B, F, T))
+    motion = cu(syn.normal(SEED, "mc", (B, F, 1, T)))
+    monkeypatch.setenv("MST_FUSE_FRAMES", "1")
+    chained, _, _ = make(F, T, B)
+    monkeypatch.setenv("MST_FUSE_FRAMES", "0")
+    plain, _, _ = make(F, T, B)
+    outs = []
+    for eng in (chained, plain):
+        eng.set_text(txt)
+        a = eng.sample_loop(sch, x0.clone(), 6, 0, SAMPLER_DDPM, mask=mask, motion=motion, seed=5)
+        b, xs = eng.sample_loop(sch, x0.clone(), 999, 993, SAMPLER_DDIM, eta=0.5, seed=6, dump_xstart=True)
+        outs.append((a, b, xs))
+    for u, v in zip(outs[0], outs[1]):
+        assert torch.equal(u, v)
+    assert torch.equal(outs[0][0][:, :3], motion[:, :3])
+
+
 def test_argument_errors_surface_as_exceptions():
     from mst_amd.engine import DenoiserEngine, Schedule
     from oracle import schedule
