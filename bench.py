@@ -51,7 +51,7 @@ SYMBOL = {
     "ffn1_gelu_gemm": "k_gemm_dma<128,256,2,2,3,1,RowsDirect,DEpiBiasF16<true>,32>",
     "layer_tail_fused": "k_layer_tail",
     "embed_out_step": "k_gemm_dma<64,512,2,2,4,NX,RowsFrames,DEpiEmbedOut<1>,32>",
-    "embed_in": "k_gemm_dma<64,512,2,2,4,1,RowsDirect,DEpiEmbedIn,32> (+ k_frames_f16 on the first step of a loop; later steps get their f16 frame rows from the previous step's epilogue)",
+    "embed_in": "k_gemm_dma<64,512,2,2,4,1,RowsDirect,DEpiEmbedIn,32> (writes the conditioning tokens too; + k_frames_f16 on the first step of a loop, later steps get their f16 frame rows from the previous step's epilogue)",
     "cond_token": "k_cond_token",
     "qkv_gemm": "k_gemm_dma<...,DEpiBiasF16<false>>",
     "attention": "k_attention<7>",

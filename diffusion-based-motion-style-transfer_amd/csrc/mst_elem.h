@@ -75,27 +75,10 @@ __global__ __launch_bounds__(256) void k_rowwise_linear(const float* __restrict_
 }
 
 // token 0 of every clip: h[clip*S][:] = temb[row] + textproj[clip] + pe[0]  (mdm :609-621)
-// uniform_row >= 0: every clip uses that temb row (sampling loop: one t per step);
-// uniform_row < 0: clip uses temb row (clip % temb_mod) (per-clip t; the CFG halves share rows).
-// tp_half > 0 (CFG slice): rows [0, tp_half) are the slice's cond clips, rows [tp_half, 2 tp_half) their uncond
-// twins, whose text projections sit tp_uncond rows further on in `textproj`.
-__global__ void k_cond_token(const float* __restrict__ temb, int uniform_row, int temb_mod,
-                             const float* __restrict__ textproj, int tp_half, int tp_uncond,
-                             const float* __restrict__ pe, int S, int rows,
-                             f16* __restrict__ hi, f16* __restrict__ lo, const LoopDev* __restrict__ ld, int joff) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * MST_D) return;
-    if (ld) uniform_row = ld->nrun - 1 - (ld->jbase + joff);      // sampling loop: the timestep row of step jbase + joff
-    int clip = i / MST_D, f = i - clip * MST_D;
-    int tr = uniform_row >= 0 ? uniform_row : clip % temb_mod;
-    int tp = (tp_half > 0 && clip >= tp_half) ? clip - tp_half + tp_uncond : clip;
-    float v = temb[(size_t)tr * MST_D + f] + textproj[(size_t)tp * MST_D + f];
-    v += pe[f];
-    size_t o = (size_t)clip * S * MST_D + f;
-    const f16 h = (f16)v;
-    hi[o] = h;
-    lo[o] = (f16)(v - (float)h);
-}
+// (The conditioning token -- temb row + text projection + positional row 0 -> token 0 of every clip -- is written by the
+// pose-embedding GEMM's epilogue: CondTok / DEpiEmbedIn in mst_gemm_dma.h.  uniform_row >= 0: every clip uses that temb row
+// (sampling loop: one t per step); < 0: clip uses temb row (clip % temb_mod).  tp_half > 0 (CFG slice): rows [0, tp_half) are the
+// slice's cond clips, rows [tp_half, 2 tp_half) their uncond twins, whose text projections sit tp_uncond rows further on.)
 
 // Small launches: y = LayerNorm(acc + bias + residual) for rows of 512, one wave per row; the stream (hi/lo pair) is
 // read as the residual and rewritten in place.  `acc` is the fp32 GEMM result of a launch tiled over N (k_gemm_dma with

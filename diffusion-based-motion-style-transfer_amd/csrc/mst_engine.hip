@@ -708,12 +708,8 @@ struct LoopRef { const LoopDev* ld = nullptr; int joff = 0; unsigned long long e
 static int assemble_stream(mst_engine* e, const WS& ws, const float* x, int clips_x, int rows, int T, int temb_uniform_row, int temb_mod,
                            hipStream_t st, int tp_uncond, LoopRef lr = LoopRef()) {
     const int S = T + 1;
-    {
-        ProfScope ps(e, FAM_COND, st);
-        hipLaunchKernelGGL(k_cond_token, dim3((rows * MST_D + 255) / 256), dim3(256), 0, st, e->temb, temb_uniform_row,
-                           temb_mod, ws.textproj, rows > clips_x ? clips_x : 0, rows > clips_x ? tp_uncond : 0, e->pe, S, rows, ws.hx, ws.hl, lr.ld, lr.joff);
-        HIPCHECK(hipGetLastError());
-    }
+    // (the conditioning token of every clip -- timestep embedding + text projection + positional row 0, formerly a launch of its
+    // own, k_cond_token -- is written by the pose-embedding GEMM's epilogue: CondTok in mst_gemm_dma.h)
     {
         // frames -> f16 rows (transpose + convert), then the pose-embedding GEMM on the DMA ring.  The doubled
         // CFG batch feeds the same x to both halves: embed once, store twice (dup).
@@ -724,6 +720,9 @@ static int assemble_stream(mst_engine* e, const WS& ws, const float* x, int clip
             HIPCHECK(hipGetLastError());
         }
         DEpiEmbedIn epi{e->b_pose_in, e->pe, ws.hx, ws.hl, T, S, tot, rows > clips_x ? (size_t)clips_x * S * MST_D : 0};
+        epi.ct.temb = e->temb; epi.ct.textproj = ws.textproj; epi.ct.ld = lr.ld;
+        epi.ct.uniform_row = temb_uniform_row; epi.ct.temb_mod = temb_mod; epi.ct.joff = lr.joff; epi.ct.rows = rows;
+        epi.ct.tp_half = rows > clips_x ? clips_x : 0; epi.ct.tp_uncond = rows > clips_x ? tp_uncond : 0;
         CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1>(dim3((tot + 63) / 64, 1), RowsDirect{ws.xt, e->kin_pad}, e->w_pose_in, e->kin_pad,
                                                    e->kin_pad, epi, st)));
     }

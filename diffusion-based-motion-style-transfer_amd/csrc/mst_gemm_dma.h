@@ -436,9 +436,16 @@ struct DEpiResidLN {
 // K3: frames x pose-embedding + bias + positional row -> token stream rows clip*S + 1 + t (fp32 + f16).
 // Same 64 x 512 tile and LDS transpose as the LayerNorm epilogue; `dup` > 0 also writes the rows of
 // the CFG uncond half (identical frames, only the conditioning token differs).
+// Conditioning token (token 0 of every clip) = timestep embedding + text projection + positional row 0, written by the tile that
+// holds the clip's first frame -- the per-step k_cond_token launch folded into this epilogue.  Fields as k_cond_token's arguments.
+struct CondTok {
+    const float* temb = nullptr; const float* textproj = nullptr; const LoopDev* ld = nullptr;
+    int uniform_row = 0, temb_mod = 1, tp_half = 0, tp_uncond = 0, joff = 0, rows = 0;
+};
 struct DEpiEmbedIn {
     const float* bias; const float* pe; f16* hi; f16* lo; int T, S, total; size_t dup;
     int tok_off = 1;                          // frame t becomes token tok_off + t (positional row included)
+    CondTok ct;                               // ct.temb != null: also write the conditioning tokens (tok_off == 1 callers)
     __device__ __forceinline__ int rows() const { return total; }
     template <int BT, int BF> static constexpr int smem_bytes() { return BT * (MST_D * 4 + 16); }
     template <int BT, int BF, int MT, int NT>
@@ -489,6 +496,24 @@ struct DEpiEmbedIn {
                 if (dup == 0) break;
                 off += dup;
             }
+        }
+        if (ct.temb) {
+            // clips whose frame 0 is a row of this tile; thread = feature (512 threads = MST_D)
+            static_assert(MST_D == 512, "one thread per feature");
+            const int f = threadIdx.x, x_clips = total / T;
+            int uniform_row = ct.uniform_row;
+            if (ct.ld) uniform_row = ct.ld->nrun - 1 - (ct.ld->jbase + ct.joff);      // sampling loop: the timestep row of step jbase + joff
+            const int lim = tok0 + BT < total ? tok0 + BT : total;
+            for (int c = (tok0 + T - 1) / T; c * T < lim; c++)
+                for (int clip = c; clip < ct.rows; clip += x_clips) {                // the clip and, under CFG, its uncond twin
+                    const int tr = uniform_row >= 0 ? uniform_row : clip % ct.temb_mod;
+                    const int tp = (ct.tp_half > 0 && clip >= ct.tp_half) ? clip - ct.tp_half + ct.tp_uncond : clip;
+                    const float v = ct.temb[(size_t)tr * MST_D + f] + ct.textproj[(size_t)tp * MST_D + f] + pe[f];
+                    const size_t o = (size_t)clip * S * MST_D + f;
+                    const f16 h = (f16)v;
+                    hi[o] = h;
+                    lo[o] = (f16)(v - (float)h);
+                }
         }
     }
 };
