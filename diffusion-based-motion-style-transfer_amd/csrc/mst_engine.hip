@@ -192,7 +192,7 @@ struct mst_engine {
                                           // re-streaming).  Off by default: wins 16-21 % in gemm_bench, nothing in the pipeline (CFG 39.7 vs
                                           // 39.9, batch 128 77.2 vs 77.1 clips/s; forced at batch 64: 58.7 vs 68.3) -- kept, parity-tested
     int wgrad_stream_on = 1;              // training: wgrads on a second stream beside the dgrad chain (MST_WGRAD_STREAM=0: one stream)
-    int nsplit = 3;                       // sampling loops run the batch as this many independent slices on separate streams (same-box A/B: 2: 61.2, 3: 63.0, 4: 61.1 clips/s)
+    int nsplit = 0;                       // clip slices of a sampling loop on separate streams: 0 = chosen per call (loop_slices_for), 1..3 = MST_STREAMS
     static constexpr int MAX_SLICES = 4;
     hipStream_t aux_stream[MAX_SLICES - 1] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[MAX_SLICES - 1] = {nullptr, nullptr, nullptr};
@@ -885,11 +885,25 @@ extern "C" int mst_forward(mst_engine* e, const float* x, const int64_t* t, cons
     return launch_out_nt<0>(e, ws, cfg, batch, frames, out, sa, st);
 }
 
-extern "C" int mst_loop_slices(const mst_engine* e, int32_t batch, int32_t cfg) {
-    if (!e || e->nsplit < 2 || e->dbg_stage >= 0) return 1;
+// How many independent clip slices a loop over `batch` clips of `frames` frames runs as.  Measured, same box, interleaved
+// (tools/streams_ab.sh, tools/streams_ab_configs.sh), final round-2 kernels at 196 frames: a batch whose tiles are all resident at
+// once on the large-tile path wants ONE slice (batch 64: 82.0 / 81.6 / 80.6 clips/s at 1 / 2 / 3 slices; batch 32: 43.8 vs 39.7
+// at 3 -- slices would drop to the small-tile kernels); more tiles than CUs (batch 128: 78.5 vs 84.3; CFG at 64 clips: 39.8 vs
+// 42.9) and the small-tile path (batch 16: 22.1 vs 28.8) want up to three.
+static int loop_slices_for(const mst_engine* e, int batch, int cfg, int frames) {
+    if (!e || e->dbg_stage >= 0) return 1;
+    const int rows = (cfg ? 2 : 1) * batch;
     int n = e->nsplit;
-    while (n > 1 && (cfg ? 2 : 1) * batch / n < 8) n--;      // at least 8 rows through the transformer per slice
+    if (n == 0) {
+        const long long M = (long long)rows * (frames + 1);
+        const bool small = e->small_m > 0 && M <= e->small_m;
+        n = (!small && (M + 63) / 64 <= 256) ? 1 : 3;
+    }
+    while (n > 1 && rows / n < 8) n--;                       // at least 8 rows through the transformer per slice
     return n;
+}
+extern "C" int mst_loop_slices(const mst_engine* e, int32_t batch, int32_t cfg) {
+    return loop_slices_for(e, batch, cfg, e ? e->cfg.max_frames : 0);
 }
 
 // One denoise step of every slice, enqueued (or captured): slice sl on streams[sl]; step = *ld.jbase + joff.
@@ -978,7 +992,7 @@ extern "C" int mst_sample_loop(mst_engine* e, const mst_schedule* s, const mst_l
     // Clips are independent, so the batch runs as `nsplit` slices on separate streams: one slice's kernels fill
     // the CUs the other leaves idle in its prologues, tails and launch gaps (per-launch time is per-CU bound and
     // flat in the block count at this size).  CFG batches are sliced the same way (cond + uncond twins stay together).
-    LoopPlan p{s, a, mst_loop_slices(e, a->batch, a->cfg), (size_t)e->cfg.feats * a->frames, (size_t)a->batch * e->cfg.feats * a->frames,
+    LoopPlan p{s, a, loop_slices_for(e, a->batch, a->cfg, a->frames), (size_t)e->cfg.feats * a->frames, (size_t)a->batch * e->cfg.feats * a->frames,
                {st, e->aux_stream[0], e->aux_stream[1], e->aux_stream[2]}};
     // per-call arguments -> device (pinned staging slot; the slot's previous upload has long completed when it comes round again)
     {

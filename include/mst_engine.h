@@ -151,10 +151,12 @@ typedef struct mst_loop_args {
 
 int mst_sample_loop(mst_engine* e, const mst_schedule* s, const mst_loop_args* a, void* stream);
 
-/* Number of independent clip slices (1..4) mst_sample_loop runs on separate streams for this
- * batch: clips never interact (no cross-sample op in mdm_forstyledataset.py:602-625), so two
- * half-batches overlap each other's launch gaps, prologues and tails.  MST_STREAMS=1 in the
- * environment at engine creation forces one slice.  Per-launch work = batch / slices clips. */
+/* Number of independent clip slices (1..3) mst_sample_loop runs on separate streams for this
+ * batch at the engine's max_frames: clips never interact (no cross-sample op in
+ * mdm_forstyledataset.py:602-625), so slices overlap each other's launch gaps, prologues and
+ * tails.  Chosen per call from the tile count (one slice when every tile of the batch is
+ * resident at once, up to three beyond that and on the small-tile path); MST_STREAMS=1..3 in
+ * the environment at engine creation fixes it.  Per-launch work = batch / slices clips. */
 int mst_loop_slices(const mst_engine* e, int32_t batch, int32_t cfg);
 
 /* -------------------------------------------------------------------------------------------

@@ -75,7 +75,8 @@ def test_odd_batch_across_the_two_slices_equals_single_slice():
     from oracle import schedule
     F, T, B = 181, 76, 17
     eng, w, pe = make(F, T, B)
-    assert eng.loop_slices(B) == 2 and eng.loop_slices(8) == 1 and eng.loop_slices(64) == 3 and eng.loop_slices(64, cfg=True) == 3
+    # 17 clips x 77 tokens take the small-tile path: sliced (8-clip minimum); 64 clips (77 tiles, large-tile path) fit the chip at once: one slice
+    assert eng.loop_slices(B) == 2 and eng.loop_slices(8) == 1 and eng.loop_slices(64) == 1 and eng.loop_slices(64, cfg=True) == 1
     shape = (B, F, 1, T)
     tab, tmap = schedule.make("cosine", 1000, "")
     sch = Schedule(tab, tmap, dev())
@@ -98,11 +99,13 @@ def test_odd_batch_across_the_two_slices_equals_single_slice():
     assert torch.isfinite(whole).all() and torch.equal(whole[:, :3], motion[:, :3])
 
 
-def test_philox_in_kernel_equals_the_same_numbers_injected():
+def test_philox_in_kernel_equals_the_same_numbers_injected(monkeypatch):
     from mst_amd.engine import Schedule, SAMPLER_DDPM
     from oracle import schedule
     F, T, B = 263, 196, 18          # 2 slices of 9: also checks the slice offset in the Philox counter
+    monkeypatch.setenv("MST_STREAMS", "3")          # (56 large tiles would run as one slice by default)
     eng, w, pe = make(F, T, B)
+    assert eng.loop_slices(B) == 2
     tab, tmap = schedule.make("cosine", 1000, "")
     sch = Schedule(tab, tmap, dev())
     eng.set_text(cu(syn.normal(SEED, "txtp", (B, 512))))
@@ -129,8 +132,10 @@ def test_chained_frame_rows_equal_the_transpose_kernel(monkeypatch):
     x0 = cu(syn.normal(SEED, "xc", (B, F, 1, T)))
     mask = cu(syn.root_horizontal_mask(B, F, T))
     motion = cu(syn.normal(SEED, "mc", (B, F, 1, T)))
+    monkeypatch.setenv("MST_STREAMS", "3")
     monkeypatch.setenv("MST_FUSE_FRAMES", "1")
     chained, _, _ = make(F, T, B)
+    assert chained.loop_slices(B) == 3
     monkeypatch.setenv("MST_FUSE_FRAMES", "0")
     plain, _, _ = make(F, T, B)
     outs = []
