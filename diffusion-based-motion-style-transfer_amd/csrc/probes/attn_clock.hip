@@ -44,6 +44,16 @@ int main(int argc, char** argv) {
             tot.push_back(rt * 0.01);
             for (int p = 0; p < 4; p++) ph[p].push_back((double)(st[g][2 * p + 3] - st[g][2 * p + 1]) * 0.01);
         }
+        // dispatch skew and drain: first start -> each workgroup's start / end on the 100 MHz counter (one launch = the last one)
+        {
+            unsigned long long t0 = ~0ull, t1 = 0; std::vector<double> st0, en;
+            const int G = (int)ghz.size();
+            for (int g = 0; g < G; g++) { t0 = std::min(t0, st[g][1]); t1 = std::max(t1, st[g][9]); }
+            for (int g = 0; g < G; g++) { st0.push_back((double)(st[g][1] - t0) * 0.01); en.push_back((double)(st[g][9] - t0) * 0.01); }
+            std::sort(st0.begin(), st0.end()); std::sort(en.begin(), en.end());
+            printf("        starts after the first workgroup's: median %.2f, last %.2f us; ends: first %.2f, median %.2f, last %.2f us\n",
+                   st0[G / 2], st0[G - 1], en[0], en[G / 2], en[G - 1]);
+        }
         auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
         printf("rep %d: %.2f us/launch over %d launches | in-kernel (median over %zu workgroups of the last launch): clock %.3f GHz, "
                "workgroup %.2f us = projection %.2f + images %.2f + scores/softmax %.2f + PV/store %.2f us\n",

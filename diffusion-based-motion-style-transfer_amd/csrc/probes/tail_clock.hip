@@ -49,6 +49,16 @@ int main(int argc, char** argv) {
             for (int j = 0; j < 3; j++) lap[j].push_back((double)st[g][10 + j] / (cyc / rt * 100.0));   // cycles -> us at this workgroup's clock
             for (int p = 0; p < 4; p++) ph[p].push_back((double)(st[g][2 * p + 3] - st[g][2 * p + 1]) * 0.01);
         }
+        // dispatch skew and drain: first start -> each workgroup's start / end on the 100 MHz counter (one launch = the last one)
+        {
+            unsigned long long t0 = ~0ull, t1 = 0; std::vector<double> st0, en;
+            const int G = (int)ghz.size();
+            for (int g = 0; g < G; g++) { t0 = std::min(t0, st[g][1]); t1 = std::max(t1, st[g][9]); }
+            for (int g = 0; g < G; g++) { st0.push_back((double)(st[g][1] - t0) * 0.01); en.push_back((double)(st[g][9] - t0) * 0.01); }
+            std::sort(st0.begin(), st0.end()); std::sort(en.begin(), en.end());
+            printf("        starts after the first workgroup's: median %.2f, last %.2f us; ends: first %.2f, median %.2f, last %.2f us\n",
+                   st0[G / 2], st0[G - 1], en[0], en[G / 2], en[G - 1]);
+        }
         auto med = [](std::vector<double>& x) { std::sort(x.begin(), x.end()); return x[x.size() / 2]; };
         printf("rep %d: %.2f us/launch over %d launches | in-kernel (median over %zu workgroups of the last launch): clock %.3f GHz, "
                "workgroup %.2f us = out-proj loop %.2f + LN1/x1h %.2f + FFN loop %.2f (FFN1 steps %.2f, GELU + H image %.2f, FFN2 steps %.2f; wave 0's view: the first FFN2 barrier of a chunk also waits for the slowest wave's GELU) + LN2/store %.2f us\n",
