@@ -457,14 +457,14 @@ def test_batch128_prior_as_denoiser_hml(golden, tile_path):
         # (two f16-operand evaluations of one function, each within TOL of the fp32 path)
         assert rel_l2(part.cpu().numpy(), out[lo:lo + 2].cpu().numpy()) < (1e-6 if tile_path != "default" else 1.5 * TOL)
     # a short sampling loop at 128 clips: deterministic, masked rows bit-exact, the same numbers whether Philox runs in the
-    # kernel or is injected, slices (3 x 43 clips) consistent with clip-wise runs
+    # kernel or is injected, slices (2 x 64 clips) consistent with clip-wise runs
     tab, tmap = schedule.make("cosine", 1000, "")
     sch = Schedule(tab, tmap, _dev())
     mask = cu(syn.root_horizontal_mask(B, F, T))
     motion = cu(syn.normal(SEED, "hml/bigmotion", (B, F, 1, T)))
     x0 = cu(x)
     eng.set_text(cu(txt))
-    assert eng.loop_slices(B) == 3
+    assert eng.loop_slices(B) == 2                          # 394 tiles: one slice per round of tiles over the 256 CUs
     a = eng.sample_loop(sch, x0.clone(), 3, 0, SAMPLER_DDPM, mask=mask, motion=motion, seed=11)
     b = eng.sample_loop(sch, x0.clone(), 3, 0, SAMPLER_DDPM, mask=mask, motion=motion, seed=11)
     assert torch.equal(a, b) and torch.isfinite(a).all()
@@ -504,7 +504,7 @@ def test_cfg_at_headline_size_hml(golden, tile_path):
     nz = cu(np.stack([syn.normal(SEED, f"hml/cfgnz/{k}", (B, F, 1, T)) for k in range(3)]))
     x0 = cu(x)
     eng.set_text(cu(txt), cfg=True)
-    assert eng.loop_slices(B, cfg=True) == 3
+    assert eng.loop_slices(B, cfg=True) == 2
     a = eng.sample_loop(sch, x0.clone(), 2, 0, SAMPLER_DDPM, cfg=True, scale=cu(scale), mask=mask, motion=motion, noise=nz)
     b = eng.sample_loop(sch, x0.clone(), 2, 0, SAMPLER_DDPM, cfg=True, scale=cu(scale), mask=mask, motion=motion, noise=nz)
     assert torch.equal(a, b) and torch.isfinite(a).all()
