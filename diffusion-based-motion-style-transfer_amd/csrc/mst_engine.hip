@@ -899,6 +899,14 @@ static int loop_slices_for(const mst_engine* e, int batch, int cfg, int frames) 
         const bool small = e->small_m > 0 && M <= e->small_m;
         const long long waves = ((M + 63) / 64 + 255) / 256;        // rounds of 64-token tiles over the 256 CUs
         n = small ? 3 : (int)(waves < 3 ? waves : 3);
+        // a batch just above the small-tile limit: slices that each fit it run the small-tile kernels side by side, whose step
+        // is shorter than the large-tile step while the batch is small (tools/streams_ab_small.sh, 196 frames: the large-tile
+        // step is ~0.73 ms whatever the batch, k small-tile slices take ~0.29 + 0.017 ms x clips: batch 16 28.3 vs 22.1 clips/s,
+        // 24: 34.0 vs 32.9, 30: 37.2 vs 41.0 -- the crossover is ~26 clips = 2.5 x the small-tile limit in token rows)
+        for (int k = 2; !small && n == 1 && e->small_m > 0 && 2 * M <= 5LL * e->small_m && k <= 3; k++) {
+            const int per = (rows + k - 1) / k;
+            if (rows / k >= 8 && (long long)per * (frames + 1) <= e->small_m) n = k;
+        }
     }
     while (n > 1 && rows / n < 8) n--;                       // at least 8 rows through the transformer per slice
     return n;
