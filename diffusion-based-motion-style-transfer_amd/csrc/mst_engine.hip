@@ -185,8 +185,8 @@ struct mst_engine {
     int fuse_qkv_attn = 1;                // K4 + K5 as one kernel per (clip, head); MST_FUSE_QKV_ATTN=0 keeps them apart
     int fuse_tail = 1;                    // K6 + K7 + K8 as one kernel per 64-token tile (mst_tail.h); MST_FUSE_TAIL=0 keeps them apart
     int fuse_frames = 1;                  // sampling loop: a step's epilogue writes the next step's f16 frame rows; MST_FUSE_FRAMES=0 runs k_frames_f16 every step
-    int small_m = 2048;                   // launches of at most this many token rows take the small-tile path (MST_SMALL_M, 0 = never);
-                                          // tools/small_m_sweep.sh: 8 clips (1576 rows) 722 -> 417 us/step, 11-clip slices (2167 rows) 766 vs 796
+    int small_m = 4096;                   // launches of at most this many token rows take the small-tile path (MST_SMALL_M, 0 = never);
+                                          // tools/small_m_ab2.sh, one launch, us per step small / large tiles: 11 clips 512 / 723, 16: 596 / 724, 20: 694 / 727, 24: 813 / 732
     float* zacc = nullptr;                // fp32 GEMM result feeding k_ln_rows on that path
     int ln128_min_m = 1 << 30;            // MST_LN128_M=n: launches of >= n token rows use 128-token LayerNorm tiles (half the weight
                                           // re-streaming).  Off by default: wins 16-21 % in gemm_bench, nothing in the pipeline (CFG 39.7 vs
@@ -902,8 +902,8 @@ static int loop_slices_for(const mst_engine* e, int batch, int cfg, int frames) 
         // a batch just above the small-tile limit: slices that each fit it run the small-tile kernels side by side, whose step
         // is shorter than the large-tile step while the batch is small (tools/streams_ab_small.sh, 196 frames: the large-tile
         // step is ~0.73 ms whatever the batch, k small-tile slices take ~0.29 + 0.017 ms x clips: batch 16 28.3 vs 22.1 clips/s,
-        // 24: 34.0 vs 32.9, 30: 37.2 vs 41.0 -- the crossover is ~26 clips = 2.5 x the small-tile limit in token rows)
-        for (int k = 2; !small && n == 1 && e->small_m > 0 && 2 * M <= 5LL * e->small_m && k <= 3; k++) {
+        // 24: 34.0 vs 32.9, 30: 37.2 vs 41.0 -- the crossover is ~26 clips = 5120 token rows)
+        for (int k = 2; !small && n == 1 && e->small_m > 0 && M <= 5120 && k <= 3; k++) {
             const int per = (rows + k - 1) / k;
             if (rows / k >= 8 && (long long)per * (frames + 1) <= e->small_m) n = k;
         }
