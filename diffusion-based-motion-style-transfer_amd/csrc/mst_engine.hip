@@ -175,7 +175,6 @@ struct mst_engine {
     // workspace
     f16* hl = nullptr;        // lo half of the stream (hx is the hi half)
     f16 *hx = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr, *xt = nullptr;
-    f16* x1h = nullptr;                   // fused layer tail: LayerNorm1 output as the f16 operand FFN1 re-reads through its ring
     float *temb_hid = nullptr, *temb = nullptr, *textproj = nullptr;
     int temb_cap = 0;
     std::vector<std::string> loaded;
@@ -315,7 +314,6 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     CHECK(dmalloc(&e->qkv, (size_t)e->M_pad * 3 * MST_D));
     CHECK(dmalloc(&e->att, (size_t)e->M_pad * MST_D));
     CHECK(dmalloc(&e->hid, (size_t)e->M_pad * MST_FF));
-    CHECK(dmalloc(&e->x1h, (size_t)e->M_pad * MST_D));
     CHECK(dmalloc(&e->xt, ((size_t)c->max_rows * c->max_frames + 128) * e->kin_pad));
     e->temb_cap = c->max_rows > 1024 ? c->max_rows : 1024;
     CHECK(dmalloc(&e->temb_hid, (size_t)e->temb_cap * MST_D));
@@ -370,8 +368,7 @@ extern "C" void mst_engine_destroy(mst_engine* e) {
         for (void* q : p) (void)hipFree(q);
     }
     void* p[] = {e->w_pose_in, e->b_pose_in, e->w_pose_out, e->b_pose_out, e->w_pose_inT, e->w_pose_outT, e->w_t0, e->b_t0, e->w_t2, e->b_t2,
-                 e->w_text, e->b_text, e->pe, e->hl, e->hx, e->qkv, e->att, e->hid, e->xt, e->temb_hid, e->temb, e->textproj, e->zacc,
-                 e->x1h};
+                 e->w_text, e->b_text, e->pe, e->hl, e->hx, e->qkv, e->att, e->hid, e->xt, e->temb_hid, e->temb, e->textproj, e->zacc};
     for (void* q : p) (void)hipFree(q);
     for (int i = 0; i < mst_engine::MAX_SLICES - 1; i++) {
         if (e->aux_stream[i]) (void)hipStreamDestroy(e->aux_stream[i]);
@@ -681,22 +678,20 @@ extern "C" int mst_set_text(mst_engine* e, const float* text_emb, const float* k
 // A slice of the workspace: clips [r0, r0 + n) of the batch get their own rows of every buffer, so slices can
 // run concurrently on different streams (tiles may over-READ into a neighbour's rows; they never write them).
 struct WS {
-    f16 *hl, *hx, *qkv, *att, *hid, *xt; float* textproj; float* zacc; f16* x1h;
+    f16 *hl, *hx, *qkv, *att, *hid, *xt; float* textproj; float* zacc;
 };
 static WS ws_slice(const mst_engine* e, int r0, int T) {
     const size_t row = (size_t)r0 * (T + 1);
     return WS{e->hl + row * MST_D, e->hx + row * MST_D, e->qkv + row * 3 * MST_D, e->att + row * MST_D, e->hid + row * MST_FF,
-              e->xt + (size_t)r0 * T * e->kin_pad, e->textproj + (size_t)r0 * MST_D, e->zacc + row * MST_D,
-              e->x1h + row * MST_D};
+              e->xt + (size_t)r0 * T * e->kin_pad, e->textproj + (size_t)r0 * MST_D, e->zacc + row * MST_D};
 }
 
 // K6 + K7 + K8 of one layer as one launch (mst_tail.h): one workgroup per 64-token tile
 static int launch_tail(const LayerW& w, const WS& ws, int M, hipStream_t st) {
     static_assert(TailCfg::SMEM <= 163840, "fused layer tail exceeds the 160 KiB LDS");
-    static_assert(64 * (MST_D * 4 + 16) <= TailCfg::OFF_B, "LayerNorm scratch must not reach the staged FFN1 bias");
     CHECK(ensure_dyn_lds((const void*)k_layer_tail, TailCfg::SMEM));
     hipLaunchKernelGGL(k_layer_tail, dim3((M + TailCfg::BT - 1) / TailCfg::BT), dim3(512), TailCfg::SMEM, st, ws.att, w.wtail,
-                       w.b_out, w.g1, w.be1, w.b1, w.b2, w.g2, w.be2, ws.hx, ws.hl, ws.x1h, M);
+                       w.b_out, w.g1, w.be1, w.b1, w.b2, w.g2, w.be2, ws.hx, ws.hl, M);
     HIPCHECK(hipGetLastError());
     return 0;
 }

@@ -4,429 +4,409 @@
 //     h  = GELU(x1 W1^T + b1)                           nn.TransformerEncoderLayer post-norm forward)
 //     x2 = LayerNorm2(x1 + h W2^T + b2)
 //
-// Why one kernel.  As three launches (out-proj+LN, FFN1+GELU, FFN2+LN) a 64-clip step moves per layer ~180 MB through HBM
-// that only exists to hand a tile from one launch to the next (`hid` written and read back: 51.6 MB; x1 written as the
-// stream and read back twice), and every launch pays its own ring prologue and an epilogue in which all workgroups hit
-// HBM at once while the matrix cores idle.  Here a tile's x1 and hidden activations never leave the CU except as the
-// f16 operand copy the DMA ring re-reads (L2-hot) and the LayerNorm2 residual.
+// Round 3 design: the weights never touch the LDS.  A 64-token tile needs all 2.5 MB of W_out | W1 | W2, and in this tiling a
+// weight fragment is used by exactly ONE wave (wave w owns weight rows [32 w, 32 w + 32) of every 256-row block, for all 64
+// tokens).  Round 2 pushed them through an LDS-DMA ring anyway: 75-90 GB/s per CU, 40 us of streaming per tile against 19 us of
+// matrix work.  Measured on MI355X (csrc/probes/wstream.hip, 197 workgroups streaming the same layer): plain
+// global_load_dwordx4 into VGPRs reads the same bytes at ~160 GB/s per CU with nothing else running and sustains 83 % of the
+// MFMA issue rate with the token fragments coming from LDS.  So:
 //
-// What bounds it.  A 64-token tile needs all 2.5 MB of the three weight matrices; at B = 64 there are 197 tiles for
-// 256 CUs, so every CU streams the full 2.5 MB through its L2->LDS path (~65 GB/s per CU, MI355X_MICROARCH "Indexed
-// rows: gather into LDS"): ~40 us, against ~20 us of MFMA work.  The kernel is therefore organised around the weight
-// stream: ONE linear stream of 80 slabs of [256 weight rows x 64 k] f16 (32 KB each), pre-packed per layer in
-// consumption order and in LDS image order (k_pack_tail), fed through a 3-slot ring with two slabs in flight; the
-// activation operand of a step is an 8 KB [64 tokens x 64 k] slab (att / x1 through a second small ring, the GELU output
-// straight from its LDS image).  Waves: wave w owns weight rows [32 w, 32 w + 32) of every slab and both 32-token tiles.
+//   * W_out | W1 | W2 are pre-packed per layer (k_pack_tail) as EIGHT per-wave streams of 320 fragments of 1 KB, each the A
+//     operand of v_mfma_f32_16x16x32_f16 for 16 weight rows x 32 k in lane order: one wave-instruction = one coalesced 1-KB load.
+//     A wave keeps TailCfg::D fragments in flight (4 VGPRs each) behind hand-counted s_waitcnt vmcnt(D - 1); the stream runs
+//     through the LayerNorm and GELU stages without draining, so no phase starts on a cold pipeline.
+//   * The shared operand -- the tile's 64 token rows -- lives in LDS for the whole phase: att (64 KB, one LDS-DMA burst at kernel
+//     start), x1 (64 KB f16 image written by LayerNorm1; no global round trip any more), the GELU output (32 KB per 256-feature
+//     chunk, double-buffered: ONE barrier per chunk instead of one per 32-KB weight slab).
+//   * 16x16x32 tiles instead of 32x32x16: same registers, same LDS bytes, +16 % in the probe at the clock the chip holds.
+//   * LayerNorm1's fp32 output re-enters the accumulators (through the LayerNorm scratch) as FFN2's initial value, so the residual
+//     of LayerNorm2 costs no registers during the FFN.
 //
-//   phase P   16 steps: slab (ks, nh) = W_out rows [256 nh, +256), k [64 ks, +64)          acc[nh][m] += W . att^T
-//   LN1       accumulators -> LDS transpose -> + b_out + x (requested before phase P) -> LayerNorm -> x1: fp32 rows stay in
-//             registers (LayerNorm2's residual), the f16 operand copy goes to a global scratch for the activation ring
-//   phase F   4 chunks of 256 hidden features, 16 steps each:
-//               8 steps  slab = W1 rows of the chunk, k [64 ks, +64)                        acch[m] += W1 . x1^T
-//               GELU(acch + b1) -> H image (LDS, 4 activation slabs)
-//               8 steps  slab (ks2, nh) = W2 rows [256 nh, +256), k = chunk's [64 ks2, +64)  acc[nh][m] += W2 . H^T
-//   LN2       + b2 + x1 (registers) -> LayerNorm -> the stream (hi/lo), in place for the next layer
+//   phase P   16 k-steps of 32: acc[nh][rb][tb] += W_out[256 nh + 32 w + 16 rb .., k] . att[16 tb .., k]^T            (4 fragments / step)
+//   LN1       two 32-token halves: accumulators -> scratch -> rows (+ b_out + stream) -> LayerNorm -> x1: f16 image + fp32 back
+//   phase F   4 chunks of 256 hidden features: FFN1 16 k-steps (2 fragments / step) -> GELU -> H image -> barrier -> FFN2 8 k-steps (4)
+//   LN2       accumulators (x1 + FFN2) -> scratch -> rows (+ b2) -> LayerNorm -> the stream (hi/lo), in place for the next layer
 #pragma once
 #include "mst_common.h"
 #include "mst_gemm_dma.h"
 
+#ifndef TAIL_MARK            // probes/tail_clock.hip defines it (with MST_PROBE_BUILD) to stamp the phases; the product build has none
+#define TAIL_MARK(i)
+#endif
+
 namespace mst {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct TailCfg {
     static constexpr int BT = 64;                        // tokens per workgroup
-    static constexpr int WROWS = 256, KD = 64;           // weight slab: 256 rows x 64 k
-    static constexpr int WSLAB = WROWS * KD * 2;         // 32 KB
-    static constexpr int ASLAB = BT * KD * 2;            // 8 KB activation slab
-    static constexpr int NW = 3, NA = 3;                 // ring slots
-    static constexpr int OFF_W = 0;
-    static constexpr int OFF_A = OFF_W + NW * WSLAB;     // 96 KB
-    static constexpr int OFF_H = OFF_A + NA * ASLAB;     // 120 KB
-    static constexpr int OFF_B = OFF_H + 4 * ASLAB;      // 152 KB: b1 (4 KB), beyond the LayerNorm scratch
-    static constexpr int SMEM = OFF_B + MST_FF * 4;      // 156 KB (LayerNorm scratch, 129 KB, overlays [0, 129 KB) between phases)
-    static constexpr int P_STEPS = 16, F_STEPS = 64, SLABS = P_STEPS + F_STEPS;
-    static constexpr size_t LAYER_BYTES = (size_t)SLABS * WSLAB;     // 2.5 MB per layer
+    static constexpr int D = 16;                         // weight fragments in flight per wave (64 VGPRs; 128 KB per CU)
+    static constexpr int P_FRAG = 64, F1_FRAG = 32, F2_FRAG = 32, NFRAG = P_FRAG + 4 * (F1_FRAG + F2_FRAG);   // per wave
+    static constexpr size_t WAVE_BYTES = (size_t)NFRAG * 1024, LAYER_BYTES = 8 * WAVE_BYTES;                    // 2.5 MB per layer
+    static constexpr int LN_LD = MST_D * 4 + 16;         // LayerNorm scratch row: 512 fp32 + 16 B (conflict-free 16-B accesses)
+    static constexpr int OFF_ATT = 0;                    // phase P: att image, 64 x 1 KB
+    static constexpr int OFF_H = 0, HBUF = 32 * 1024;    // phase F: GELU output, 2 x (64 x 512 B)
+    static constexpr int OFF_B1 = 92 * 1024;             // FFN1 bias (4 KB), staged at kernel start
+    static constexpr int OFF_X1 = 96 * 1024;             // LayerNorm1 output, 64 x 1 KB; LN1's half-tile scratch [0, 66 KB) stays below OFF_B1
+    static constexpr int SMEM = 160 * 1024;
+    static_assert(32 * LN_LD <= OFF_B1 && 64 * LN_LD <= SMEM && 2 * HBUF <= OFF_B1, "LDS map");
+    static_assert(P_FRAG % D == 0 && F1_FRAG % D == 0 && F2_FRAG % D == 0, "every phase starts on prefetch slot 0");
 };
 
-// Pack one layer's three matrices ([out][in] f16, torch Linear layout) into the tail's weight stream.
-// Slab image: 16-B chunk c of row r at byte r * 128 + ((c ^ ((r >> 1) & 7)) << 4)  (ring_off_rb<128>: conflict-free b128 reads).
+// Pack one layer's three matrices ([out][in] f16, torch Linear layout) into the eight per-wave fragment streams.
+// Fragment f of wave w, lane l (r = l & 15, kq = l >> 4) = 8 consecutive k of one weight row: the 16x16x32 A operand.
 __global__ __launch_bounds__(256) void k_pack_tail(const f16* __restrict__ w_out, const f16* __restrict__ w1,
                                                    const f16* __restrict__ w2, f16* __restrict__ dst) {
-    const int total = TailCfg::SLABS * (TailCfg::WSLAB / 16);
+    using C = TailCfg;
+    const int total = 8 * C::NFRAG * 64;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int s = i / (TailCfg::WSLAB / 16), o = (i - s * (TailCfg::WSLAB / 16)) * 16;
-        const int r = o >> 7, pc = (o & 127) >> 4, c = pc ^ ((r >> 1) & 7), k0 = c * 8;
+        const int lane = i & 63, f = (i >> 6) % C::NFRAG, wave = (i >> 6) / C::NFRAG;
+        const int r = 32 * wave + (lane & 15), kq = 8 * (lane >> 4);
         const f16* src;
-        if (s < TailCfg::P_STEPS) {
-            const int ks = s >> 1, nh = s & 1;
-            src = w_out + (size_t)(256 * nh + r) * MST_D + 64 * ks + k0;
+        if (f < C::P_FRAG) {
+            const int k32 = f >> 2, nh = (f >> 1) & 1, rb = f & 1;
+            src = w_out + (size_t)(256 * nh + 16 * rb + r) * MST_D + 32 * k32 + kq;
         } else {
-            const int u = s - TailCfg::P_STEPS, hc = u >> 4, v = u & 15;
-            if (v < 8) src = w1 + (size_t)(256 * hc + r) * MST_D + 64 * v + k0;
-            else {
-                const int ks2 = (v - 8) >> 1, nh = (v - 8) & 1;
-                src = w2 + (size_t)(256 * nh + r) * MST_FF + 256 * hc + 64 * ks2 + k0;
+            const int u = f - C::P_FRAG, hc = u / (C::F1_FRAG + C::F2_FRAG), v = u % (C::F1_FRAG + C::F2_FRAG);
+            if (v < C::F1_FRAG) {
+                const int k32 = v >> 1, rb = v & 1;
+                src = w1 + (size_t)(256 * hc + 16 * rb + r) * MST_D + 32 * k32 + kq;
+            } else {
+                const int v2 = v - C::F1_FRAG, k32 = v2 >> 2, nh = (v2 >> 1) & 1, rb = v2 & 1;
+                src = w2 + (size_t)(256 * nh + 16 * rb + r) * MST_FF + 256 * hc + 32 * k32 + kq;
             }
         }
-        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(dst) + (size_t)s * TailCfg::WSLAB + o) = *reinterpret_cast<const uint4*>(src);
+        reinterpret_cast<uint4*>(dst)[i] = *reinterpret_cast<const uint4*>(src);
     }
 }
 
-struct TailLane {                 // accumulator -> (token, feature) map of this kernel's [nh][m] tiles
-    int wave, hh, l31;
-    __device__ __forceinline__ TailLane() {
-        const int lane = threadIdx.x & 63;
-        wave = threadIdx.x >> 6;
-        hh = lane >> 5;
-        l31 = lane & 31;
-    }
-    __device__ __forceinline__ int tok(int m) const { return 32 * m + l31; }
-    __device__ __forceinline__ int feat(int n, int g) const { return 256 * n + 32 * wave + 8 * g + 4 * hh; }
-};
-
-// 4 consecutive 1-KiB pieces, contiguous in LDS and in global memory: one M0 write, the instruction's immediate offset
-// advances both addresses (mst_gemm_dma.h, glds_group).
-__device__ __forceinline__ void tail_glds4(unsigned voff, unsigned long long sbase, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %2, %3\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024\n\t"
-                 "global_load_lds_dwordx4 %2, %3 offset:2048\n\tglobal_load_lds_dwordx4 %2, %3 offset:3072\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
+// One weight fragment: issued and counted by hand.  hipcc would batch plain loads (all D at the end of an unrolled pass,
+// vmcnt(0) at its head) and expose the L2 latency once per pass; it also cannot count loads it does not see, so NO
+// compiler-visible global load or store may be issued between a fragment's load and its wait (cdna guide 5.7 item 1) -- the
+// phases below keep theirs behind `tail_fence()`, where every outstanding fragment is OLDER than anything hipcc then counts.
+template <int OFF> __device__ __forceinline__ void tail_wload(u32x4& d, unsigned voff, unsigned long long sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(d) : "v"(voff), "s"(sbase), "n"(OFF));
 }
+template <int N> __device__ __forceinline__ void tail_wwait(u32x4& d) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(d) : "n"(N)); }
+__device__ __forceinline__ void tail_fence() { asm volatile("" ::: "memory"); }
+__device__ __forceinline__ void tail_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }   // LDS only: the stream stays in flight
+
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
 __device__ __forceinline__ void tail_glds1(unsigned voff, unsigned long long sbase, unsigned lds_dst) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
 }
 
-
-// LayerNorm of a 64 x 512 accumulator tile in ROW layout.  The accumulators (lane = token) are transposed through `scratch`
-// (64 rows of 2064 B, conflict-free for 16-B accesses); afterwards wave w owns rows [8 w, 8 w + 8) and a lane holds features
-// [4 lane, +4) and [256 + 4 lane, +4) of each: statistics are wave-level shuffles.  `ra` / `rb` carry the residual in and the
-// normalised rows out -- in the same registers, so LayerNorm1's output stays on chip as LayerNorm2's residual.
-struct TailRows { f32x4 a[8], b[8]; };
-
-// `resid(r, xa, xb)` adds row 8 wave + r's residual to (xa, xb) = this lane's two 4-feature groups.
-template <class Resid>
-__device__ __forceinline__ void tail_layernorm(f32x16 (&acc)[1][2][2], const TailLane& lc, char* scratch, const float* __restrict__ bias,
-                                               const float* __restrict__ gamma, const float* __restrict__ beta, TailRows& rv, Resid resid) {
-    constexpr int LD = MST_D * 4 + 16;
-#pragma unroll
-    for (int m = 0; m < 2; m++) {
-        char* trow = scratch + lc.tok(m) * LD;
-#pragma unroll
-        for (int n = 0; n < 2; n++)
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const f32x4 v = {acc[0][m][n][4 * g], acc[0][m][n][4 * g + 1], acc[0][m][n][4 * g + 2], acc[0][m][n][4 * g + 3]};
-                *reinterpret_cast<f32x4*>(trow + lc.feat(n, g) * 4) = v;
-            }
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int fa = lane * 4, fb = 256 + lane * 4;
-    const f32x4 ba = *reinterpret_cast<const f32x4*>(bias + fa), bb = *reinterpret_cast<const f32x4*>(bias + fb);
-    float mean[8], rstd[8];
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const int row = wave * 8 + r;
-        f32x4 xa = *reinterpret_cast<const f32x4*>(scratch + row * LD + fa * 4) + ba;
-        f32x4 xb = *reinterpret_cast<const f32x4*>(scratch + row * LD + fb * 4) + bb;
-        resid(r, xa, xb);
-        rv.a[r] = xa;
-        rv.b[r] = xb;
-        const f32x4 t = xa + xb;
-        mean[r] = wave_sum((t[0] + t[1]) + (t[2] + t[3])) * (1.0f / MST_D);
-    }
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        rv.a[r] -= mean[r];
-        rv.b[r] -= mean[r];
-        const f32x4 q = rv.a[r] * rv.a[r] + rv.b[r] * rv.b[r];
-        rstd[r] = ln_rstd(wave_sum((q[0] + q[1]) + (q[2] + q[3])));
-    }
-    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + fa), gb = *reinterpret_cast<const f32x4*>(gamma + fb);
-    const f32x4 ea = *reinterpret_cast<const f32x4*>(beta + fa), eb = *reinterpret_cast<const f32x4*>(beta + fb);
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        rv.a[r] = rv.a[r] * (ga * rstd[r]) + ea;
-        rv.b[r] = rv.b[r] * (gb * rstd[r]) + eb;
-    }
-}
-
 __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att, const f16* __restrict__ wt,
                                                     const float* __restrict__ b_out, const float* __restrict__ g1, const float* __restrict__ be1,
                                                     const float* __restrict__ b1, const float* __restrict__ b2,
                                                     const float* __restrict__ g2, const float* __restrict__ be2,
-                                                    f16* __restrict__ hx, f16* __restrict__ hl,
-                                                    f16* __restrict__ x1h, int M) {
+                                                    f16* __restrict__ hx, f16* __restrict__ hl, int M) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using C = TailCfg;
+    constexpr int D = C::D;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hh = lane >> 5, l31 = lane & 31;
+    const int t16 = lane & 15, q4 = lane >> 4;                       // accumulator map: token 16 tb + t16, features .. + 4 q4 + i
     const int tok0 = blockIdx.x * C::BT;
     const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-#if defined(TAIL_STAMP)                                 // diagnostic build (probes/tail_clock.hip): shader-clock / 100 MHz stamps per phase
-#define TAIL_MARK(i) if (tid == 0) { g_tail_stamp[blockIdx.x][2 * (i)] = __builtin_amdgcn_s_memtime(); g_tail_stamp[blockIdx.x][2 * (i) + 1] = __builtin_amdgcn_s_memrealtime(); }
-    unsigned long long tl_last = 0, tl_sum[3] = {0, 0, 0};   // FFN loop split: FFN1 steps / GELU + H image / FFN2 steps (shader cycles)
-#define TAIL_LAP(j) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tl_sum[j] += now_ - tl_last; tl_last = now_; }
-#else
-#define TAIL_MARK(i)
-#define TAIL_LAP(j)
-#endif
     TAIL_MARK(0)
 
-    // ---- DMA addressing.  Weight slab s: this wave's 4 pieces are bytes [4096 wave, +4096) of the slab, linear on both sides.
-    const unsigned w_voff = (unsigned)lane * 16u;
-    const char* const wbase = reinterpret_cast<const char*>(wt) + 4096 * wave;
-    // Activation slab ks of a [M][512] f16 tensor: this wave's piece = rows [8 wave, +8); lane -> row, physical chunk.
-    const int a_row = 8 * wave + (lane >> 3);
-    int a_tok = tok0 + a_row;
-    if (a_tok >= M) a_tok = M - 1;                                      // tail tile: clamp (rows beyond M are never stored)
-    const unsigned a_voff = (unsigned)a_tok * (unsigned)(MST_D * 2) + (unsigned)(((lane & 7) ^ ((a_row >> 1) & 7)) << 4);
-
-    auto issue_w = [&](int s) {                                          // weight slab s of the layer -> ring slot s % 3
-#if defined(TAIL_NODMA)                                 // timing ablation: MFMA + LDS reads on whatever the ring holds
-        return;
-#endif
-        const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + C::OFF_W + (s % C::NW) * C::WSLAB + 4096 * wave);
-        tail_glds4(w_voff, (unsigned long long)(wbase + (size_t)s * C::WSLAB), dst);
-    };
-    auto issue_a = [&](const f16* X, int ks, int aslot) {               // activation slab ks of X -> A slot
-#if defined(TAIL_NODMA)
-        return;
-#endif
-        const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + C::OFF_A + aslot * C::ASLAB + 1024 * wave);
-        tail_glds1(a_voff, (unsigned long long)(reinterpret_cast<const char*>(X) + ks * 128), dst);
-    };
-    // one slab against one activation slab: 4 k-steps of 16, A operand = weight rows of this wave, B = the two token tiles
-    auto mma_slab = [&](const char* wslot, const char* aslab, f32x16& a0, f32x16& a1) {
-#if defined(TAIL_NOMMA)                                 // timing ablation: DMA stream, waits and barriers only
-        return;
-#endif
-#pragma unroll
-        for (int k16 = 0; k16 < 4; k16++) {
-            const int c = 2 * k16 + hh;
-            f16x8 wf, x0, x1;
-#if defined(TAIL_NOREAD)                                // timing ablation: MFMAs on register garbage, no LDS reads
-            asm volatile("" : "=v"(wf), "=v"(x0), "=v"(x1));
-#else
-            wf = *reinterpret_cast<const f16x8*>(wslot + ring_off_rb<128>(32 * wave + l31, c));
-            x0 = *reinterpret_cast<const f16x8*>(aslab + ring_off_rb<128>(l31, c));
-            x1 = *reinterpret_cast<const f16x8*>(aslab + ring_off_rb<128>(32 + l31, c));
-#endif
-#if defined(TAIL_READONLY)                              // timing ablation: LDS reads only
-            asm volatile("" :: "v"(wf), "v"(x0), "v"(x1));
-#else
-            a0 = mfma_f16(wf, x0, a0);
-            a1 = mfma_f16(wf, x1, a1);
-#endif
-        }
-    };
-
-    // The two steps of a (k-slab, feature-half) pair -- out-proj and FFN2 -- multiply the SAME activation slab: its eight token
-    // fragments are read once, by the first step, and stay in registers for the second (8 + 4 fragment reads per pair instead
-    // of 12 + 12; fragment reads are one of the three ~0.5 kW consumers of DESIGN.md section 4 "Power").
-#ifndef TAIL_XREUSE
-#define TAIL_XREUSE 1
-#endif
-    f16x8 xk0[4], xk1[4];
-    auto mma_first = [&](const char* wslot, const char* aslab, f32x16& a0, f32x16& a1) {
-#if !TAIL_XREUSE || defined(TAIL_NOMMA) || defined(TAIL_NOREAD) || defined(TAIL_READONLY)
-        mma_slab(wslot, aslab, a0, a1);
-#else
-#pragma unroll
-        for (int k16 = 0; k16 < 4; k16++) {
-            const int c = 2 * k16 + hh;
-            const f16x8 wf = *reinterpret_cast<const f16x8*>(wslot + ring_off_rb<128>(32 * wave + l31, c));
-            xk0[k16] = *reinterpret_cast<const f16x8*>(aslab + ring_off_rb<128>(l31, c));
-            xk1[k16] = *reinterpret_cast<const f16x8*>(aslab + ring_off_rb<128>(32 + l31, c));
-            a0 = mfma_f16(wf, xk0[k16], a0);
-            a1 = mfma_f16(wf, xk1[k16], a1);
-        }
-#endif
-    };
-    auto mma_second = [&](const char* wslot, const char* aslab, f32x16& a0, f32x16& a1) {
-#if !TAIL_XREUSE || defined(TAIL_NOMMA) || defined(TAIL_NOREAD) || defined(TAIL_READONLY)
-        mma_slab(wslot, aslab, a0, a1);
-#else
-#pragma unroll
-        for (int k16 = 0; k16 < 4; k16++) {
-            const f16x8 wf = *reinterpret_cast<const f16x8*>(wslot + ring_off_rb<128>(32 * wave + l31, 2 * k16 + hh));
-            a0 = mfma_f16(wf, xk0[k16], a0);
-            a1 = mfma_f16(wf, xk1[k16], a1);
-        }
-#endif
-    };
-
-    // b1 (1024 floats) into LDS once: the GELU step then needs no global load inside the DMA-counted loop (an ordinary load
-    // there makes hipcc wait vmcnt(0), draining the ring: cdna guide section 5, "three .s-level traps" (b))
-    float* b1s = reinterpret_cast<float*>(smem + C::OFF_B);
+    // FFN1 bias -> LDS (the GELU stage must not issue a compiler-counted global load beside the stream)
+    float* b1s = reinterpret_cast<float*>(smem + C::OFF_B1);
     b1s[tid] = b1[tid];
     b1s[tid + 512] = b1[tid + 512];
+    tail_fence();
 
-    f32x16 acc[1][2][2];                    // [.][m][nh]: the LayerNorm epilogue's [1][MT][NT] shape (NT index = feature half)
-    auto zero_acc = [&]() {
+    // ---- att image: token row r of the tile = 1 KB, 16-B chunk c at c ^ (r & 15) (conflict-free ds_read_b128 of the 16x16x32 B
+    // operand: a 16-lane group reads 16 rows at chunks {c, c ^ 1} -> 16 distinct slots of the 256-B bank row).  LDS-DMA writes
+    // lane-linearly, so the swizzle is on the per-lane SOURCE address; wave w fills rows [8 w, 8 w + 8).
 #pragma unroll
-        for (int m = 0; m < 2; m++)
-#pragma unroll
-            for (int n = 0; n < 2; n++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) acc[0][m][n][r] = 0.f;
+    for (int j = 0; j < 8; j++) {
+        const int r = 8 * wave + j;
+        int tok = tok0 + r;
+        if (tok >= M) tok = M - 1;                                    // last tile: clamp (rows beyond M are never stored)
+        const unsigned voff = (unsigned)tok * (unsigned)(MST_D * 2) + (unsigned)((lane ^ (r & 15)) << 4);
+        tail_glds1(voff, (unsigned long long)att, __builtin_amdgcn_readfirstlane(smem_base + C::OFF_ATT + r * 1024));
+    }
+
+    // ---- the weight stream of this wave
+    const unsigned w_voff = (unsigned)lane * 16u;
+    const char* wnext = reinterpret_cast<const char*>(wt) + (size_t)wave * C::WAVE_BYTES;       // next fragment to request (wave-uniform)
+    u32x4 q[D];
+    auto issue = [&](auto jc) {                                       // fragment -> prefetch slot j (compile-time)
+        constexpr int j = decltype(jc)::value;
+        tail_wload<(j & 3) * 1024>(q[j], w_voff, (unsigned long long)(wnext + (j >> 2) * 4096));
     };
-    zero_acc();
+#define TAIL_ISSUE(j) issue(std::integral_constant<int, (j)>())
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+        // (unrolled: j is a constant in every copy)
+        switch (j) {
+#define TAIL_CASE(J) case J: TAIL_ISSUE(J); break;
+            TAIL_CASE(0) TAIL_CASE(1) TAIL_CASE(2) TAIL_CASE(3) TAIL_CASE(4) TAIL_CASE(5) TAIL_CASE(6) TAIL_CASE(7)
+            TAIL_CASE(8) TAIL_CASE(9) TAIL_CASE(10) TAIL_CASE(11) TAIL_CASE(12) TAIL_CASE(13) TAIL_CASE(14) TAIL_CASE(15)
+#undef TAIL_CASE
+        }
+    }
+    wnext += D * 1024;
+
+    // token fragments of k-step k32 from an image with ROWB-byte rows: lane -> token 16 tb + t16, chunk (4 k32 + q4) ^ t16
+    const unsigned xlane1k = (unsigned)t16 * 1024u, xlane512 = (unsigned)t16 * 512u, xswz = (unsigned)((q4 ^ t16) << 4);
+    auto xread = [&](const char* img, auto rowb, int k32, f16x8 (&x)[4]) {
+        constexpr int ROWB = decltype(rowb)::value;
+        const char* p = img + (ROWB == 1024 ? xlane1k : xlane512) + (((unsigned)k32 << 6) ^ xswz);
+#pragma unroll
+        for (int tb = 0; tb < 4; tb++) x[tb] = *reinterpret_cast<const f16x8*>(p + tb * 16 * ROWB);
+    };
+    using RB1K = std::integral_constant<int, 1024>;
+    using RB512 = std::integral_constant<int, 512>;
+
+    f32x4 acc[2][2][4];                     // [feature half nh][16-row block rb][16-token block tb]
+    f32x4 acch[2][4];                       // FFN1 chunk: [rb][tb]
+    f16x8 xs[2][4];                         // token fragments, double-buffered by k-step parity
+
+    // One unrolled pass = D fragments (`more`: another pass of the same phase follows).  RA fragments per k-step (4: out-proj / FFN2, both feature halves; 2: FFN1), each against the
+    // step's four token fragments.  LOAD = false: the stream's last pass (nothing left to request; the waits count down).
+    auto pass = [&](const char* img, auto rowb, auto rac, auto loadc, int k32base, bool more) {
+        constexpr int RA = decltype(rac)::value;
+        constexpr bool LOAD = decltype(loadc)::value;
+        constexpr int STEPS = D / RA;
+#pragma unroll
+        for (int s = 0; s < STEPS; s++) {
+            if (s + 1 < STEPS || more) xread(img, rowb, k32base + s + 1, xs[(s + 1) & 1]);   // one step ahead, across passes (STEPS is even); the phase's first by the caller
+#pragma unroll
+            for (int a = 0; a < RA; a++) {
+                constexpr int dummy = 0; (void)dummy;
+                const int j = s * RA + a;
+                // static slot index: the switch folds after unrolling
+                auto use = [&](auto jc) {
+                    constexpr int J = decltype(jc)::value;
+                    if constexpr (LOAD) tail_wwait<D - 1>(q[J]); else tail_wwait<D - 1 - J>(q[J]);
+                    const f16x8 wf = __builtin_bit_cast(f16x8, q[J]);
+                    if constexpr (RA == 4) {
+                        constexpr int nh = (J >> 1) & 1, rb = J & 1;
+#pragma unroll
+                        for (int tb = 0; tb < 4; tb++) acc[nh][rb][tb] = mfma16(wf, xs[(J / RA) & 1][tb], acc[nh][rb][tb]);
+                    } else {
+                        constexpr int rb = J & 1;
+#pragma unroll
+                        for (int tb = 0; tb < 4; tb++) acch[rb][tb] = mfma16(wf, xs[(J / RA) & 1][tb], acch[rb][tb]);
+                    }
+                    if constexpr (LOAD) tail_wload<(J & 3) * 1024>(q[J], w_voff, (unsigned long long)(wnext + (J >> 2) * 4096));
+                };
+                switch (j) {
+#define TAIL_CASE(J) case J: use(std::integral_constant<int, J>()); break;
+                    TAIL_CASE(0) TAIL_CASE(1) TAIL_CASE(2) TAIL_CASE(3) TAIL_CASE(4) TAIL_CASE(5) TAIL_CASE(6) TAIL_CASE(7)
+                    TAIL_CASE(8) TAIL_CASE(9) TAIL_CASE(10) TAIL_CASE(11) TAIL_CASE(12) TAIL_CASE(13) TAIL_CASE(14) TAIL_CASE(15)
+#undef TAIL_CASE
+                }
+            }
+        }
+        if constexpr (LOAD) wnext += D * 1024;
+    };
+    using RA4 = std::integral_constant<int, 4>;
+    using RA2 = std::integral_constant<int, 2>;
+    using LD1 = std::integral_constant<bool, true>;
+    using LD0 = std::integral_constant<bool, false>;
 
     // =========================================================================================== phase P: out-proj
-    // group of step s = weight slab s (+ the att slab ks = s / 2 when s is even); two groups in flight.
-    // Every accumulator index below is a compile-time constant (runtime-indexed ext-vector arrays go to scratch).
-    auto p_sync = [&](int s) {
-        if (s + 1 < C::P_STEPS) wait_vmcnt<4>();           // all but the newest group (>= 4 pieces per wave) have landed
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();                      // slab s visible to every wave; slot of slab s - 1 is free
-        if (s + 2 < C::P_STEPS) {
-            issue_w(s + 2);
-            if (((s + 2) & 1) == 0) issue_a(att, (s + 2) >> 1, ((s + 2) >> 1) % C::NA);
-        }
-    };
-    // LayerNorm1's residual (the stream rows of this tile, hi + lo) is requested NOW, as raw f16 pairs, and first touched after
-    // the out-proj loop: its HBM latency and its 128 KB per tile hide behind the weight stream of phase P.
-    const int row_lane = threadIdx.x & 63;
-    const int fa = row_lane * 4, fb = 256 + row_lane * 4;
-    uint2 rh_a[8], rl_a[8], rh_b[8], rl_b[8];
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const int tok = tok0 + 8 * wave + r;
-        const size_t off = (size_t)(tok < M ? tok : M - 1) * MST_D;
-        rh_a[r] = *reinterpret_cast<const uint2*>(hx + off + fa);
-        rl_a[r] = *reinterpret_cast<const uint2*>(hl + off + fa);
-        rh_b[r] = *reinterpret_cast<const uint2*>(hx + off + fb);
-        rl_b[r] = *reinterpret_cast<const uint2*>(hl + off + fb);
-    }
-    issue_w(0); issue_a(att, 0, 0);
-    issue_w(1);
-#pragma unroll 1
-    for (int ks = 0; ks < 8; ks++) {
-        const char* aslab = smem + C::OFF_A + (ks % C::NA) * C::ASLAB;
-        p_sync(2 * ks);
-        mma_first(smem + C::OFF_W + ((2 * ks) % C::NW) * C::WSLAB, aslab, acc[0][0][0], acc[0][1][0]);
-        p_sync(2 * ks + 1);
-        mma_second(smem + C::OFF_W + ((2 * ks + 1) % C::NW) * C::WSLAB, aslab, acc[0][0][1], acc[0][1][1]);
-    }
-    __syncthreads();                                       // ring dead (no DMA in flight): LayerNorm scratch overlays it
+    for (int nh = 0; nh < 2; nh++)
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+            for (int tb = 0; tb < 4; tb++) acc[nh][rb][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D) : "memory");          // this wave's att rows have landed (the D fragments behind them may fly on)
+    tail_barrier();                                                    // ... and everybody's
     TAIL_MARK(1)
-
-    const TailLane lm;
-    TailRows rv;                                           // x1 = LayerNorm1 output; lives through phase F as LayerNorm2's residual
-    tail_layernorm(acc, lm, smem, b_out, g1, be1, rv, [&](int r, f32x4& xa, f32x4& xb) {
-        xa = add4_f16(rh_a[r], rl_a[r], xa);
-        xb = add4_f16(rh_b[r], rl_b[r], xb);
-    });
-    // x1's f16 operand copy -> global scratch: phase F re-reads it through the activation ring (L2-hot; the LDS has no room
-    // for a resident 64 KB image beside the weight ring).  The fp32 rows stay in `rv` as LayerNorm2's residual.
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const int tok = tok0 + 8 * wave + r;
-        if (tok < M) {
-            const size_t off = (size_t)tok * MST_D;
-            *reinterpret_cast<uint2*>(x1h + off + fa) = pack4_f16(rv.a[r][0], rv.a[r][1], rv.a[r][2], rv.a[r][3]);
-            *reinterpret_cast<uint2*>(x1h + off + fb) = pack4_f16(rv.b[r][0], rv.b[r][1], rv.b[r][2], rv.b[r][3]);
-        }
+    {
+        const char* img = smem + C::OFF_ATT;
+        xread(img, RB1K(), 0, xs[0]);
+#pragma unroll 1
+        for (int ps = 0; ps < C::P_FRAG / D; ps++) pass(img, RB1K(), RA4(), LD1(), ps * (D / 4), ps + 1 < C::P_FRAG / D);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's x1 stores have reached L2 ...
-    __syncthreads();                                       // ... and everybody's: the ring may re-read x1h, the scratch is dead
     TAIL_MARK(2)
 
-    // =========================================================================================== phase F: FFN
-    zero_acc();
-    f32x16 acch0, acch1;
-    // step u = 16 hc + v: v < 8 -> FFN1 k-slab v (activation: x1h slab v through the A ring), v >= 8 -> FFN2 (ks2, nh) (activation: H image)
-    auto issue_f = [&](int u) {
-        issue_w(C::P_STEPS + u);
-        const int v = u & 15;
-        if (v < 8) issue_a(x1h, v, ((u >> 4) * 8 + v) % C::NA);
-    };
-    auto f_sync = [&](int u) {
-        if (u + 1 < C::F_STEPS) wait_vmcnt<4>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (u + 2 < C::F_STEPS) issue_f(u + 2);
-    };
-    issue_f(0);
-    issue_f(1);
-#if defined(TAIL_STAMP)
-    tl_last = __builtin_amdgcn_s_memtime();
-#endif
-#pragma unroll 1
-    for (int hc = 0; hc < 4; hc++) {
-        TAIL_LAP(2)
-#pragma unroll
-        for (int r = 0; r < 16; r++) { acch0[r] = 0.f; acch1[r] = 0.f; }
-#pragma unroll 1
-        for (int v = 0; v < 8; v++) {
-            const int u = 16 * hc + v;
-            f_sync(u);
-            mma_slab(smem + C::OFF_W + ((C::P_STEPS + u) % C::NW) * C::WSLAB, smem + C::OFF_A + ((hc * 8 + v) % C::NA) * C::ASLAB, acch0, acch1);
-        }
-        TAIL_LAP(0)
-        {
-            // GELU(acch + b1) -> H image: hidden feature j = 32 wave + 8 g + 4 hh + i of the chunk lives in activation slab
-            // j / 64 at k = j % 64.  The previous chunk's FFN2 steps finished 8 barriers ago; the barrier of the next step
-            // publishes these writes.
-            const float* bb = b1s + 256 * hc + 32 * wave + 4 * hh;
-            char* hslab = smem + C::OFF_H + (wave >> 1) * C::ASLAB;
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(bb + 8 * g);
-                const int c = 4 * (wave & 1) + g;
-                *reinterpret_cast<uint2*>(hslab + ring_off_rb<128>(l31, c) + 8 * hh) =
-                    pack4_f16(gelu_erf(acch0[4 * g] + bv[0]), gelu_erf(acch0[4 * g + 1] + bv[1]),
-                              gelu_erf(acch0[4 * g + 2] + bv[2]), gelu_erf(acch0[4 * g + 3] + bv[3]));
-                *reinterpret_cast<uint2*>(hslab + ring_off_rb<128>(32 + l31, c) + 8 * hh) =
-                    pack4_f16(gelu_erf(acch1[4 * g] + bv[0]), gelu_erf(acch1[4 * g + 1] + bv[1]),
-                              gelu_erf(acch1[4 * g + 2] + bv[2]), gelu_erf(acch1[4 * g + 3] + bv[3]));
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the raw s_barrier below waits for no counter
-        }
-        TAIL_LAP(1)
-#pragma unroll 1
-        for (int q = 0; q < 4; q++) {
-            const char* hsl = smem + C::OFF_H + q * C::ASLAB;
-            const int u = 16 * hc + 8 + 2 * q;
-            f_sync(u);
-            mma_first(smem + C::OFF_W + ((C::P_STEPS + u) % C::NW) * C::WSLAB, hsl, acc[0][0][0], acc[0][1][0]);
-            f_sync(u + 1);
-            mma_second(smem + C::OFF_W + ((C::P_STEPS + u + 1) % C::NW) * C::WSLAB, hsl, acc[0][0][1], acc[0][1][1]);
-        }
-    }
-    TAIL_LAP(2)
-    __syncthreads();
-    TAIL_MARK(3)
+    // =========================================================================================== LayerNorm1
+    // Rows of this wave in a half: 4 w + r, r < 4; a lane holds features [4 lane, +4) and [256 + 4 lane, +4) of each.
+    tail_fence();
+    tail_barrier();                                                    // every wave is done with the att image: the scratch overlays it
     {
-        TailRows x2;                                       // residual = x1 (still in registers), result = the stream rows
-        tail_layernorm(acc, lm, smem, b2, g2, be2, x2, [&](int r, f32x4& xa, f32x4& xb) { xa += rv.a[r]; xb += rv.b[r]; });
-        rv = x2;
-    }
+        const int fa = lane * 4, fb = 256 + lane * 4;
+        const f32x4 ba = *reinterpret_cast<const f32x4*>(b_out + fa), bb = *reinterpret_cast<const f32x4*>(b_out + fb);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(g1 + fa), gb = *reinterpret_cast<const f32x4*>(g1 + fb);
+        const f32x4 ea = *reinterpret_cast<const f32x4*>(be1 + fa), eb = *reinterpret_cast<const f32x4*>(be1 + fb);
+        char* x1img = smem + C::OFF_X1;
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const int tok = tok0 + 8 * wave + r;
-        if (tok < M) {
-            const size_t off = (size_t)tok * MST_D;
-            uint2 h, l;
-            split4_f16(rv.a[r], h, l);
-            *reinterpret_cast<uint2*>(hx + off + fa) = h;
-            *reinterpret_cast<uint2*>(hl + off + fa) = l;
-            split4_f16(rv.b[r], h, l);
-            *reinterpret_cast<uint2*>(hx + off + fb) = h;
-            *reinterpret_cast<uint2*>(hl + off + fb) = l;
+        for (int m = 0; m < 2; m++) {
+            // the stream rows (hi + lo) of this half: requested first, consumed behind the transpose and its barrier
+            uint2 rh_a[4], rl_a[4], rh_b[4], rl_b[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int tok = tok0 + 32 * m + 4 * wave + r;
+                const size_t off = (size_t)(tok < M ? tok : M - 1) * MST_D;
+                rh_a[r] = *reinterpret_cast<const uint2*>(hx + off + fa);
+                rl_a[r] = *reinterpret_cast<const uint2*>(hl + off + fa);
+                rh_b[r] = *reinterpret_cast<const uint2*>(hx + off + fb);
+                rl_b[r] = *reinterpret_cast<const uint2*>(hl + off + fb);
+            }
+            // accumulators of token blocks 2 m, 2 m + 1 -> scratch rows [0, 32)
+#pragma unroll
+            for (int tbl = 0; tbl < 2; tbl++) {
+                char* trow = smem + (16 * tbl + t16) * C::LN_LD;
+#pragma unroll
+                for (int nh = 0; nh < 2; nh++)
+#pragma unroll
+                    for (int rb = 0; rb < 2; rb++)
+                        *reinterpret_cast<f32x4*>(trow + (256 * nh + 32 * wave + 16 * rb + 4 * q4) * 4) = acc[nh][rb][2 * m + tbl];
+            }
+            tail_barrier();
+            f32x4 xa[4], xb[4];
+            float mean[4], rstd[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const char* srow = smem + (4 * wave + r) * C::LN_LD;
+                xa[r] = add4_f16(rh_a[r], rl_a[r], *reinterpret_cast<const f32x4*>(srow + fa * 4) + ba);
+                xb[r] = add4_f16(rh_b[r], rl_b[r], *reinterpret_cast<const f32x4*>(srow + fb * 4) + bb);
+                const f32x4 t = xa[r] + xb[r];
+                mean[r] = wave_sum((t[0] + t[1]) + (t[2] + t[3])) * (1.0f / MST_D);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                xa[r] -= mean[r];
+                xb[r] -= mean[r];
+                const f32x4 sq = xa[r] * xa[r] + xb[r] * xb[r];
+                rstd[r] = ln_rstd(wave_sum((sq[0] + sq[1]) + (sq[2] + sq[3])));
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                xa[r] = xa[r] * (ga * rstd[r]) + ea;
+                xb[r] = xb[r] * (gb * rstd[r]) + eb;
+                const int row = 4 * wave + r, trow = 32 * m + row;
+                // x1: fp32 back into the scratch row (FFN2's initial accumulator), f16 into the operand image
+                char* srow = smem + row * C::LN_LD;
+                *reinterpret_cast<f32x4*>(srow + fa * 4) = xa[r];
+                *reinterpret_cast<f32x4*>(srow + fb * 4) = xb[r];
+                char* irow = x1img + trow * 1024 + 8 * (lane & 1);
+                *reinterpret_cast<uint2*>(irow + ((((lane >> 1)) ^ (trow & 15)) << 4)) = pack4_f16(xa[r][0], xa[r][1], xa[r][2], xa[r][3]);
+                *reinterpret_cast<uint2*>(irow + (((32 + (lane >> 1)) ^ (trow & 15)) << 4)) = pack4_f16(xb[r][0], xb[r][1], xb[r][2], xb[r][3]);
+            }
+            tail_barrier();
+#pragma unroll
+            for (int tbl = 0; tbl < 2; tbl++) {
+                const char* trow = smem + (16 * tbl + t16) * C::LN_LD;
+#pragma unroll
+                for (int nh = 0; nh < 2; nh++)
+#pragma unroll
+                    for (int rb = 0; rb < 2; rb++) {
+                        acc[nh][rb][2 * m + tbl] = *reinterpret_cast<const f32x4*>(trow + (256 * nh + 32 * wave + 16 * rb + 4 * q4) * 4);
+                    }
+            }
+            tail_barrier();                                            // scratch free: the next half / the H image may overwrite it
         }
     }
+    tail_fence();
+    TAIL_MARK(3)
+
+    // =========================================================================================== phase F: FFN
+    {
+        const char* x1img = smem + C::OFF_X1;
+        // one chunk of 256 hidden features; LASTC: the stream ends with this chunk's FFN2 (its last pass requests nothing)
+        auto chunk = [&](int hc, auto lastc) {
+            constexpr bool LASTC = decltype(lastc)::value;
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+                for (int tb = 0; tb < 4; tb++) acch[rb][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            xread(x1img, RB1K(), 0, xs[0]);
+#pragma unroll 1
+            for (int ps = 0; ps < C::F1_FRAG / D; ps++) pass(x1img, RB1K(), RA2(), LD1(), ps * (D / 2), ps + 1 < C::F1_FRAG / D);
+            // GELU(acch + b1) -> H image of this chunk: hidden feature 32 w + 16 rb + 4 q4 + i = 8-B half (q4 & 1) of chunk
+            // 4 w + 2 rb + (q4 >> 1) of token row 16 tb + t16 (512-B rows, chunk ^ (row & 15)).  Buffer hc & 1: its previous readers
+            // (FFN2 of chunk hc - 2) passed the barrier of chunk hc - 1 after their last read.
+            char* himg = smem + C::OFF_H + (hc & 1) * C::HBUF;
+            {
+                const float* bb = b1s + 256 * hc + 32 * wave + 4 * q4;
+#pragma unroll
+                for (int rb = 0; rb < 2; rb++) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bb + 16 * rb);
+                    const unsigned coff = (unsigned)(((4 * wave + 2 * rb + (q4 >> 1)) ^ t16) << 4) + 8u * (q4 & 1);
+#pragma unroll
+                    for (int tb = 0; tb < 4; tb++) {
+                        const f32x4 v = acch[rb][tb] + bv;
+                        *reinterpret_cast<uint2*>(himg + (16 * tb + t16) * 512 + coff) =
+                            pack4_f16(gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3]));
+                    }
+                }
+            }
+            tail_barrier();
+            xread(himg, RB512(), 0, xs[0]);
+            static_assert(C::F2_FRAG / D == 2, "FFN2 of a chunk = two passes");
+            pass(himg, RB512(), RA4(), LD1(), 0, true);
+            if constexpr (LASTC) pass(himg, RB512(), RA4(), LD0(), D / 4, false);
+            else pass(himg, RB512(), RA4(), LD1(), D / 4, false);
+        };
+#pragma unroll 1
+        for (int hc = 0; hc < 3; hc++) chunk(hc, std::false_type());
+        chunk(3, std::true_type());
+    }
+    tail_fence();
+    tail_barrier();                                                    // everybody is done with the H / x1 images: the scratch overlays them
     TAIL_MARK(4)
-#if defined(TAIL_STAMP)
-    if (tid == 0) { g_tail_stamp[blockIdx.x][10] = tl_sum[0]; g_tail_stamp[blockIdx.x][11] = tl_sum[1]; g_tail_stamp[blockIdx.x][12] = tl_sum[2]; }
-#endif
-#undef TAIL_LAP
-#undef TAIL_MARK
+
+    // =========================================================================================== LayerNorm2 -> the stream
+    {
+#pragma unroll
+        for (int tb = 0; tb < 4; tb++) {
+            char* trow = smem + (16 * tb + t16) * C::LN_LD;
+#pragma unroll
+            for (int nh = 0; nh < 2; nh++)
+#pragma unroll
+                for (int rb = 0; rb < 2; rb++)
+                    *reinterpret_cast<f32x4*>(trow + (256 * nh + 32 * wave + 16 * rb + 4 * q4) * 4) = acc[nh][rb][tb];
+        }
+        tail_barrier();
+        const int fa = lane * 4, fb = 256 + lane * 4;
+        const f32x4 ba = *reinterpret_cast<const f32x4*>(b2 + fa), bb = *reinterpret_cast<const f32x4*>(b2 + fb);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(g2 + fa), gb = *reinterpret_cast<const f32x4*>(g2 + fb);
+        const f32x4 ea = *reinterpret_cast<const f32x4*>(be2 + fa), eb = *reinterpret_cast<const f32x4*>(be2 + fb);
+        f32x4 xa[8], xb[8];
+        float mean[8], rstd[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const char* srow = smem + (8 * wave + r) * C::LN_LD;
+            xa[r] = *reinterpret_cast<const f32x4*>(srow + fa * 4) + ba;
+            xb[r] = *reinterpret_cast<const f32x4*>(srow + fb * 4) + bb;
+            const f32x4 t = xa[r] + xb[r];
+            mean[r] = wave_sum((t[0] + t[1]) + (t[2] + t[3])) * (1.0f / MST_D);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            xa[r] -= mean[r];
+            xb[r] -= mean[r];
+            const f32x4 sq = xa[r] * xa[r] + xb[r] * xb[r];
+            rstd[r] = ln_rstd(wave_sum((sq[0] + sq[1]) + (sq[2] + sq[3])));
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int tok = tok0 + 8 * wave + r;
+            if (tok < M) {
+                const size_t off = (size_t)tok * MST_D;
+                uint2 h, l;
+                split4_f16(xa[r] * (ga * rstd[r]) + ea, h, l);
+                *reinterpret_cast<uint2*>(hx + off + fa) = h;
+                *reinterpret_cast<uint2*>(hl + off + fa) = l;
+                split4_f16(xb[r] * (gb * rstd[r]) + eb, h, l);
+                *reinterpret_cast<uint2*>(hx + off + fb) = h;
+                *reinterpret_cast<uint2*>(hl + off + fb) = l;
+            }
+        }
+    }
+    TAIL_MARK(5)
+#undef TAIL_ISSUE
 }
 
 }  // namespace mst
