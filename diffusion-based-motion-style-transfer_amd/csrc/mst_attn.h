@@ -27,7 +27,8 @@ __device__ __forceinline__ int v_off(int key, int d) { return key * 256 + ((((d 
 // qsplit = 1: grid.y = NKT and the workgroup computes only query tile blockIdx.y (small batches: rows * 4 workgroups
 // would leave the chip idle; re-staging K and V seven times is cheap when only a few clips run).
 template <int NKT>   // number of 32-key tiles = ceil(S / 32), 1..7
-__global__ __launch_bounds__(512) void k_attention(const f16* __restrict__ qkv, f16* __restrict__ out, int S, int qsplit) {
+// out_lo != null: also f16(o - hi), so that the out-projection can multiply the attention output as hi + lo (RowsDirect::Xlo).
+__global__ __launch_bounds__(512) void k_attention(const f16* __restrict__ qkv, f16* __restrict__ out, int S, int qsplit, f16* __restrict__ out_lo = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KEYS = NKT * 32;
     char* ks = smem;
@@ -150,8 +151,11 @@ __global__ __launch_bounds__(512) void k_attention(const f16* __restrict__ qkv, 
 #pragma unroll
             for (int gq = 0; gq < 4; gq++) {
                 int dd = dt * 32 + 8 * gq + 4 * hh;
-                *reinterpret_cast<uint2*>(orow + dd) =
-                    pack4_f16(o[4 * gq] * inv_l, o[4 * gq + 1] * inv_l, o[4 * gq + 2] * inv_l, o[4 * gq + 3] * inv_l);
+                const f32x4 ov = {o[4 * gq] * inv_l, o[4 * gq + 1] * inv_l, o[4 * gq + 2] * inv_l, o[4 * gq + 3] * inv_l};
+                uint2 h, l;
+                split4_f16(ov, h, l);
+                *reinterpret_cast<uint2*>(orow + dd) = h;
+                if (out_lo) *reinterpret_cast<uint2*>(out_lo + (orow - out) + dd) = l;
             }
         }
     }

@@ -114,7 +114,21 @@ __device__ __forceinline__ float erf_as(float x) {
 // LayerNorm in the engine (fused tail, GEMM epilogue, training rows) goes through here so the paths agree bit for bit.
 __device__ __forceinline__ float ln_rstd(float sum_sq) { return __builtin_amdgcn_rsqf(sum_sq * (1.0f / MST_D) + 1e-5f); }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
+// GELU(x) = x Phi(x) written as max(x, 0) - |x| E(|x|) with E(a) = erfc(a / sqrt 2) / 2 = (t P(t) / 2) exp(-a^2 / 2), t = 1 / (1 + p a / sqrt 2)
+// (the same Abramowitz-Stegun 7.1.26 polynomial as erf_as; 0.5 folded into its coefficients): 13 VALU ops instead of 18 -- no 1 + erf,
+// no sign transfer, exp2 taken directly -- and no cancellation for x < 0.  The layer tail spends ~7 us per 64-token tile in this
+// function (128 values per lane), which is why the instruction count matters.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float a = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, a, 1.0f));
+    float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+    p = fmaf(p, t, 0.5f * 1.421413741f);
+    p = fmaf(p, t, 0.5f * -0.284496736f);
+    p = fmaf(p, t, 0.5f * 0.254829592f);
+    const float m = a * 0.84932180028801904f;                    // sqrt(log2(e) / 2): exp(-a^2 / 2) = exp2(-m^2)
+    const float e = __builtin_amdgcn_exp2f(-(m * m));
+    return fmaf(-a, (p * t) * e, fmaxf(x, 0.0f));
+}
 
 // ------------------------------------------------------------------------------------------
 // Philox4x32-10 + Box-Muller: counter-based normals for the in-kernel noise mode.

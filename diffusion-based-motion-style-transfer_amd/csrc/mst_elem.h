@@ -24,8 +24,10 @@ __global__ void k_copy_pad_f32(const float* __restrict__ src, int n, float* __re
 // the activation operand of the pose-embedding GEMM in the layout the LDS-DMA ring loads.
 // gscale != null: values are multiplied by gscale[0] first (backward of the output projection: the incoming gradient
 // is brought into f16 range by the device-side scale of the training path).
+// xt_lo != null: also f16(x - hi), the second half of a hi + lo operand (RowsDirect::Xlo).
 __global__ __launch_bounds__(256) void k_frames_f16(const float* __restrict__ x, int F, int T, int Kpad, f16* __restrict__ xt,
-                                                    const float* __restrict__ gscale, const LoopDev* __restrict__ ld, unsigned long long eo) {
+                                                    const float* __restrict__ gscale, const LoopDev* __restrict__ ld, unsigned long long eo,
+                                                    f16* __restrict__ xt_lo = nullptr) {
     __shared__ float tile[32][33];
     if (ld) x = ld->x + eo;                          // sampling loop: the clip tensor of THIS call (captured graphs are replayed across calls)
     const float sc = gscale ? gscale[0] : 1.0f;
@@ -40,7 +42,12 @@ __global__ __launch_bounds__(256) void k_frames_f16(const float* __restrict__ x,
 #pragma unroll
     for (int j = ty; j < 32; j += 8) {
         int t = t0 + j, f = f0 + tx;
-        if (t < T && f < Kpad) xt[((size_t)clip * T + t) * Kpad + f] = (f16)(tile[tx][j] * sc);
+        if (t < T && f < Kpad) {
+            const float v = tile[tx][j] * sc;
+            const f16 h = (f16)v;
+            xt[((size_t)clip * T + t) * Kpad + f] = h;
+            if (xt_lo) xt_lo[((size_t)clip * T + t) * Kpad + f] = (f16)(v - (float)h);
+        }
     }
 }
 

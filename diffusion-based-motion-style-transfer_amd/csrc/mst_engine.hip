@@ -175,6 +175,7 @@ struct mst_engine {
     // workspace
     f16* hl = nullptr;        // lo half of the stream (hx is the hi half)
     f16 *hx = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr, *xt = nullptr;
+    f16* xt_lo = nullptr;     // lo half of the frame rows: the pose embedding multiplies x_t as hi + lo (RowsDirect::Xlo)
     float *temb_hid = nullptr, *temb = nullptr, *textproj = nullptr;
     int temb_cap = 0;
     std::vector<std::string> loaded;
@@ -315,6 +316,7 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     CHECK(dmalloc(&e->att, (size_t)e->M_pad * MST_D));
     CHECK(dmalloc(&e->hid, (size_t)e->M_pad * MST_FF));
     CHECK(dmalloc(&e->xt, ((size_t)c->max_rows * c->max_frames + 128) * e->kin_pad));
+    CHECK(dmalloc(&e->xt_lo, ((size_t)c->max_rows * c->max_frames + 128) * e->kin_pad));
     e->temb_cap = c->max_rows > 1024 ? c->max_rows : 1024;
     CHECK(dmalloc(&e->temb_hid, (size_t)e->temb_cap * MST_D));
     CHECK(dmalloc(&e->temb, (size_t)e->temb_cap * MST_D));
@@ -368,7 +370,7 @@ extern "C" void mst_engine_destroy(mst_engine* e) {
         for (void* q : p) (void)hipFree(q);
     }
     void* p[] = {e->w_pose_in, e->b_pose_in, e->w_pose_out, e->b_pose_out, e->w_pose_inT, e->w_pose_outT, e->w_t0, e->b_t0, e->w_t2, e->b_t2,
-                 e->w_text, e->b_text, e->pe, e->hl, e->hx, e->qkv, e->att, e->hid, e->xt, e->temb_hid, e->temb, e->textproj, e->zacc};
+                 e->w_text, e->b_text, e->pe, e->hl, e->hx, e->qkv, e->att, e->hid, e->xt, e->xt_lo, e->temb_hid, e->temb, e->textproj, e->zacc};
     for (void* q : p) (void)hipFree(q);
     for (int i = 0; i < mst_engine::MAX_SLICES - 1; i++) {
         if (e->aux_stream[i]) (void)hipStreamDestroy(e->aux_stream[i]);
@@ -599,11 +601,11 @@ static int launch_small(int M, int N, const SRC& xs, const f16* W, int ldw, int 
 }
 
 template <int NKT>
-static int launch_attn_n(const f16* qkv, f16* out, int S, int rows, hipStream_t st, int qsplit) {
+static int launch_attn_n(const f16* qkv, f16* out, int S, int rows, hipStream_t st, int qsplit, f16* out_lo) {
     auto kern = k_attention<NKT>;
     const int smem = NKT * 32 * 256 * 2;
     CHECK(ensure_dyn_lds((const void*)kern, smem));
-    hipLaunchKernelGGL(kern, dim3(rows * MST_H, qsplit ? NKT : 1), dim3(512), smem, st, qkv, out, S, qsplit);
+    hipLaunchKernelGGL(kern, dim3(rows * MST_H, qsplit ? NKT : 1), dim3(512), smem, st, qkv, out, S, qsplit, out_lo);
     HIPCHECK(hipGetLastError());
     return 0;
 }
@@ -632,15 +634,15 @@ static int launch_qkv_attn(const f16* hx, const f16* w_in, const float* b_in, f1
     return fail("attention: S=%d unsupported", S);
 }
 
-static int launch_attn(const f16* qkv, f16* out, int S, int rows, hipStream_t st, int qsplit = 0) {
+static int launch_attn(const f16* qkv, f16* out, int S, int rows, hipStream_t st, int qsplit = 0, f16* out_lo = nullptr) {
     switch ((S + 31) / 32) {
-        case 1: return launch_attn_n<1>(qkv, out, S, rows, st, qsplit);
-        case 2: return launch_attn_n<2>(qkv, out, S, rows, st, qsplit);
-        case 3: return launch_attn_n<3>(qkv, out, S, rows, st, qsplit);
-        case 4: return launch_attn_n<4>(qkv, out, S, rows, st, qsplit);
-        case 5: return launch_attn_n<5>(qkv, out, S, rows, st, qsplit);
-        case 6: return launch_attn_n<6>(qkv, out, S, rows, st, qsplit);
-        case 7: return launch_attn_n<7>(qkv, out, S, rows, st, qsplit);
+        case 1: return launch_attn_n<1>(qkv, out, S, rows, st, qsplit, out_lo);
+        case 2: return launch_attn_n<2>(qkv, out, S, rows, st, qsplit, out_lo);
+        case 3: return launch_attn_n<3>(qkv, out, S, rows, st, qsplit, out_lo);
+        case 4: return launch_attn_n<4>(qkv, out, S, rows, st, qsplit, out_lo);
+        case 5: return launch_attn_n<5>(qkv, out, S, rows, st, qsplit, out_lo);
+        case 6: return launch_attn_n<6>(qkv, out, S, rows, st, qsplit, out_lo);
+        case 7: return launch_attn_n<7>(qkv, out, S, rows, st, qsplit, out_lo);
     }
     return fail("attention: S=%d unsupported", S);
 }
@@ -678,12 +680,13 @@ extern "C" int mst_set_text(mst_engine* e, const float* text_emb, const float* k
 // A slice of the workspace: clips [r0, r0 + n) of the batch get their own rows of every buffer, so slices can
 // run concurrently on different streams (tiles may over-READ into a neighbour's rows; they never write them).
 struct WS {
-    f16 *hl, *hx, *qkv, *att, *hid, *xt; float* textproj; float* zacc;
+    f16 *hl, *hx, *qkv, *att, *hid, *xt; float* textproj; float* zacc; f16* xt_lo;
 };
 static WS ws_slice(const mst_engine* e, int r0, int T) {
     const size_t row = (size_t)r0 * (T + 1);
     return WS{e->hl + row * MST_D, e->hx + row * MST_D, e->qkv + row * 3 * MST_D, e->att + row * MST_D, e->hid + row * MST_FF,
-              e->xt + (size_t)r0 * T * e->kin_pad, e->textproj + (size_t)r0 * MST_D, e->zacc + row * MST_D};
+              e->xt + (size_t)r0 * T * e->kin_pad, e->textproj + (size_t)r0 * MST_D, e->zacc + row * MST_D,
+              e->xt_lo + (size_t)r0 * T * e->kin_pad};
 }
 
 // K6 + K7 + K8 of one layer as one launch (mst_tail.h): one workgroup per 64-token tile
@@ -711,14 +714,14 @@ static int assemble_stream(mst_engine* e, const WS& ws, const float* x, int clip
         ProfScope ps(e, FAM_EMBED_IN, st);
         const int F = e->cfg.feats, tot = clips_x * T;
         if (!lr.frames_ready) {
-            hipLaunchKernelGGL(k_frames_f16, dim3((T + 31) / 32, e->kin_pad / 32, clips_x), dim3(256), 0, st, x, F, T, e->kin_pad, ws.xt, (const float*)nullptr, lr.ld, lr.eo);
+            hipLaunchKernelGGL(k_frames_f16, dim3((T + 31) / 32, e->kin_pad / 32, clips_x), dim3(256), 0, st, x, F, T, e->kin_pad, ws.xt, (const float*)nullptr, lr.ld, lr.eo, ws.xt_lo);
             HIPCHECK(hipGetLastError());
         }
         DEpiEmbedIn epi{e->b_pose_in, e->pe, ws.hx, ws.hl, T, S, tot, rows > clips_x ? (size_t)clips_x * S * MST_D : 0};
         epi.ct.temb = e->temb; epi.ct.textproj = ws.textproj; epi.ct.ld = lr.ld;
         epi.ct.uniform_row = temb_uniform_row; epi.ct.temb_mod = temb_mod; epi.ct.joff = lr.joff; epi.ct.rows = rows;
         epi.ct.tp_half = rows > clips_x ? clips_x : 0; epi.ct.tp_uncond = rows > clips_x ? tp_uncond : 0;
-        CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1>(dim3((tot + 63) / 64, 1), RowsDirect{ws.xt, e->kin_pad}, e->w_pose_in, e->kin_pad,
+        CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1>(dim3((tot + 63) / 64, 1), RowsDirect{ws.xt, e->kin_pad, ws.xt_lo}, e->w_pose_in, e->kin_pad,
                                                    e->kin_pad, epi, st)));
     }
     return 0;
@@ -732,37 +735,45 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
     if (e->dbg_stage == 0) return 0;
 #define DBG_STOP(stage) if (e->dbg_layer == l && e->dbg_stage == stage) return 0;
     const bool small = e->small_m > 0 && M <= e->small_m;
+    // Clips of at most 16 frames: so few values are averaged per output that the f16 rounding of the ACTIVATION operands shows at the
+    // 1e-3 bar (oracle rounding model, classifier-free guidance: 1.07e-3 mean over seeds at 1 frame, 9.1e-4 at 5 frames, 7.6e-4 at
+    // 196).  Those launches -- a handful of tiles, nowhere near a throughput regime -- multiply every activation as hi + lo
+    // (RowsDirect::Xlo; the lo halves of att and hid borrow the idle hid / qkv buffers): 6.5e-4 mean in the same model.
+    const bool precise = small && T <= 16;
+    f16* const att_lo = precise ? ws.hid : nullptr;
+    f16* const hid_lo = precise ? ws.qkv : nullptr;
+    const f16* const hl_in = precise ? ws.hl : nullptr;
     for (int l = 0; small && l < e->cfg.num_layers; l++) {
         const LayerW& w = e->L[l];
         {
             ProfScope ps(e, FAM_QKV, st);
             DEpiBiasF16<false> epi{w.b_in, ws.qkv, 3 * MST_D, M};
-            CHECK(launch_small(M, 3 * MST_D, RowsDirect{ws.hx, MST_D}, w.w_in, MST_D, MST_D, epi, st));
+            CHECK(launch_small(M, 3 * MST_D, RowsDirect{ws.hx, MST_D, hl_in}, w.w_in, MST_D, MST_D, epi, st));
         }
         DBG_STOP(1)
         {
             ProfScope ps(e, FAM_ATTN, st);
-            CHECK(launch_attn(ws.qkv, ws.att, S, rows, st, 1));
+            CHECK(launch_attn(ws.qkv, ws.att, S, rows, st, 1, att_lo));
         }
         DBG_STOP(2)
         {
             ProfScope ps(e, FAM_OUTPROJ_LN, st);
             DEpiPlainF32 epi{ws.zacc, MST_D, M};
-            CHECK(launch_small(M, MST_D, RowsDirect{ws.att, MST_D}, w.w_out, MST_D, MST_D, epi, st));
+            CHECK(launch_small(M, MST_D, RowsDirect{ws.att, MST_D, att_lo}, w.w_out, MST_D, MST_D, epi, st));
             hipLaunchKernelGGL(k_ln_rows, dim3((M + 3) / 4), dim3(256), 0, st, ws.zacc, w.b_out, w.g1, w.be1, ws.hx, ws.hl, M);
             HIPCHECK(hipGetLastError());
         }
         DBG_STOP(3)
         {
             ProfScope ps(e, FAM_FFN1, st);
-            DEpiBiasF16<true> epi{w.b1, ws.hid, MST_FF, M};
-            CHECK(launch_small(M, MST_FF, RowsDirect{ws.hx, MST_D}, w.w1, MST_D, MST_D, epi, st));
+            DEpiBiasF16<true> epi{w.b1, ws.hid, MST_FF, M, hid_lo};
+            CHECK(launch_small(M, MST_FF, RowsDirect{ws.hx, MST_D, hl_in}, w.w1, MST_D, MST_D, epi, st));
         }
         DBG_STOP(4)
         {
             ProfScope ps(e, FAM_FFN2_LN, st);
             DEpiPlainF32 epi{ws.zacc, MST_D, M};
-            CHECK(launch_small(M, MST_D, RowsDirect{ws.hid, MST_FF}, w.w2, MST_FF, MST_FF, epi, st));
+            CHECK(launch_small(M, MST_D, RowsDirect{ws.hid, MST_FF, hid_lo}, w.w2, MST_FF, MST_FF, epi, st));
             hipLaunchKernelGGL(k_ln_rows, dim3((M + 3) / 4), dim3(256), 0, st, ws.zacc, w.b2, w.g2, w.be2, ws.hx, ws.hl, M);
             HIPCHECK(hipGetLastError());
         }
@@ -829,26 +840,27 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
 // output projection tiles: 64 frames x (256 * NTO) features, 8 waves as 1 x 8 with 2 x NTO MFMA tiles each
 template <int MODE, int NTO, int NX>
 static int launch_out(mst_engine* e, const WS& ws, int batch, int T, float* out, const StepArgs& sa, hipStream_t st,
-                      const f16* w_override = nullptr, const float* b_override = nullptr, int tok_off = 1, bool frames_next = false) {
+                      const f16* w_override = nullptr, const float* b_override = nullptr, int tok_off = 1, bool frames_next = false,
+                      bool hi_lo = false) {
     const int S = T + tok_off;
-    RowsFrames xs{ws.hx, MST_D, T, S, batch * T, 64, (size_t)batch * S, tok_off};
+    RowsFrames xs{ws.hx, MST_D, T, S, batch * T, 64, (size_t)batch * S, tok_off, hi_lo ? ws.hl : nullptr};   // hi_lo: ws.hx / ws.hl are the last stream
     DEpiEmbedOut<MODE> epi{b_override ? b_override : e->b_pose_out, e->cfg.feats, T, batch * T, out, sa};
-    if (frames_next) { epi.xt_next = ws.xt; epi.kpad = e->kin_pad; }
+    if (frames_next) { epi.xt_next = ws.xt; epi.kpad = e->kin_pad; epi.xt_next_lo = ws.xt_lo; }
     return launch_gemm_dma<64, 256 * NTO, 2, NTO, 4, NX>(dim3((batch * T + 63) / 64, 1), xs, w_override ? w_override : e->w_pose_out, MST_D, MST_D, epi, st);
 }
 template <int MODE, int NTO>
 static int launch_out_nx(mst_engine* e, const WS& ws, int cfg, int batch, int T, float* out, const StepArgs& sa, hipStream_t st,
-                         const f16* wo = nullptr, const float* bo = nullptr, int tok_off = 1, bool frames_next = false) {
-    return cfg ? launch_out<MODE, NTO, 2>(e, ws, batch, T, out, sa, st, wo, bo, tok_off, frames_next)
-               : launch_out<MODE, NTO, 1>(e, ws, batch, T, out, sa, st, wo, bo, tok_off, frames_next);
+                         const f16* wo = nullptr, const float* bo = nullptr, int tok_off = 1, bool frames_next = false, bool hi_lo = false) {
+    return cfg ? launch_out<MODE, NTO, 2>(e, ws, batch, T, out, sa, st, wo, bo, tok_off, frames_next, hi_lo)
+               : launch_out<MODE, NTO, 1>(e, ws, batch, T, out, sa, st, wo, bo, tok_off, frames_next, hi_lo);
 }
 template <int MODE>
 static int launch_out_nt(mst_engine* e, const WS& ws, int cfg, int batch, int T, float* out, const StepArgs& sa, hipStream_t st,
-                         const f16* wo = nullptr, const float* bo = nullptr, int tok_off = 1, bool frames_next = false) {
+                         const f16* wo = nullptr, const float* bo = nullptr, int tok_off = 1, bool frames_next = false, bool hi_lo = false) {
     ProfScope ps(e, FAM_EMBED_OUT, st);
     switch (e->nt_out) {
-        case 1: return launch_out_nx<MODE, 1>(e, ws, cfg, batch, T, out, sa, st, wo, bo, tok_off, frames_next);
-        case 2: return launch_out_nx<MODE, 2>(e, ws, cfg, batch, T, out, sa, st, wo, bo, tok_off, frames_next);
+        case 1: return launch_out_nx<MODE, 1>(e, ws, cfg, batch, T, out, sa, st, wo, bo, tok_off, frames_next, hi_lo);
+        case 2: return launch_out_nx<MODE, 2>(e, ws, cfg, batch, T, out, sa, st, wo, bo, tok_off, frames_next, hi_lo);
     }
     return fail("output projection: feats %d unsupported", e->cfg.feats);
 }
@@ -877,7 +889,7 @@ extern "C" int mst_forward(mst_engine* e, const float* x, const int64_t* t, cons
     CHECK(run_trunk(e, ws, x, batch, rows, frames, -1, batch, st, batch));
     StepArgs sa{};
     sa.scale = scale;
-    return launch_out_nt<0>(e, ws, cfg, batch, frames, out, sa, st);
+    return launch_out_nt<0>(e, ws, cfg, batch, frames, out, sa, st, nullptr, nullptr, 1, false, true);
 }
 
 // How many independent clip slices a loop over `batch` clips of `frames` frames runs as.  Measured, same box, interleaved
@@ -951,8 +963,8 @@ static int enqueue_step(mst_engine* e, const LoopPlan& p, int joff, int nsj, boo
         sa.eo = eo;
         sa.step_stride = p.clip_elems;
         sa.rowflag = (a->inpainting_mask_dev && a->inpainted_motion_dev) ? e->rowflag + (size_t)c0 * e->cfg.feats : nullptr;
-        if (a->sampler == MST_SAMPLER_DDPM) CHECK(launch_out_nt<1>(e, ws, a->cfg, nb, a->frames, nullptr, sa, ss, nullptr, nullptr, 1, frames_next));
-        else CHECK(launch_out_nt<2>(e, ws, a->cfg, nb, a->frames, nullptr, sa, ss, nullptr, nullptr, 1, frames_next));
+        if (a->sampler == MST_SAMPLER_DDPM) CHECK(launch_out_nt<1>(e, ws, a->cfg, nb, a->frames, nullptr, sa, ss, nullptr, nullptr, 1, frames_next, true));
+        else CHECK(launch_out_nt<2>(e, ws, a->cfg, nb, a->frames, nullptr, sa, ss, nullptr, nullptr, 1, frames_next, true));
     }
     return 0;
 }
@@ -1569,8 +1581,9 @@ extern "C" int mst_train_model_forward(mst_engine* e, const float* x, const int6
     }
     CHECK(train_stack_forward(e, t, batch, S, p_drop, seed, nullptr, st));
     ws.hx = t.sh[nl];
+    ws.hl = t.sl[nl];
     StepArgs sa{};
-    return launch_out_nt<0>(e, ws, 0, batch, frames, out, sa, st);
+    return launch_out_nt<0>(e, ws, 0, batch, frames, out, sa, st, nullptr, nullptr, 1, false, true);
 }
 
 extern "C" int mst_train_model_backward(mst_engine* e, const void* tape, const float* d_out, int32_t batch, int32_t frames,

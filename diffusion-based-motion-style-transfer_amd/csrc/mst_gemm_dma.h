@@ -121,16 +121,24 @@ struct DmaPlan {
 };
 
 // Row sources: which global row feeds tile row r of the activation operand.
+// `Xlo` (optional, same layout as X): the activation is the pair hi + lo (f16(x) and f16(x - hi), ~22 significant bits) and the
+// GEMM runs its K range twice -- W . hi + W . lo into the same accumulators -- so the operand rounding of THIS product
+// disappears.  Used where it is nearly free and pays most: the pose embedding (the rounding of x_t perturbs everything
+// behind it) and the output projection (the rounding of the last stream goes straight into the result): one 64-clip
+// forward 4.8e-4 -> 3.6e-4, classifier-free guidance 7.3e-4 -> 5.5e-4 relative L2 in the oracle's rounding model.
 struct RowsDirect {                       // tile row r = matrix row tok0 + r
-    const f16* X; int ld;
+    const f16* X; int ld; const f16* Xlo = nullptr;
     __device__ __forceinline__ const char* base() const { return reinterpret_cast<const char*>(X); }
+    __device__ __forceinline__ const char* base_lo() const { return reinterpret_cast<const char*>(Xlo); }
     __device__ __forceinline__ unsigned rowbyte(int tok0, int r) const { return (unsigned)(tok0 + r) * (unsigned)ld * 2u; }
 };
 struct RowsFrames {                       // tile row r = frame (tok0 + r) of the token stream, conditioning token skipped;
     const f16* X; int ld; int T, S, total;   // rows >= BT (second group) come from the uncond half (+cfg_rows)
     int BT; size_t cfg_rows;
     int tok_off = 1;                          // tokens in front of the frames: 1 (conditioning token) or 2 (the motion encoder's mu / sigma queries)
+    const f16* Xlo = nullptr;
     __device__ __forceinline__ const char* base() const { return reinterpret_cast<const char*>(X); }
+    __device__ __forceinline__ const char* base_lo() const { return reinterpret_cast<const char*>(Xlo); }
     __device__ __forceinline__ unsigned rowbyte(int tok0, int r) const {
         int half = r >= BT ? 1 : 0;
         int tok = tok0 + r - half * BT;
@@ -153,12 +161,17 @@ __device__ __forceinline__ void gemm_mainloop_dma(char* smem, const SRC& xs, con
         return row < TL::XROWS ? xs.rowbyte(tok0, row) : (unsigned)(f0 + row - TL::XROWS) * (unsigned)ldw * 2u;
     });
     const char* xb = xs.base();
+    const char* xlo = xs.base_lo();
     const char* wb = reinterpret_cast<const char*>(W);
-    const int KT = K / TL::KDEPTH;
+    const int KT1 = K / TL::KDEPTH, KT = xlo ? 2 * KT1 : KT1;   // hi + lo operand: the K range twice, weights re-streamed (L2-hot)
     constexpr int AHEAD = TL::NSTAGE - 1;                    // slabs in flight
+    auto issue = [&](int kt) {
+        if (kt < KT1) plan.issue(smem_base, kt, kt, xb, wb);
+        else plan.issue(smem_base, kt, kt - KT1, xlo, wb);
+    };
 #pragma unroll
     for (int s = 0; s < AHEAD; s++)
-        if (s < KT) plan.issue(smem_base, s, s, xb, wb);
+        if (s < KT) issue(s);
 
     for (int kt = 0; kt < KT; kt++) {
         const int rem = KT - 1 - kt;                        // slabs already issued beyond kt: min(rem, AHEAD - 1)
@@ -166,7 +179,7 @@ __device__ __forceinline__ void gemm_mainloop_dma(char* smem, const SRC& xs, con
         else if (AHEAD >= 3 && rem == 1) wait_vmcnt<TL::PER>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();                       // slab kt landed for every wave; slot of slab kt-1 is free
-        if (kt + AHEAD < KT) plan.issue(smem_base, kt + AHEAD, kt + AHEAD, xb, wb);
+        if (kt + AHEAD < KT) issue(kt + AHEAD);
         const char* st = smem + (kt % TL::NSTAGE) * TL::STAGE;
 #pragma unroll
         for (int ks = 0; ks < TL::KDEPTH / 16; ks++) {
@@ -215,6 +228,7 @@ struct DLane {
 template <bool GELU>
 struct DEpiBiasF16 {
     const float* bias; f16* out; int ldo; int M;
+    f16* out_lo = nullptr;                   // optional f16(v - hi) beside the result (precise tiny-clip path: the next GEMM's Xlo)
     __device__ __forceinline__ int rows() const { return M; }
     // rows transposed per pass: as many as fit ~68 KB (128 rows of 512 B, 64 rows of 1 KiB)
     template <int BT, int BF> static constexpr int pass_rows() { return (BT * (BF * 2 + 16) <= 69632) ? BT : (BF == 512 ? 64 : 128); }
@@ -249,7 +263,11 @@ struct DEpiBiasF16 {
                             v[i] = acc[0][m][n][4 * g + i] + b[i];
                             if (GELU) v[i] = gelu_erf(v[i]);
                         }
-                        *reinterpret_cast<uint2*>(trow + f * 2) = pack4_f16(v[0], v[1], v[2], v[3]);
+                        uint2 hi2, lo2;
+                        split4_f16(f32x4{v[0], v[1], v[2], v[3]}, hi2, lo2);
+                        *reinterpret_cast<uint2*>(trow + f * 2) = hi2;
+                        // lo half: straight from the accumulator layout (tiny launches only; no second transpose pass)
+                        if (out_lo && tok0 + tl < M) *reinterpret_cast<uint2*>(out_lo + (size_t)(tok0 + tl) * ldo + f0 + f) = lo2;
                     }
             }
             __syncthreads();
@@ -530,7 +548,7 @@ struct DEpiEmbedOut {
     const float* bias; int F, T, total; float* out; StepArgs sa;
     // xt_next != null (sampling loop, T % 4 == 0): the updated clip is ALSO written as the f16 frame rows [token][kpad] the NEXT
     // step's pose-embedding GEMM stages -- bit for bit what k_frames_f16 would make of it -- so that step needs no transpose launch
-    f16* xt_next = nullptr; int kpad = 0;
+    f16* xt_next = nullptr; int kpad = 0; f16* xt_next_lo = nullptr;      // lo: f16(x - hi), the second half of the pose embedding's hi + lo operand
     __device__ __forceinline__ int rows() const { return total; }
     template <int BT, int BF> static constexpr int smem_bytes() { return BF * (BT + 4) * 4; }
 
@@ -634,13 +652,16 @@ struct DEpiEmbedOut {
             for (int it = threadIdx.x; it < BT * groups; it += 512) {
                 const int tl = it % BT, fg = it / BT, tok = tok0 + tl;
                 if (tok >= total) continue;
-                f16x8 v;
+                f16x8 v, vl;
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
                     const int f = f0 + 8 * fg + q;
-                    v[q] = f < F ? (f16)tile[f * LDT + tl] : (f16)0.f;
+                    const float xv = f < F ? tile[f * LDT + tl] : 0.f;
+                    v[q] = (f16)xv;
+                    vl[q] = (f16)(xv - (float)v[q]);
                 }
                 *reinterpret_cast<f16x8*>(xt_next + (size_t)tok * kpad + f0 + 8 * fg) = v;
+                if (xt_next_lo) *reinterpret_cast<f16x8*>(xt_next_lo + (size_t)tok * kpad + f0 + 8 * fg) = vl;
             }
         }
     }

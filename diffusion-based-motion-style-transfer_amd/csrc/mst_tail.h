@@ -51,6 +51,7 @@ struct TailCfg {
     static constexpr int SMEM = 160 * 1024;
     static_assert(32 * LN_LD <= OFF_B1 && 64 * LN_LD <= SMEM && 2 * HBUF <= OFF_B1, "LDS map");
     static_assert(P_FRAG % D == 0 && F1_FRAG % D == 0 && F2_FRAG % D == 0, "every phase starts on prefetch slot 0");
+    static_assert(F1_FRAG == 32 && F2_FRAG == 32, "k_pack_tail's unit arithmetic");
 };
 
 // Pack one layer's three matrices ([out][in] f16, torch Linear layout) into the eight per-wave fragment streams.
@@ -67,12 +68,16 @@ __global__ __launch_bounds__(256) void k_pack_tail(const f16* __restrict__ w_out
             const int k32 = f >> 2, nh = (f >> 1) & 1, rb = f & 1;
             src = w_out + (size_t)(256 * nh + 16 * rb + r) * MST_D + 32 * k32 + kq;
         } else {
-            const int u = f - C::P_FRAG, hc = u / (C::F1_FRAG + C::F2_FRAG), v = u % (C::F1_FRAG + C::F2_FRAG);
-            if (v < C::F1_FRAG) {
+            // FFN units of 32 fragments in consumption order: F1(0) F1(1) F2(0) F1(2) F2(1) F1(3) F2(2) F2(3) -- FFN2 of chunk hc runs
+            // beside the GELU of chunk hc + 1, so FFN1 is one chunk ahead
+            const int u = f - C::P_FRAG, unit = u >> 5, v = u & 31;
+            const bool is2 = unit == 7 || (unit >= 2 && !(unit & 1));
+            const int hc = unit == 7 ? 3 : is2 ? (unit >> 1) - 1 : unit == 0 ? 0 : (unit + 1) >> 1;
+            if (!is2) {
                 const int k32 = v >> 1, rb = v & 1;
                 src = w1 + (size_t)(256 * hc + 16 * rb + r) * MST_D + 32 * k32 + kq;
             } else {
-                const int v2 = v - C::F1_FRAG, k32 = v2 >> 2, nh = (v2 >> 1) & 1, rb = v2 & 1;
+                const int k32 = v >> 2, nh = (v >> 1) & 1, rb = v & 1;
                 src = w2 + (size_t)(256 * nh + 16 * rb + r) * MST_FF + 256 * hc + 32 * k32 + kq;
             }
         }
@@ -114,15 +119,17 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
     const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     TAIL_MARK(0)
 
-    // FFN1 bias -> LDS (the GELU stage must not issue a compiler-counted global load beside the stream)
+    // ---- kernel-start burst, all LDS-DMA (counted in vmcnt with the weight fragments behind it, no register, no compiler-visible load):
+    //  (1) the att image: token row r of the tile = 1 KB, 16-B chunk c at c ^ (r & 15) (conflict-free ds_read_b128 of the 16x16x32 B
+    //      operand: a 16-lane group reads 16 rows at chunks {c, c ^ 1} -> 16 distinct slots of the 256-B bank row).  LDS-DMA writes
+    //      lane-linearly, so the swizzle is on the per-lane SOURCE address; wave w fills rows [8 w, 8 w + 8);
+    //  (2) the FFN1 bias (4 KB, waves 0..3): the GELU stage reads it from LDS;
+    //  (3) LayerNorm1's residual for the tile's first 32 tokens: stream rows hi -> [OFF_X1, +32 KB), lo -> [OFF_X1 + 32 KB, +32 KB), row-linear,
+    //      wave w its own LN1 rows [4 w, 4 w + 4).  Requested after the out-proj loop instead, these rows cost ~3 us of exposed latency
+    //      (the loads queue behind 128 KB of prefetched fragments and then miss L2); the second half's rows ARE requested there, into
+    //      registers, and land while the first half is normalised.  The x1 image later overwrites the staging area row by row, each
+    //      row by the wave that consumed it.
     float* b1s = reinterpret_cast<float*>(smem + C::OFF_B1);
-    b1s[tid] = b1[tid];
-    b1s[tid + 512] = b1[tid + 512];
-    tail_fence();
-
-    // ---- att image: token row r of the tile = 1 KB, 16-B chunk c at c ^ (r & 15) (conflict-free ds_read_b128 of the 16x16x32 B
-    // operand: a 16-lane group reads 16 rows at chunks {c, c ^ 1} -> 16 distinct slots of the 256-B bank row).  LDS-DMA writes
-    // lane-linearly, so the swizzle is on the per-lane SOURCE address; wave w fills rows [8 w, 8 w + 8).
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const int r = 8 * wave + j;
@@ -130,6 +137,16 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
         if (tok >= M) tok = M - 1;                                    // last tile: clamp (rows beyond M are never stored)
         const unsigned voff = (unsigned)tok * (unsigned)(MST_D * 2) + (unsigned)((lane ^ (r & 15)) << 4);
         tail_glds1(voff, (unsigned long long)att, __builtin_amdgcn_readfirstlane(smem_base + C::OFF_ATT + r * 1024));
+    }
+    if (wave < 4) tail_glds1((unsigned)lane * 16u, (unsigned long long)(b1 + 256 * wave), __builtin_amdgcn_readfirstlane(smem_base + C::OFF_B1 + 1024 * wave));
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        int tok = tok0 + 4 * wave + r;
+        if (tok >= M) tok = M - 1;
+        const unsigned voff = (unsigned)tok * (unsigned)(MST_D * 2) + (unsigned)lane * 16u;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + C::OFF_X1 + (4 * wave + r) * 1024);
+        tail_glds1(voff, (unsigned long long)hx, dst);
+        tail_glds1(voff, (unsigned long long)hl, dst + 32768);
     }
 
     // ---- the weight stream of this wave
@@ -170,7 +187,7 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
 
     // One unrolled pass = D fragments (`more`: another pass of the same phase follows).  RA fragments per k-step (4: out-proj / FFN2, both feature halves; 2: FFN1), each against the
     // step's four token fragments.  LOAD = false: the stream's last pass (nothing left to request; the waits count down).
-    auto pass = [&](const char* img, auto rowb, auto rac, auto loadc, int k32base, bool more) {
+    auto pass = [&](const char* img, auto rowb, auto rac, auto loadc, int k32base, bool more, auto side) {
         constexpr int RA = decltype(rac)::value;
         constexpr bool LOAD = decltype(loadc)::value;
         constexpr int STEPS = D / RA;
@@ -204,6 +221,7 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
 #undef TAIL_CASE
                 }
             }
+            side(s);                                                   // VALU work riding in the matrix steps' shadow (the GELU of the next chunk)
         }
         if constexpr (LOAD) wnext += D * 1024;
     };
@@ -226,7 +244,7 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
         const char* img = smem + C::OFF_ATT;
         xread(img, RB1K(), 0, xs[0]);
 #pragma unroll 1
-        for (int ps = 0; ps < C::P_FRAG / D; ps++) pass(img, RB1K(), RA4(), LD1(), ps * (D / 4), ps + 1 < C::P_FRAG / D);
+        for (int ps = 0; ps < C::P_FRAG / D; ps++) pass(img, RB1K(), RA4(), LD1(), ps * (D / 4), ps + 1 < C::P_FRAG / D, [](int) {});
     }
     TAIL_MARK(2)
 
@@ -240,19 +258,19 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
         const f32x4 ga = *reinterpret_cast<const f32x4*>(g1 + fa), gb = *reinterpret_cast<const f32x4*>(g1 + fb);
         const f32x4 ea = *reinterpret_cast<const f32x4*>(be1 + fa), eb = *reinterpret_cast<const f32x4*>(be1 + fb);
         char* x1img = smem + C::OFF_X1;
+        // the stream rows (hi + lo) of the second half: requested now, consumed after the first half (its rows wait in LDS)
+        uint2 rh_a[4], rl_a[4], rh_b[4], rl_b[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int tok = tok0 + 32 + 4 * wave + r;
+            const size_t off = (size_t)(tok < M ? tok : M - 1) * MST_D;
+            rh_a[r] = *reinterpret_cast<const uint2*>(hx + off + fa);
+            rl_a[r] = *reinterpret_cast<const uint2*>(hl + off + fa);
+            rh_b[r] = *reinterpret_cast<const uint2*>(hx + off + fb);
+            rl_b[r] = *reinterpret_cast<const uint2*>(hl + off + fb);
+        }
 #pragma unroll
         for (int m = 0; m < 2; m++) {
-            // the stream rows (hi + lo) of this half: requested first, consumed behind the transpose and its barrier
-            uint2 rh_a[4], rl_a[4], rh_b[4], rl_b[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int tok = tok0 + 32 * m + 4 * wave + r;
-                const size_t off = (size_t)(tok < M ? tok : M - 1) * MST_D;
-                rh_a[r] = *reinterpret_cast<const uint2*>(hx + off + fa);
-                rl_a[r] = *reinterpret_cast<const uint2*>(hl + off + fa);
-                rh_b[r] = *reinterpret_cast<const uint2*>(hx + off + fb);
-                rl_b[r] = *reinterpret_cast<const uint2*>(hl + off + fb);
-            }
             // accumulators of token blocks 2 m, 2 m + 1 -> scratch rows [0, 32)
 #pragma unroll
             for (int tbl = 0; tbl < 2; tbl++) {
@@ -264,13 +282,20 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
                         *reinterpret_cast<f32x4*>(trow + (256 * nh + 32 * wave + 16 * rb + 4 * q4) * 4) = acc[nh][rb][2 * m + tbl];
             }
             tail_barrier();
+            TAIL_MARK(6 + 3 * m)
             f32x4 xa[4], xb[4];
             float mean[4], rstd[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const char* srow = smem + (4 * wave + r) * C::LN_LD;
-                xa[r] = add4_f16(rh_a[r], rl_a[r], *reinterpret_cast<const f32x4*>(srow + fa * 4) + ba);
-                xb[r] = add4_f16(rh_b[r], rl_b[r], *reinterpret_cast<const f32x4*>(srow + fb * 4) + bb);
+                if (m == 0) {
+                    const char* stg = x1img + (4 * wave + r) * 1024 + lane * 8;
+                    xa[r] = add4_f16(*reinterpret_cast<const uint2*>(stg), *reinterpret_cast<const uint2*>(stg + 32768), *reinterpret_cast<const f32x4*>(srow + fa * 4) + ba);
+                    xb[r] = add4_f16(*reinterpret_cast<const uint2*>(stg + 512), *reinterpret_cast<const uint2*>(stg + 32768 + 512), *reinterpret_cast<const f32x4*>(srow + fb * 4) + bb);
+                } else {
+                    xa[r] = add4_f16(rh_a[r], rl_a[r], *reinterpret_cast<const f32x4*>(srow + fa * 4) + ba);
+                    xb[r] = add4_f16(rh_b[r], rl_b[r], *reinterpret_cast<const f32x4*>(srow + fb * 4) + bb);
+                }
                 const f32x4 t = xa[r] + xb[r];
                 mean[r] = wave_sum((t[0] + t[1]) + (t[2] + t[3])) * (1.0f / MST_D);
             }
@@ -294,6 +319,7 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
                 *reinterpret_cast<uint2*>(irow + ((((lane >> 1)) ^ (trow & 15)) << 4)) = pack4_f16(xa[r][0], xa[r][1], xa[r][2], xa[r][3]);
                 *reinterpret_cast<uint2*>(irow + (((32 + (lane >> 1)) ^ (trow & 15)) << 4)) = pack4_f16(xb[r][0], xb[r][1], xb[r][2], xb[r][3]);
             }
+            TAIL_MARK(7 + 3 * m)
             tail_barrier();
 #pragma unroll
             for (int tbl = 0; tbl < 2; tbl++) {
@@ -306,52 +332,65 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
                     }
             }
             tail_barrier();                                            // scratch free: the next half / the H image may overwrite it
+            TAIL_MARK(8 + 3 * m)
         }
     }
     tail_fence();
     TAIL_MARK(3)
 
     // =========================================================================================== phase F: FFN
+    // Order: F1(0) G(0) | F1(1) [F2(0) + G(1)] | F1(2) [F2(1) + G(2)] | F1(3) [F2(2) + G(3)] | F2(3), "|" = the one barrier per chunk.
+    // The GELU of a chunk (128 values per lane and tile, ~13 VALU ops each: 1.8 us per chunk when it runs alone, with the matrix
+    // pipe idle) rides in the FFN2 steps of the chunk before it: those accumulate into `acc`, the GELU reads the finished `acch`.
     {
         const char* x1img = smem + C::OFF_X1;
-        // one chunk of 256 hidden features; LASTC: the stream ends with this chunk's FFN2 (its last pass requests nothing)
-        auto chunk = [&](int hc, auto lastc) {
-            constexpr bool LASTC = decltype(lastc)::value;
+        auto ffn1 = [&]() {
 #pragma unroll
             for (int rb = 0; rb < 2; rb++)
 #pragma unroll
                 for (int tb = 0; tb < 4; tb++) acch[rb][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
             xread(x1img, RB1K(), 0, xs[0]);
 #pragma unroll 1
-            for (int ps = 0; ps < C::F1_FRAG / D; ps++) pass(x1img, RB1K(), RA2(), LD1(), ps * (D / 2), ps + 1 < C::F1_FRAG / D);
-            // GELU(acch + b1) -> H image of this chunk: hidden feature 32 w + 16 rb + 4 q4 + i = 8-B half (q4 & 1) of chunk
-            // 4 w + 2 rb + (q4 >> 1) of token row 16 tb + t16 (512-B rows, chunk ^ (row & 15)).  Buffer hc & 1: its previous readers
-            // (FFN2 of chunk hc - 2) passed the barrier of chunk hc - 1 after their last read.
-            char* himg = smem + C::OFF_H + (hc & 1) * C::HBUF;
-            {
-                const float* bb = b1s + 256 * hc + 32 * wave + 4 * q4;
-#pragma unroll
-                for (int rb = 0; rb < 2; rb++) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bb + 16 * rb);
-                    const unsigned coff = (unsigned)(((4 * wave + 2 * rb + (q4 >> 1)) ^ t16) << 4) + 8u * (q4 & 1);
-#pragma unroll
-                    for (int tb = 0; tb < 4; tb++) {
-                        const f32x4 v = acch[rb][tb] + bv;
-                        *reinterpret_cast<uint2*>(himg + (16 * tb + t16) * 512 + coff) =
-                            pack4_f16(gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3]));
-                    }
-                }
-            }
-            tail_barrier();
-            xread(himg, RB512(), 0, xs[0]);
-            static_assert(C::F2_FRAG / D == 2, "FFN2 of a chunk = two passes");
-            pass(himg, RB512(), RA4(), LD1(), 0, true);
-            if constexpr (LASTC) pass(himg, RB512(), RA4(), LD0(), D / 4, false);
-            else pass(himg, RB512(), RA4(), LD1(), D / 4, false);
+            for (int ps = 0; ps < C::F1_FRAG / D; ps++) pass(x1img, RB1K(), RA2(), LD1(), ps * (D / 2), ps + 1 < C::F1_FRAG / D, [](int) {});
         };
+        // GELU(acch[rb][tb] + b1) -> H image of chunk hc: hidden feature 32 w + 16 rb + 4 q4 + i = 8-B half (q4 & 1) of chunk
+        // 4 w + 2 rb + (q4 >> 1) of token row 16 tb + t16 (512-B rows, chunk ^ (row & 15)).  Buffer hc & 1: its previous readers (FFN2 of
+        // chunk hc - 2) passed a barrier after their last read.
+        auto gelu_group = [&](int hc, int rb, int tb) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(b1s + 256 * hc + 32 * wave + 4 * q4 + 16 * rb);
+            const unsigned coff = (unsigned)(((4 * wave + 2 * rb + (q4 >> 1)) ^ t16) << 4) + 8u * (q4 & 1);
+            const f32x4 v = acch[rb][tb] + bv;
+            *reinterpret_cast<uint2*>(smem + C::OFF_H + (hc & 1) * C::HBUF + (16 * tb + t16) * 512 + coff) =
+                pack4_f16(gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3]));
+        };
+        static_assert(C::F2_FRAG / D == 2 && D / 4 == 4, "FFN2 of a chunk = two passes of four k-steps: one GELU group per k-step");
+        ffn1();
+        TAIL_MARK(12)
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+            for (int tb = 0; tb < 4; tb++) gelu_group(0, rb, tb);
+        TAIL_MARK(13)
+        tail_barrier();
+        TAIL_MARK(14)
 #pragma unroll 1
-        for (int hc = 0; hc < 3; hc++) chunk(hc, std::false_type());
-        chunk(3, std::true_type());
+        for (int hc = 0; hc < 3; hc++) {
+            ffn1();                                                     // chunk hc + 1
+            TAIL_MARK(15 + 3 * hc)
+            const char* himg = smem + C::OFF_H + (hc & 1) * C::HBUF;
+            xread(himg, RB512(), 0, xs[0]);
+            pass(himg, RB512(), RA4(), LD1(), 0, true, [&](int s) { gelu_group(hc + 1, 0, s); });
+            pass(himg, RB512(), RA4(), LD1(), D / 4, false, [&](int s) { gelu_group(hc + 1, 1, s); });
+            TAIL_MARK(16 + 3 * hc)
+            tail_barrier();
+            TAIL_MARK(17 + 3 * hc)
+        }
+        {
+            const char* himg = smem + C::OFF_H + C::HBUF;              // chunk 3
+            xread(himg, RB512(), 0, xs[0]);
+            pass(himg, RB512(), RA4(), LD1(), 0, true, [](int) {});
+            pass(himg, RB512(), RA4(), LD0(), D / 4, false, [](int) {});
+        }
     }
     tail_fence();
     tail_barrier();                                                    // everybody is done with the H / x1 images: the scratch overlays them

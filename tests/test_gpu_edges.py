@@ -43,12 +43,17 @@ def test_forward_and_loop_on_ragged_shapes(F, T, B):
     t = np.array([0, 999, 431][:B])
     eng.set_text(cu(txt))
     out = eng.forward(cu(x), cu(t)).cpu().numpy()
-    assert rel_l2(out, denoiser.forward(w, pe, x, t, txt).numpy()) < TOL
+    e_fwd = rel_l2(out, denoiser.forward(w, pe, x, t, txt).numpy())
+    assert e_fwd < TOL
     # CFG on the same shape
     eng.set_text(cu(txt), cfg=True)
     sc = np.linspace(1.5, 2.5, B).astype(np.float32)
     out = eng.forward(cu(x), cu(t), scale=cu(sc), cfg=True).cpu().numpy()
-    assert rel_l2(out, denoiser.cfg_forward(w, pe, x, t, txt, sc).numpy()) < TOL
+    e_cfg = rel_l2(out, denoiser.cfg_forward(w, pe, x, t, txt, sc).numpy())
+    print(f"ragged ({F},{T},{B}): forward {e_fwd:.3e}, cfg {e_cfg:.3e}")
+    assert e_cfg < TOL
+    if T <= 16:                      # clips of <= 16 frames multiply every activation as hi + lo (engine: `precise`): margin, not luck, under the bar
+        assert e_cfg < 8e-4
     # a short loop per sampler, with a mask that is not the root pattern (every third feature, frames 0..T/2)
     mask = np.zeros(shape, np.float32)
     mask[:, ::3, :, : max(1, T // 2)] = 1

@@ -1,0 +1,10 @@
+# Round 3: quick look at a tail edit: forward parity (one file, -k forward), phase stamps, two interleaved A/B rounds against the round-2 library.
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "forward" > gpurun_out/r3_parity.log 2>&1; rc=$?
+tail -3 gpurun_out/r3_parity.log
+[ $rc -eq 0 ] || exit $rc
+P=diffusion-based-motion-style-transfer_amd/csrc/probes/bin
+timeout -k 10 120 $P/tail_clock > gpurun_out/r3_tail_clock.txt 2>&1 || exit 1
+tail -3 gpurun_out/r3_tail_clock.txt
+bash tools/lib_ab.sh ${1:-lib_r2.so} default | head -4
