@@ -40,16 +40,17 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct TailCfg {
     static constexpr int BT = 64;                        // tokens per workgroup
-    static constexpr int D = 16;                         // weight fragments in flight per wave (64 VGPRs; 128 KB per CU)
+    static constexpr int D = 16;                         // weight fragments in flight per wave (64 VGPRs; 128 KB per CU).  8 measures the same (43.2 vs 43.1 us)
     static constexpr int P_FRAG = 64, F1_FRAG = 32, F2_FRAG = 32, NFRAG = P_FRAG + 4 * (F1_FRAG + F2_FRAG);   // per wave
     static constexpr size_t WAVE_BYTES = (size_t)NFRAG * 1024, LAYER_BYTES = 8 * WAVE_BYTES;                    // 2.5 MB per layer
     static constexpr int LN_LD = MST_D * 4 + 16;         // LayerNorm scratch row: 512 fp32 + 16 B (conflict-free 16-B accesses)
     static constexpr int OFF_ATT = 0;                    // phase P: att image, 64 x 1 KB
     static constexpr int OFF_H = 0, HBUF = 32 * 1024;    // phase F: GELU output, 2 x (64 x 512 B)
+    static constexpr int OFF_CNT = 68 * 1024;            // 4 arrival counters of the FFN chunks (above LN1's half-tile scratch, below OFF_B1)
     static constexpr int OFF_B1 = 92 * 1024;             // FFN1 bias (4 KB), staged at kernel start
     static constexpr int OFF_X1 = 96 * 1024;             // LayerNorm1 output, 64 x 1 KB; LN1's half-tile scratch [0, 66 KB) stays below OFF_B1
     static constexpr int SMEM = 160 * 1024;
-    static_assert(32 * LN_LD <= OFF_B1 && 64 * LN_LD <= SMEM && 2 * HBUF <= OFF_B1, "LDS map");
+    static_assert(32 * LN_LD <= OFF_CNT && OFF_CNT + 16 <= OFF_B1 && 64 * LN_LD <= SMEM && 2 * HBUF <= OFF_CNT, "LDS map");
     static_assert(P_FRAG % D == 0 && F1_FRAG % D == 0 && F2_FRAG % D == 0, "every phase starts on prefetch slot 0");
     static_assert(F1_FRAG == 32 && F2_FRAG == 32, "k_pack_tail's unit arithmetic");
 };
@@ -130,6 +131,8 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
     //      registers, and land while the first half is normalised.  The x1 image later overwrites the staging area row by row, each
     //      row by the wave that consumed it.
     float* b1s = reinterpret_cast<float*>(smem + C::OFF_B1);
+    unsigned* const arrived = reinterpret_cast<unsigned*>(smem + C::OFF_CNT);      // [chunk]: waves whose GELU output of that chunk is in the H image
+    if (tid < 4) arrived[tid] = 0;                                                  // published by the barrier in front of the out-proj loop
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const int r = 8 * wave + j;
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
     u32x4 q[D];
     auto issue = [&](auto jc) {                                       // fragment -> prefetch slot j (compile-time)
         constexpr int j = decltype(jc)::value;
-        tail_wload<(j & 3) * 1024>(q[j], w_voff, (unsigned long long)(wnext + (j >> 2) * 4096));
+        if constexpr (j < D) tail_wload<(j & 3) * 1024>(q[j], w_voff, (unsigned long long)(wnext + (j >> 2) * 4096));
     };
 #define TAIL_ISSUE(j) issue(std::integral_constant<int, (j)>())
 #pragma unroll
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
                 const int j = s * RA + a;
                 // static slot index: the switch folds after unrolling
                 auto use = [&](auto jc) {
-                    constexpr int J = decltype(jc)::value;
+                    constexpr int J = decltype(jc)::value < D ? decltype(jc)::value : 0;      // (cases >= D are never taken)
                     if constexpr (LOAD) tail_wwait<D - 1>(q[J]); else tail_wwait<D - 1 - J>(q[J]);
                     const f16x8 wf = __builtin_bit_cast(f16x8, q[J]);
                     if constexpr (RA == 4) {
@@ -339,57 +342,79 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
     TAIL_MARK(3)
 
     // =========================================================================================== phase F: FFN
-    // Order: F1(0) G(0) | F1(1) [F2(0) + G(1)] | F1(2) [F2(1) + G(2)] | F1(3) [F2(2) + G(3)] | F2(3), "|" = the one barrier per chunk.
-    // The GELU of a chunk (128 values per lane and tile, ~13 VALU ops each: 1.8 us per chunk when it runs alone, with the matrix
+    // Order: F1(0) G(0) a0 | F1(1) w0 [F2(0) + G(1)] a1 | F1(2) w1 [F2(1) + G(2)] a2 | F1(3) w2 [F2(2) + G(3)] a3 | w3 F2(3).
+    // The GELU of a chunk (128 values per lane and tile, ~12 VALU ops each: 1.8 us per chunk when it runs alone, with the matrix
     // pipe idle) rides in the FFN2 steps of the chunk before it: those accumulate into `acc`, the GELU reads the finished `acch`.
+    // (Measured and not kept: a second acch set so that the GELU also spreads over the following FFN1 -- the phase is bound by the
+    // SIMDs' VALU + MFMA issue slots, 20.4 us of busy time per wave however the ~2 300 GELU issue cycles per chunk are placed.)
+    // a / w = a SPLIT barrier on an LDS counter per chunk: a wave announces its GELU output (a), runs the next chunk's FFN1 -- ~2 us
+    // that need nobody else's data -- and only then waits for the other seven (w).  LDS operations of a wave are processed in
+    // order, so the H stores are in place before the counter moves; whoever reads the counter as 8 reads the data behind it.
     {
         const char* x1img = smem + C::OFF_X1;
-        auto ffn1 = [&]() {
+        auto ffn1 = [&](int hc) {                                      // acch = b1 + W1 . x1^T of chunk hc (the bias is the initial accumulator)
+            const float* bb = b1s + 256 * hc + 32 * wave + 4 * q4;
 #pragma unroll
-            for (int rb = 0; rb < 2; rb++)
+            for (int rb = 0; rb < 2; rb++) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bb + 16 * rb);
 #pragma unroll
-                for (int tb = 0; tb < 4; tb++) acch[rb][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int tb = 0; tb < 4; tb++) acch[rb][tb] = bv;
+            }
             xread(x1img, RB1K(), 0, xs[0]);
 #pragma unroll 1
             for (int ps = 0; ps < C::F1_FRAG / D; ps++) pass(x1img, RB1K(), RA2(), LD1(), ps * (D / 2), ps + 1 < C::F1_FRAG / D, [](int) {});
         };
-        // GELU(acch[rb][tb] + b1) -> H image of chunk hc: hidden feature 32 w + 16 rb + 4 q4 + i = 8-B half (q4 & 1) of chunk
+        // GELU(acch[rb][tb]) -> H image of chunk hc: hidden feature 32 w + 16 rb + 4 q4 + i = 8-B half (q4 & 1) of chunk
         // 4 w + 2 rb + (q4 >> 1) of token row 16 tb + t16 (512-B rows, chunk ^ (row & 15)).  Buffer hc & 1: its previous readers (FFN2 of
-        // chunk hc - 2) passed a barrier after their last read.
+        // chunk hc - 2) had all announced chunk hc - 1 before this wave got past w(hc - 1).
         auto gelu_group = [&](int hc, int rb, int tb) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(b1s + 256 * hc + 32 * wave + 4 * q4 + 16 * rb);
             const unsigned coff = (unsigned)(((4 * wave + 2 * rb + (q4 >> 1)) ^ t16) << 4) + 8u * (q4 & 1);
-            const f32x4 v = acch[rb][tb] + bv;
+            const f32x4 v = acch[rb][tb];
             *reinterpret_cast<uint2*>(smem + C::OFF_H + (hc & 1) * C::HBUF + (16 * tb + t16) * 512 + coff) =
                 pack4_f16(gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3]));
         };
-        static_assert(C::F2_FRAG / D == 2 && D / 4 == 4, "FFN2 of a chunk = two passes of four k-steps: one GELU group per k-step");
-        ffn1();
+        auto announce = [&](int hc) {
+            tail_fence();
+            if (lane == 0) __hip_atomic_fetch_add(arrived + hc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            tail_fence();
+        };
+        auto await = [&](int hc) {
+            tail_fence();
+            while (__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile unsigned*>(arrived + hc)) < 8u) __builtin_amdgcn_s_sleep(1);
+            tail_fence();
+        };
+        static_assert(C::F2_FRAG / 4 == 8, "FFN2 of a chunk = eight k-steps: one GELU group (rb, tb) per k-step");
+        constexpr int NP2 = C::F2_FRAG / D, ST2 = D / 4;               // FFN2 passes per chunk, k-steps per pass
+        ffn1(0);
         TAIL_MARK(12)
 #pragma unroll
         for (int rb = 0; rb < 2; rb++)
 #pragma unroll
             for (int tb = 0; tb < 4; tb++) gelu_group(0, rb, tb);
+        announce(0);
         TAIL_MARK(13)
-        tail_barrier();
-        TAIL_MARK(14)
 #pragma unroll 1
         for (int hc = 0; hc < 3; hc++) {
-            ffn1();                                                     // chunk hc + 1
+            ffn1(hc + 1);
+            TAIL_MARK(14 + 3 * hc)
+            await(hc);
             TAIL_MARK(15 + 3 * hc)
             const char* himg = smem + C::OFF_H + (hc & 1) * C::HBUF;
             xread(himg, RB512(), 0, xs[0]);
-            pass(himg, RB512(), RA4(), LD1(), 0, true, [&](int s) { gelu_group(hc + 1, 0, s); });
-            pass(himg, RB512(), RA4(), LD1(), D / 4, false, [&](int s) { gelu_group(hc + 1, 1, s); });
+#pragma unroll
+            for (int ps = 0; ps < NP2; ps++)
+                pass(himg, RB512(), RA4(), LD1(), ps * ST2, ps + 1 < NP2, [&](int s) { const int g = ps * ST2 + s; gelu_group(hc + 1, g >> 2, g & 3); });
+            announce(hc + 1);
             TAIL_MARK(16 + 3 * hc)
-            tail_barrier();
-            TAIL_MARK(17 + 3 * hc)
         }
         {
+            await(3);
+            TAIL_MARK(23)
             const char* himg = smem + C::OFF_H + C::HBUF;              // chunk 3
             xread(himg, RB512(), 0, xs[0]);
-            pass(himg, RB512(), RA4(), LD1(), 0, true, [](int) {});
-            pass(himg, RB512(), RA4(), LD0(), D / 4, false, [](int) {});
+#pragma unroll
+            for (int ps = 0; ps + 1 < NP2; ps++) pass(himg, RB512(), RA4(), LD1(), ps * ST2, true, [](int) {});
+            pass(himg, RB512(), RA4(), LD0(), (NP2 - 1) * ST2, false, [](int) {});
         }
     }
     tail_fence();

@@ -44,7 +44,7 @@ int main(int argc, char** argv) {
         float ms; hipEventElapsedTime(&ms, e0, e1);
         static unsigned long long st[1024][8][48];
         hipMemcpyFromSymbol(st, HIP_SYMBOL(g_tail_stamp), sizeof(st));
-        std::vector<double> ghz, tot, ph[5], ln[7], ff[4];
+        std::vector<double> ghz, tot, ph[5], ln[7], ff[5];
         for (int g = 0; g < grid; g++) {
             unsigned long long rt[12], r0 = ~0ull;
             double cyc = 0, rsum = 0;
@@ -55,17 +55,18 @@ int main(int argc, char** argv) {
             tot.push_back((double)(rt[5] - r0) * 0.01);
             ph[0].push_back((double)(rt[1] - r0) * 0.01);
             for (int p = 1; p < 5; p++) ph[p].push_back((double)(rt[p + 1] - rt[p]) * 0.01);
-            {   // phase F as each wave lives it (mean over the 8 waves): FFN1(0), GELU(0) alone, the 4 barrier waits, 3 x (FFN1 + FFN2 with the next GELU inside), FFN2(3)
-                double a[4] = {0, 0, 0, 0};
+            {   // phase F as each wave lives it (mean over the 8 waves): FFN1 passes alone, GELU(0) alone, the waits on the arrival counters, FFN2 with the next GELU inside, FFN2(3)
+                double a[5] = {0, 0, 0, 0, 0};
                 for (int wv = 0; wv < 8; wv++) {
                     auto R = [&](int i) { return (double)st[g][wv][2 * i + 1]; };
-                    a[0] += R(12) - R(3);
-                    a[1] += R(13) - R(12);
-                    a[2] += R(14) - R(13);
-                    for (int hc = 0; hc < 3; hc++) { a[3] += R(16 + 3 * hc) - R(14 + 3 * hc); a[2] += R(17 + 3 * hc) - R(16 + 3 * hc); }
-                    a[0] += R(4) - R(23);
+                    a[0] += R(12) - R(3);                  // F1(0)
+                    a[1] += R(13) - R(12);                 // G(0) + announce
+                    double prev = R(13);
+                    for (int hc = 0; hc < 3; hc++) { a[0] += R(14 + 3 * hc) - prev; a[2] += R(15 + 3 * hc) - R(14 + 3 * hc); a[3] += R(16 + 3 * hc) - R(15 + 3 * hc); prev = R(16 + 3 * hc); }
+                    a[2] += R(23) - prev;
+                    a[4] += R(4) - R(23);
                 }
-                for (int j = 0; j < 4; j++) ff[j].push_back(a[j] * 0.01 / 8);
+                for (int j = 0; j < 5; j++) ff[j].push_back(a[j] * 0.01 / 8);
             }
             { const unsigned long long seq[8] = {rt[2], rt[6], rt[7], rt[8], rt[9], rt[10], rt[11], rt[3]};
               for (int p = 0; p < 7; p++) ln[p].push_back(((double)seq[p + 1] - (double)seq[p]) * 0.01); }
@@ -76,8 +77,8 @@ int main(int argc, char** argv) {
                rep, ms * 1e3 / iters, iters, ghz.size(), med(ghz), med(tot), med(ph[0]), med(ph[1]), med(ph[2]), med(ph[3]), med(ph[4]));
         printf("        LN1: half 0: transpose + barrier %.2f, rows %.2f, barrier + read-back + barrier %.2f | half 1: %.2f, %.2f, %.2f | rest %.2f us\n",
                med(ln[0]), med(ln[1]), med(ln[2]), med(ln[3]), med(ln[4]), med(ln[5]), med(ln[6]));
-        printf("        FFN per wave (mean of 8): FFN1(0) + FFN2(3) %.2f, GELU(0) alone %.2f, 3 x [FFN1 + FFN2 with the next chunk's GELU inside] %.2f, barrier waits %.2f us\n",
-               med(ff[0]), med(ff[1]), med(ff[3]), med(ff[2]));
+        printf("        FFN per wave (mean of 8): 4 x FFN1 %.2f, GELU(0) alone %.2f, 3 x [FFN2 with the next chunk's GELU inside] %.2f, FFN2(3) + final barrier %.2f, waits on the arrival counters %.2f us\n",
+               med(ff[0]), med(ff[1]), med(ff[3]), med(ff[4]), med(ff[2]));
     }
     return 0;
 }

@@ -6,5 +6,5 @@ tail -3 gpurun_out/r3_parity.log
 [ $rc -eq 0 ] || exit $rc
 P=diffusion-based-motion-style-transfer_amd/csrc/probes/bin
 timeout -k 10 120 $P/tail_clock > gpurun_out/r3_tail_clock.txt 2>&1 || exit 1
-tail -3 gpurun_out/r3_tail_clock.txt
+tail -3 gpurun_out/r3_tail_clock.txt | cut -c1-400
 bash tools/lib_ab.sh ${1:-lib_r2.so} default | head -4
