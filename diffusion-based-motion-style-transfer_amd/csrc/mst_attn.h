@@ -23,6 +23,15 @@ __device__ __forceinline__ int k_off(int row, int ch) { return row * 256 + ((ch 
 // V image: 256-B rows cut into four 64-B pieces (one 32-wide d tile each); piece p of key `key`
 // at piece p ^ (key & 3): the 4 keys x 64 B a half-wave's transposed read touches cover all 64 banks.
 __device__ __forceinline__ int v_off(int key, int d) { return key * 256 + ((((d >> 5) ^ (key & 3))) << 6) + ((d & 31) << 1); }
+// The same image for a writer that stores 8 bytes (4 consecutive d) per lane with 16 consecutive keys per store group -- the fused
+// QKV + attention kernel's accumulators.  In v_off those 16 rows meet on two bank pairs (8-way: the round-2 PMC profile's
+// SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 18 % was exactly these 16 + 16 stores per wave); here the 8-byte slot inside the
+// 64-byte piece is rotated by (key >> 1) & 7 as well, which puts the 16 rows on 16 different bank pairs.  A half-wave's
+// transposed read takes the WHOLE piece of each of its four keys, so any per-key permutation of a piece's slots leaves it
+// conflict-free.
+__device__ __forceinline__ int v_off8(int key, int d) {
+    return key * 256 + ((((d >> 5) ^ (key & 3))) << 6) + (((((d & 31) >> 2) ^ ((key >> 1) & 7))) << 3) + ((d & 3) << 1);
+}
 
 // qsplit = 1: grid.y = NKT and the workgroup computes only query tile blockIdx.y (small batches: rows * 4 workgroups
 // would leave the chip idle; re-staging K and V seven times is cheap when only a few clips run).
@@ -447,7 +456,7 @@ __global__ __launch_bounds__(512) void k_qkv_attention(const f16* __restrict__ h
                 if (8 + n < nfeat) {                            // balanced roles: d = 32..127 of token tiles 4..6 comes from wave 7
                     uint2 vv = pack4_f16(acc[8 + n][4 * g] + b2[0], acc[8 + n][4 * g + 1] + b2[1], acc[8 + n][4 * g + 2] + b2[2], acc[8 + n][4 * g + 3] + b2[3]);
                     if (tok >= S) vv = make_uint2(0u, 0u);
-                    *reinterpret_cast<uint2*>(vs_img + v_off(tok, d)) = vv;
+                    *reinterpret_cast<uint2*>(vs_img + v_off8(tok, d)) = vv;
                 }
             }
     } else if (BAL && wave == 7) {
@@ -464,7 +473,7 @@ __global__ __launch_bounds__(512) void k_qkv_attention(const f16* __restrict__ h
                     uint2 vv = pack4_f16(acc[3 * j + i][4 * g] + b2[0], acc[3 * j + i][4 * g + 1] + b2[1], acc[3 * j + i][4 * g + 2] + b2[2],
                                          acc[3 * j + i][4 * g + 3] + b2[3]);
                     if (tk >= S) vv = make_uint2(0u, 0u);
-                    *reinterpret_cast<uint2*>(vs_img + v_off(tk, d)) = vv;
+                    *reinterpret_cast<uint2*>(vs_img + v_off8(tk, d)) = vv;
                 }
         }
     }
@@ -541,8 +550,8 @@ __global__ __launch_bounds__(512) void k_qkv_attention(const f16* __restrict__ h
             for (int s2 = 0; s2 < 2; s2++) {
                 int key = kt * 32 + 16 * s2 + key_lane;
                 int d = dt * 32 + d_lane;
-                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vs_img + v_off(key, d)));
-                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vs_img + v_off(key + 8, d)));
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vs_img + v_off8(key, d)));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vs_img + v_off8(key + 8, d)));
                 const f16x4 lo_h = __builtin_bit_cast(f16x4, lo), hi_h = __builtin_bit_cast(f16x4, hi);
                 f16x8 vf = __builtin_shufflevector(lo_h, hi_h, 0, 1, 2, 3, 4, 5, 6, 7);
                 o = mfma_f16(vf, pf[kt][s2], o);

@@ -38,15 +38,28 @@ def main():
     spill = sum(1 for l in lines[start:end] if "scratch_" in l)
     agpr = sum(1 for l in lines[start:end] if "v_accvgpr" in l)
     labels = {lines[i].split(":")[0]: i for i in range(start, end) if re.match(r"^\.LBB\w+:", lines[i])}
+    def is_stream_line(l):
+        t = l.split(";")[0].strip()
+        if not t.startswith("global_load_dwordx4"):
+            return False
+        ops = [o.strip() for o in t[len("global_load_dwordx4"):].split(",")]
+        return len(ops) >= 3 and ops[2].split()[0].startswith("s[")
+    last_stream = max((i for i in range(start, end) if is_stream_line(lines[i])), default=start)
     work = [(start, ())]
     visited = set()
     leftover = set()
     while work:
+        if len(visited) > 200000:
+            print("state space too large (more than 200000 (block, queue) states): audit incomplete")
+            return 2
         i, fifo_t = work.pop()
         fifo = list(fifo_t)
         while i < end:
             l = lines[i].split(";")[0].strip()
             i += 1
+            if i > last_stream + 1 and not any(fifo):     # past the last stream load with none in flight: nothing left to check on this path
+                leftover.add(len(fifo))
+                break
             if not l or l.endswith(":") or l.startswith("."):
                 if l.endswith(":"):                       # block entry: memoise on (pc, queue)
                     key = (i, tuple(fifo))
