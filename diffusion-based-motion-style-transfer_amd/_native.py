@@ -45,7 +45,7 @@ SIGNATURES = {
     "mst_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                               C.c_void_p, C.c_void_p]),
     "mst_sample_loop": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(MstLoopArgs), C.c_void_p]),
-    "mst_loop_slices": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "mst_loop_slices": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "mst_q_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
                                C.c_void_p, C.c_void_p]),
     "mst_step_epilogue": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -87,6 +87,11 @@ SIGNATURES = {
 }
 
 
+# The one compile recipe.  No -D but the source hash is ever passed: the kernels' tunables are constants in the sources, and the
+# diagnostic hooks (phase stamps) exist only in the probes under csrc/probes/, which define MST_PROBE_BUILD themselves.
+HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC")
+
+
 def source_files():
     """Everything the library is compiled from: csrc/*.hip, csrc/*.h and the public header."""
     import glob
@@ -96,8 +101,10 @@ def source_files():
 
 
 def source_hash():
+    """Hash of the sources AND of the compile flags: a library built with other flags is stale, not silently different."""
     import hashlib
     h = hashlib.sha256()
+    h.update(" ".join(HIPCC_FLAGS).encode() + b"\0")
     for f in source_files():
         h.update(os.path.basename(f).encode() + b"\0")
         with open(f, "rb") as fh:
@@ -141,10 +148,16 @@ def lib():
     return _lib
 
 
-def build_in_place(check=False):
+def build_in_place(check=False, force=False):
     """Compile the library with hipcc where it belongs (the one build recipe: __graft_entry__.build() calls this too).
-    The source hash is compiled in (mst_source_hash) and written beside the .so, so a library that is older than an edit
-    of ANY csrc/ file is rebuilt instead of silently used."""
+    The source hash (sources + flags) is compiled in (mst_source_hash) and written beside the .so, so a library that is older
+    than an edit of ANY csrc/ file is rebuilt instead of silently used.
+
+    Safe when several ranks import the package at once (bench.py --gpus N, torchrun): the build runs under an exclusive lock on
+    LIB_PATH + '.lock', staleness is re-checked once the lock is held (the winner's library is then simply used), the compiler
+    writes to a temporary file that is renamed over the library, and an existing library is never deleted -- a rank whose own
+    compile fails reports it (check=True) or leaves whatever is there (check=False) for lib() to judge by its hash."""
+    import fcntl
     import shutil
     import subprocess
     hipcc = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -152,18 +165,29 @@ def build_in_place(check=False):
         if check:
             raise RuntimeError("hipcc not found")
         return
-    h = source_hash()
-    try:
-        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", f'-DMST_SRC_HASH="{h}"',
-                        "-o", LIB_PATH, "mst_engine.hip"], cwd=os.path.join(_HERE, "csrc"), check=True)
-        with open(LIB_PATH + ".srchash", "w") as fh:
-            fh.write(h + "\n")
-    except (subprocess.CalledProcessError, OSError):
-        for f in (LIB_PATH, LIB_PATH + ".srchash"):
-            if os.path.exists(f):
-                os.remove(f)
-        if check:
-            raise
+    if any("MST_PROBE_BUILD" in f for f in HIPCC_FLAGS):
+        raise RuntimeError("MST_PROBE_BUILD is for csrc/probes/ only: the product library is never built with diagnostic hooks")
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not is_stale():
+                return                                  # another process built it while we waited
+            h = source_hash()
+            tmp = f"{LIB_PATH}.tmp.{os.getpid()}"
+            try:
+                subprocess.run([hipcc, *HIPCC_FLAGS, f'-DMST_SRC_HASH="{h}"', "-o", tmp, "mst_engine.hip"],
+                               cwd=os.path.join(_HERE, "csrc"), check=True)
+                os.replace(tmp, LIB_PATH)
+                with open(LIB_PATH + ".srchash.tmp", "w") as fh:
+                    fh.write(h + "\n")
+                os.replace(LIB_PATH + ".srchash.tmp", LIB_PATH + ".srchash")
+            except (subprocess.CalledProcessError, OSError):
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+                if check:
+                    raise
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 def check(rc):

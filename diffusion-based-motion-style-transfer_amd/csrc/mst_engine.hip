@@ -23,30 +23,16 @@
 using namespace mst;
 
 // wide (QKV / FFN1) tile: WIDE_BT tokens x 256 features, 8 waves of (WIDE_BT/64) x 2 MFMA tiles
-#ifndef WIDE_BT
 #define WIDE_BT 128   // same-box A/B (tools/ab.sh): 128/3-slot/XCD 52.4 clips/s, 128/4-slot 47.2, 256/4-slot 47.5
-#endif
-#ifndef WIDE_NS
 #define WIDE_NS 3     // 3 x 24 KB ring: two blocks share a CU
-#endif
-// ablation builds only (tools/ab.sh): ABL_LN == 2 shortens the LN GEMMs' K loop to 3 slabs
-#if defined(ABL_LN) && ABL_LN == 2
-#define ABL_K(k) 96
-#else
-#define ABL_K(k) (k)
-#endif
-#ifndef FFN1_BF
 #define FFN1_BF 256   // same-box A/B: 128x512 tiles (one 8-wave block per CU) 40 us vs 35 us for two co-resident 128x256 blocks
-#endif
-#ifndef WIDE_XCD
 #define WIDE_XCD 1
 // LayerNorm GEMMs (64 x 512 tiles, one block per CU): slab depth / ring slots.  64-deep slabs move whole
 // 128-B cache lines per DMA segment; 32-deep slabs fetch every line twice, one slab apart (gemm_bench: 24.3 -> 19.5 us at K=512).
-#ifndef LN_BK
 #define LN_BK 64
-#endif
 #define LN_NS (LN_BK == 64 ? 2 : 4)
-#endif
+// (These are fixed constants, not -D knobs: a stray compile flag must not be able to change what the product library computes or how
+// fast -- _native.build_in_place passes no -D but the source hash, and folds its flag list into that hash.)
 // launch geometry of a wide GEMM over nx token tiles x ny feature tiles (1-D when XCD-aware)
 static dim3 wide_grid(int M, int ny) {
     const int nx = (M + WIDE_BT - 1) / WIDE_BT;
@@ -54,9 +40,7 @@ static dim3 wide_grid(int M, int ny) {
 }
 
 // dgrad GEMMs that end in the fp32 gradient stream (N = 512): token tile
-#ifndef DG_BT
 #define DG_BT 128     // same-box A/B of the backward pass at batch 64: 128 x 256 tiles 2.99 ms, 64 x 256 (394 blocks, two per CU) 3.10 ms
-#endif
 static dim3 dg_grid(int M, int ny) {
     const int nx = (M + DG_BT - 1) / DG_BT;
     return WIDE_XCD ? dim3(((nx + 7) / 8) * 8 * ny, 1, 1) : dim3(nx, ny, 1);
@@ -583,9 +567,7 @@ static int launch_gemm_dma(dim3 grid, const SRC& xs, const f16* W, int ldw, int 
 // Wide (128 x 256) GEMM launch.  Few token rows = few workgroups, each walking the whole K loop alone: the loop is then
 // bound by the DMA round trip per slab, not by bandwidth, so small launches use 64-deep slabs (half as many round trips,
 // one workgroup per CU is plenty); large launches keep 32-deep slabs and two co-resident workgroups per CU.
-#ifndef SMALL_M
 #define SMALL_M 2048
-#endif
 template <class SRC, class EPI>
 static int launch_wide(int M, int ny, const SRC& xs, const f16* W, int ldw, int K, const EPI& epi, hipStream_t st) {
     if (M <= SMALL_M && (K % 64) == 0 && K >= 128)
@@ -807,9 +789,9 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
             ProfScope ps(e, FAM_OUTPROJ_LN, st);
             DEpiResidLN epi{w.b_out, w.g1, w.be1, ws.hx, ws.hl, M};
             if (M >= e->ln128_min_m)
-                CHECK((launch_gemm_dma<128, 512, 2, 4, 2, 1, 64>(dim3((M + 127) / 128, 1), RowsDirect{ws.att, MST_D}, w.w_out, MST_D, ABL_K(MST_D), epi, st)));
+                CHECK((launch_gemm_dma<128, 512, 2, 4, 2, 1, 64>(dim3((M + 127) / 128, 1), RowsDirect{ws.att, MST_D}, w.w_out, MST_D, MST_D, epi, st)));
             else
-                CHECK((launch_gemm_dma<64, 512, 2, 2, LN_NS, 1, LN_BK>(dim3((M + 63) / 64, 1), RowsDirect{ws.att, MST_D}, w.w_out, MST_D, ABL_K(MST_D), epi, st)));
+                CHECK((launch_gemm_dma<64, 512, 2, 2, LN_NS, 1, LN_BK>(dim3((M + 63) / 64, 1), RowsDirect{ws.att, MST_D}, w.w_out, MST_D, MST_D, epi, st)));
         }
         DBG_STOP(3)
         {
@@ -827,9 +809,9 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
             ProfScope ps(e, FAM_FFN2_LN, st);
             DEpiResidLN epi{w.b2, w.g2, w.be2, ws.hx, ws.hl, M};
             if (M >= e->ln128_min_m)
-                CHECK((launch_gemm_dma<128, 512, 2, 4, 2, 1, 64>(dim3((M + 127) / 128, 1), RowsDirect{ws.hid, MST_FF}, w.w2, MST_FF, ABL_K(MST_FF), epi, st)));
+                CHECK((launch_gemm_dma<128, 512, 2, 4, 2, 1, 64>(dim3((M + 127) / 128, 1), RowsDirect{ws.hid, MST_FF}, w.w2, MST_FF, MST_FF, epi, st)));
             else
-                CHECK((launch_gemm_dma<64, 512, 2, 2, LN_NS, 1, LN_BK>(dim3((M + 63) / 64, 1), RowsDirect{ws.hid, MST_FF}, w.w2, MST_FF, ABL_K(MST_FF), epi, st)));
+                CHECK((launch_gemm_dma<64, 512, 2, 2, LN_NS, 1, LN_BK>(dim3((M + 63) / 64, 1), RowsDirect{ws.hid, MST_FF}, w.w2, MST_FF, MST_FF, epi, st)));
         }
         DBG_STOP(5)
     }
@@ -918,8 +900,8 @@ static int loop_slices_for(const mst_engine* e, int batch, int cfg, int frames) 
     while (n > 1 && rows / n < 8) n--;                       // at least 8 rows through the transformer per slice
     return n;
 }
-extern "C" int mst_loop_slices(const mst_engine* e, int32_t batch, int32_t cfg) {
-    return loop_slices_for(e, batch, cfg, e ? e->cfg.max_frames : 0);
+extern "C" int mst_loop_slices(const mst_engine* e, int32_t batch, int32_t cfg, int32_t frames) {
+    return loop_slices_for(e, batch, cfg, frames > 0 ? frames : (e ? e->cfg.max_frames : 0));
 }
 
 // One denoise step of every slice, enqueued (or captured): slice sl on streams[sl]; step = *ld.jbase + joff.

@@ -343,14 +343,6 @@ struct DEpiResidLN {
     __device__ __forceinline__ void run_map(f32x16 (&acc)[1][MT][NT], const LM& lc, int tok0, char* smem) const {
         const f16* const rh = rhi ? rhi : hi;
         const f16* const rl = rlo ? rlo : lo;
-#if defined(ABL_LN) && ABL_LN == 1      // ablation build: no epilogue (keep the accumulators alive)
-        {
-            float keep = 0.f;
-            for (int m = 0; m < MT; m++) for (int n = 0; n < NT; n++) for (int r = 0; r < 16; r++) keep += acc[0][m][n][r];
-            if (keep == 123.456f) hi[0] = (f16)keep;
-            return;
-        }
-#endif
         constexpr int LD = MST_D * 4 + 16;                    // 2064-B rows: conflict-free b128 writes and reads
         constexpr int PR = 64, PASSES = BT / PR;              // 128-token tiles (large launches) go through LDS in two halves
         const int tok0_tile = tok0;

@@ -6,8 +6,9 @@
 #include <algorithm>
 #include <cstdio>
 #include <vector>
-#define QA_STAMP
+#define MST_PROBE_BUILD
 __device__ unsigned long long g_qa_stamp[1024][10];
+#define QA_MARK(i) if (threadIdx.x == 0) { g_qa_stamp[blockIdx.x][2 * (i)] = __builtin_amdgcn_s_memtime(); g_qa_stamp[blockIdx.x][2 * (i) + 1] = __builtin_amdgcn_s_memrealtime(); }
 #ifndef ATTN_HEADER
 #define ATTN_HEADER "../mst_attn.h"
 #endif

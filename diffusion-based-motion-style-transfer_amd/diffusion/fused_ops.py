@@ -71,8 +71,9 @@ class MaskedL2Fn(torch.autograd.Function):
         a_c, a_stride = _rows(a, n, F * one * T, "masked_l2 a")
         m_c, m_stride = _rows(mask.float() if mask.dtype != torch.float32 else mask, n, T, "masked_l2 mask")
         loss = torch.empty(n, dtype=torch.float32, device=b.device)
-        N.check(N.lib().mst_masked_l2(N.ptr(a_c), a_stride, N.ptr(b_c), N.ptr(m_c), m_stride, n, F * one, T, None, N.ptr(loss),
-                                      N.stream_ptr(b.device)))
+        with torch.cuda.device(b.device):      # the entry point launches on the current device (no device argument in the ABI)
+            N.check(N.lib().mst_masked_l2(N.ptr(a_c), a_stride, N.ptr(b_c), N.ptr(m_c), m_stride, n, F * one, T, None, N.ptr(loss),
+                                          N.stream_ptr(b.device)))
         ctx.save_for_backward(a_c, b_c, m_c)
         ctx.meta = (a_stride, m_stride, n, F * one, T, a.shape, a.requires_grad)
         return loss
@@ -83,8 +84,9 @@ class MaskedL2Fn(torch.autograd.Function):
         a_stride, m_stride, n, F, T, a_shape, a_needs = ctx.meta
         d_b = torch.empty_like(b_c)
         g = _cuda_f32(g.contiguous(), "masked_l2 grad")
-        N.check(N.lib().mst_masked_l2(N.ptr(a_c), a_stride, N.ptr(b_c), N.ptr(m_c), m_stride, n, F, T, N.ptr(g), N.ptr(d_b),
-                                      N.stream_ptr(d_b.device)))
+        with torch.cuda.device(d_b.device):
+            N.check(N.lib().mst_masked_l2(N.ptr(a_c), a_stride, N.ptr(b_c), N.ptr(m_c), m_stride, n, F, T, N.ptr(g), N.ptr(d_b),
+                                          N.stream_ptr(d_b.device)))
         d_a = None
         if ctx.needs_input_grad[0]:
             d_a = -d_b if a_stride else (-d_b).sum(0, keepdim=True).expand(a_shape)
@@ -97,7 +99,8 @@ class TextCosineFn(torch.autograd.Function):
         f_c, m_c = _cuda_f32(f.contiguous(), "text_features"), _cuda_f32(m.contiguous(), "mu")
         B, D = m_c.shape
         out = torch.empty(1, dtype=torch.float32, device=m.device)
-        N.check(N.lib().mst_text_cosine(N.ptr(f_c), N.ptr(m_c), B, D, None, N.ptr(out), N.stream_ptr(m.device)))
+        with torch.cuda.device(m.device):
+            N.check(N.lib().mst_text_cosine(N.ptr(f_c), N.ptr(m_c), B, D, None, N.ptr(out), N.stream_ptr(m.device)))
         ctx.save_for_backward(f_c, m_c)
         return out[0]
 
@@ -109,5 +112,6 @@ class TextCosineFn(torch.autograd.Function):
         B, D = m_c.shape
         d_m = torch.empty_like(m_c)
         gg = _cuda_f32(g.reshape(1).contiguous(), "grad")
-        N.check(N.lib().mst_text_cosine(N.ptr(f_c), N.ptr(m_c), B, D, N.ptr(gg), N.ptr(d_m), N.stream_ptr(d_m.device)))
+        with torch.cuda.device(d_m.device):
+            N.check(N.lib().mst_text_cosine(N.ptr(f_c), N.ptr(m_c), B, D, N.ptr(gg), N.ptr(d_m), N.stream_ptr(d_m.device)))
         return None, d_m

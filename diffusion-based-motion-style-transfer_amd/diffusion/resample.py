@@ -1,44 +1,42 @@
-"""Timestep samplers of the training loop (reference `diffusion/resample.py:8-73`).  The loop hard-codes
-'uniform' (train/training_loop.py:92-94); `sample` keeps the reference's np.random call pattern, so a seeded
-run draws the same indices."""
+"""Timestep sampler of the fine-tune loop: the counterpart of the reference's `diffusion/resample.py` for the one sampler the
+scripts create ('uniform', train/training_loop.py:92-94).
+
+What has to match the reference is observable behaviour, not text: for a seeded numpy global RNG, `sample` must consume the
+generator exactly as the reference does (ONE `np.random.choice` call with a probability vector: resample.py:52-59) so that a
+seeded fine-tune run visits the same timesteps, and the importance weights of a uniform draw are all 1.
+"""
 import numpy as np
-import torch as th
+import torch
+
+
+class UniformSampler:
+    """Uniform timesteps over the whole process, or over the loop's restricted `data_range` (the first
+    (1000 - skip_steps) / 1000 * 20 indices of the respaced process, training_loop.py:241-242)."""
+
+    def __init__(self, diffusion):
+        self.diffusion = diffusion
+        self.n = int(diffusion.num_timesteps)
+
+    def weights(self):
+        return np.ones([self.n])
+
+    def sample(self, batch_size, device, data_range=None):
+        support = np.arange(self.n) if data_range is None else np.asarray(data_range)
+        k = len(support)
+        # same generator consumption as the reference: choice(population, size, p) with p = 1/k each
+        # (np.ones / sum, as there, so that the probabilities are the same doubles bit for bit)
+        prob = np.ones([k]) / np.sum(np.ones([k]))
+        drawn = np.random.choice(len(prob) if data_range is None else data_range, size=(batch_size,), p=prob)
+        steps = torch.from_numpy(np.asarray(drawn)).long().to(device)
+        # importance weight 1 / (k p) = 1 for every draw of a uniform sampler
+        return steps, torch.ones(batch_size, dtype=torch.float32, device=device)
+
+
+class LossAwareSampler:
+    """Never instantiated by the scripts; the loop only asks `isinstance(sampler, LossAwareSampler)` (training_loop.py:263)."""
 
 
 def create_named_schedule_sampler(name, diffusion):
-    if name == "uniform":
-        return UniformSampler(diffusion)
-    raise NotImplementedError(f"unknown schedule sampler: {name}")      # 'loss-second-moment' is never created by the scripts
-
-
-class ScheduleSampler:
-    def weights(self):
-        raise NotImplementedError
-
-    def sample(self, batch_size, device, data_range=None):
-        """(:42-63) indices ~ weights (restricted to `data_range` when given), and the importance weights."""
-        w = self.weights()
-        p = w / np.sum(w)
-        if data_range is None:
-            indices_np = np.random.choice(len(p), size=(batch_size,), p=p)
-        else:
-            w_1 = self.weights()[data_range]
-            p = w_1 / np.sum(w_1)
-            indices_np = np.random.choice(data_range, size=(batch_size,), p=p)
-        indices = th.from_numpy(indices_np).long().to(device)
-        weights_np = 1 / (len(p) * p[indices_np])
-        weights = th.from_numpy(weights_np).float().to(device)
-        return indices, weights
-
-
-class UniformSampler(ScheduleSampler):
-    def __init__(self, diffusion):
-        self.diffusion = diffusion
-        self._weights = np.ones([diffusion.num_timesteps])
-
-    def weights(self):
-        return self._weights
-
-
-class LossAwareSampler(ScheduleSampler):
-    """Marker base class (the loop's isinstance check, training_loop.py:263); no instance is ever created."""
+    if name != "uniform":
+        raise NotImplementedError(f"unknown schedule sampler: {name}")      # 'loss-second-moment' is never created by the scripts
+    return UniformSampler(diffusion)

@@ -303,9 +303,10 @@ class DenoiserEngine:
         self._loop_keepalive = keep
         return (x, dump) if dump_xstart else x
 
-    def loop_slices(self, batch, cfg=False):
-        """How many independent clip slices sample_loop runs concurrently for this batch (1 or 2)."""
-        return int(N.lib().mst_loop_slices(self.handle, int(batch), int(bool(cfg))))
+    def loop_slices(self, batch, cfg=False, frames=None):
+        """How many independent clip slices sample_loop runs concurrently for this batch (1..3) of `frames`-frame clips
+        (default: the engine's frame cap)."""
+        return int(N.lib().mst_loop_slices(self.handle, int(batch), int(bool(cfg)), int(frames or 0)))
 
     def philox_normal(self, batch, frames, seed, step):
         out = torch.empty((batch, self.feats, 1, frames), dtype=torch.float32, device=self.device)

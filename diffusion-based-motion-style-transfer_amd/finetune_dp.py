@@ -69,6 +69,12 @@ class LayerBucketReducer:
             model.__dict__["_native_layer_ready"] = self._native_layer_ready
             model.__dict__["_native_grads_ready"] = self._native_grads_ready
 
+    # The exchange of a bucket starts while the backward pass is still running and the kernels add straight into the bucket: a
+    # second backward before zero_grad() (gradient accumulation, two losses) would add into memory the collective is reading or has
+    # already reduced, and the ranks would silently diverge.  One backward per iteration is the protocol; anything else raises.
+    _TWICE = ("LayerBucketReducer: a second backward pass reached a bucket whose all-reduce was already launched; call "
+              "zero_grad() between backward passes (accumulate losses into ONE backward instead)")
+
     # ------------------------------------------------------------------------------ launching
     def _launch(self, b, where):
         b["launched"], b["pending"] = True, 0
@@ -80,6 +86,8 @@ class LayerBucketReducer:
     def _native_layer_ready(self, eng):
         """Called by the LAST native node of a backward pass right after its backward call returned (GPU work enqueued, not
         finished): start every layer's exchange behind that layer's gradient event."""
+        if all(b["launched"] for b in self.buckets):
+            raise RuntimeError(self._TWICE)
         for b in self.buckets:
             if b["launched"]:
                 continue
@@ -96,6 +104,8 @@ class LayerBucketReducer:
 
     def _hook(self, bucket):
         def fire(_param):
+            if bucket["launched"]:
+                raise RuntimeError(self._TWICE)
             bucket["pending"] -= 1
             if bucket["pending"] == 0:
                 self._launch(bucket, "backward")

@@ -152,12 +152,13 @@ typedef struct mst_loop_args {
 int mst_sample_loop(mst_engine* e, const mst_schedule* s, const mst_loop_args* a, void* stream);
 
 /* Number of independent clip slices (1..3) mst_sample_loop runs on separate streams for this
- * batch at the engine's max_frames: clips never interact (no cross-sample op in
+ * batch of `frames`-frame clips (frames <= 0: the engine's max_frames; the policy depends on the
+ * token-row count, so pass the loop's own frame count when it is below the cap): clips never interact (no cross-sample op in
  * mdm_forstyledataset.py:602-625), so slices overlap each other's launch gaps, prologues and
  * tails.  Chosen per call from the tile count (one slice when every tile of the batch is
  * resident at once, up to three beyond that and on the small-tile path); MST_STREAMS=1..3 in
  * the environment at engine creation fixes it.  Per-launch work = batch / slices clips. */
-int mst_loop_slices(const mst_engine* e, int32_t batch, int32_t cfg);
+int mst_loop_slices(const mst_engine* e, int32_t batch, int32_t cfg, int32_t frames);
 
 /* -------------------------------------------------------------------------------------------
  * stand-alone elementwise kernels for callers that bring their own model callable
