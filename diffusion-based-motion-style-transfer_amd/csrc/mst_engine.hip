@@ -134,6 +134,8 @@ struct TrainWS {
     hipEvent_t ev_layer[16] = {nullptr};                // recorded when layer l's parameter gradients of the LAST backward call are enqueued
     bool layer_done[16] = {false};
     float* part = nullptr;                              // split-K partial products
+    float* ln_part = nullptr;                           // k_ln_bwd's per-block [dgamma | dbeta | dbias] partials (dgrad stream)
+    float* cs_part = nullptr;                           // k_colsum_f16's per-row-block bias-gradient partials (wgrad stream)
     float* zeros = nullptr;                             // zero bias
     float* gscale = nullptr;                            // [0] scale applied to the incoming gradient, [1] its inverse
     unsigned* amax = nullptr;
@@ -347,7 +349,7 @@ extern "C" void mst_engine_destroy(mst_engine* e) {
     {
         TrainWS& t = e->tw;
         void* p[] = {t.g0, t.g1, t.dbr2[0], t.dbr2[1], t.dbr1[0], t.dbr1[1], t.dpre[0], t.dpre[1], t.dqkv[0], t.dqkv[1],
-                     t.datt, t.part, t.zeros, t.gscale, t.amax};
+                     t.datt, t.part, t.zeros, t.gscale, t.amax, t.ln_part, t.cs_part};
         if (t.ev_ready) (void)hipEventDestroy(t.ev_ready);
         for (int i = 0; i < 16; i++) if (t.ev_layer[i]) (void)hipEventDestroy(t.ev_layer[i]);
         for (int i = 0; i < 2; i++) if (t.ev_side[i]) (void)hipEventDestroy(t.ev_side[i]);
@@ -1351,6 +1353,8 @@ static int train_ws(mst_engine* e) {
     for (int i = 0; i < 16; i++) HIPCHECK(hipEventCreateWithFlags(&t.ev_layer[i], hipEventDisableTiming));
     CHECK(dmalloc(&t.datt, Mp * MST_D));
     CHECK(dmalloc(&t.part, t.split_cap * (size_t)3 * MST_D * MST_D));
+    CHECK(dmalloc(&t.ln_part, (size_t)512 * 3 * MST_D));
+    CHECK(dmalloc(&t.cs_part, (Mp / 128 + 2) * (size_t)3 * MST_D));
     CHECK(dmalloc(&t.zeros, 3 * MST_D + MST_D));          // zero bias [1536] + a 512-float dump for unwanted reductions
     CHECK(dmalloc(&t.gscale, 2));
     CHECK(dmalloc(&t.amax, 1));
@@ -1386,9 +1390,13 @@ static int wgrad(mst_engine* e, const f16* dY, int n_out, const f16* X, int k_in
         HIPCHECK(hipGetLastError());
     }
     if (db) {
-        const int rpb = 128;
-        hipLaunchKernelGGL(k_colsum_f16, dim3(n_out / 256, (M + rpb - 1) / rpb), dim3(256), 0, st, dY, n_out, M, rpb, t.gscale, db);
+        const int rpb = 128, nrb = (M + rpb - 1) / rpb;      // bias gradient: row-block partials, then an ordered sum (no float atomics)
+        hipLaunchKernelGGL(k_colsum_f16, dim3(n_out / 256, nrb), dim3(256), 0, st, dY, n_out, M, rpb, t.gscale, db, t.cs_part);
         HIPCHECK(hipGetLastError());
+        if (nrb > 1) {
+            hipLaunchKernelGGL(k_sum_partials, dim3((n_out + 255) / 256), dim3(256), 0, st, t.cs_part, nrb, n_out, t.gscale, db);
+            HIPCHECK(hipGetLastError());
+        }
     }
     return 0;
 }
@@ -1442,7 +1450,8 @@ static int train_stack_backward(mst_engine* e, const Tape& t, int rows, int S, f
         if (two && side_used[par]) HIPCHECK(hipStreamWaitEvent(st, w_.ev_side[par], 0));
         // LayerNorm2 backward: gB -> dz2 (gA, fp32) and the branch gradient dbr2 (f16); dgamma2, dbeta2, db2
         hipLaunchKernelGGL(k_ln_bwd, dim3(ln_blocks), dim3(256), 0, st, gB, a.z2h, a.z2l, w.g2, M, make_drop(seed, l, 3, p_drop), w_.gscale,
-                           gA, dbr2, G[10], G[11], G[7]);
+                           gA, dbr2, w_.ln_part);
+        if (wg) hipLaunchKernelGGL(k_ln_bwd_finish, dim3(6), dim3(256), 0, st, w_.ln_part, ln_blocks, w_.gscale, G[10], G[11], G[7]);
         HIPCHECK(hipGetLastError());
         TO_SIDE()
         if (wg) CHECK(wgrad(e, dbr2, MST_D, a.hid, MST_FF, M, G[6], nullptr, sw));                 // dW2 += dbr2^T hid
@@ -1462,7 +1471,8 @@ static int train_stack_backward(mst_engine* e, const Tape& t, int rows, int S, f
         }
         // LayerNorm1 backward: gB -> dz1 (gA), dbr1 = d(out-proj output); dgamma1, dbeta1, db_out
         hipLaunchKernelGGL(k_ln_bwd, dim3(ln_blocks), dim3(256), 0, st, gB, a.z1h, a.z1l, w.g1, M, make_drop(seed, l, 1, p_drop), w_.gscale,
-                           gA, dbr1, G[8], G[9], G[3]);
+                           gA, dbr1, w_.ln_part);
+        if (wg) hipLaunchKernelGGL(k_ln_bwd_finish, dim3(6), dim3(256), 0, st, w_.ln_part, ln_blocks, w_.gscale, G[8], G[9], G[3]);
         HIPCHECK(hipGetLastError());
         TO_SIDE()
         if (wg) CHECK(wgrad(e, dbr1, MST_D, a.att, MST_D, M, G[2], nullptr, sw));                  // dW_out += dbr1^T att
@@ -1704,7 +1714,7 @@ extern "C" int64_t mst_adamw_workspace_bytes(int32_t n_tensors, const int64_t* n
     if (n_tensors < 1 || !numel) return -1;
     int64_t chunks = 0;
     for (int i = 0; i < n_tensors; i++) chunks += (numel[i] + kAdamChunk - 1) / kAdamChunk;
-    return (int64_t)n_tensors * (int64_t)sizeof(AdamTensor) + chunks * (int64_t)sizeof(AdamChunk) + 256;
+    return (int64_t)n_tensors * (int64_t)sizeof(AdamTensor) + chunks * (int64_t)sizeof(AdamChunk) + 512 + chunks * 2 * (int64_t)sizeof(float);
 }
 
 extern "C" int mst_adamw_step(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
@@ -1741,9 +1751,16 @@ extern "C" int mst_adamw_step(int32_t n_tensors, float* const* params, const flo
     }
     const float bias1 = 1.0f - (float)pow((double)beta1, (double)step);
     const float bias2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    // grad / param norms: per-chunk partials behind the tables, summed in chunk order (no float atomics: the logged norms and
+    // anything derived from them are bit-reproducible)
+    float* norm_part = norms_dev ? (float*)(ws + tb_al + ((sizeof(AdamChunk) * nchunks + 255) / 256) * 256) : nullptr;
     hipLaunchKernelGGL(k_adamw_multi, dim3((unsigned)nchunks), dim3(256), 0, st, (const AdamTensor*)ws, (const AdamChunk*)(ws + tb_al),
-                       lr, beta1, beta2, eps, weight_decay, bias1, bias2_sqrt, norms_dev);
+                       lr, beta1, beta2, eps, weight_decay, bias1, bias2_sqrt, norm_part);
     HIPCHECK(hipGetLastError());
+    if (norms_dev) {
+        hipLaunchKernelGGL(k_adamw_norms, dim3(1), dim3(256), 0, st, norm_part, (int)nchunks, norms_dev);
+        HIPCHECK(hipGetLastError());
+    }
     return 0;
 }
 

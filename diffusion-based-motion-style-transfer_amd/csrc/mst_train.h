@@ -462,8 +462,7 @@ __global__ void k_scale_f32(const float* __restrict__ in, size_t n, const float*
 // One wave per row; lane owns features [4 lane, +4) and [256 + 4 lane, +4).
 __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ g, const f16* __restrict__ z_hi, const f16* __restrict__ z_lo,
                                                 const float* __restrict__ gamma, int M, Drop d, const float* __restrict__ gscale,
-                                                float* __restrict__ dz, f16* __restrict__ dbr,
-                                                float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias) {
+                                                float* __restrict__ dz, f16* __restrict__ dbr, float* __restrict__ part) {
     __shared__ float red[3][4][MST_D];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fa = lane * 4, fb = 256 + lane * 4;
@@ -534,50 +533,24 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ g, con
         red[2][wave][fa + i] = dca[i]; red[2][wave][fb + i] = dcb[i];
     }
     __syncthreads();
-    const float inv = gscale[1];
+    // per-block partial sums; k_ln_bwd_finish adds them up in block order (float atomics here made dgamma / dbeta / dbias differ in the
+    // last bits from run to run -- and between data-parallel replicas)
     for (int i = threadIdx.x; i < 3 * MST_D; i += 256) {
         const int a = i / MST_D, f = i - a * MST_D;
-        const float v = (red[a][0][f] + red[a][1][f] + red[a][2][f] + red[a][3][f]) * inv;
-        float* dst = a == 0 ? dgamma : (a == 1 ? dbeta : dbias);
-        atomicAdd(dst + f, v);
+        part[(size_t)blockIdx.x * (3 * MST_D) + i] = red[a][0][f] + red[a][1][f] + red[a][2][f] + red[a][3][f];
     }
 }
 
-// in [M][N] (row stride ld_in) f16 -> out [N][ld_out] f16 (token-contiguous rows, zero for tokens in [M, ld_out)):
-// the K-contiguous operands of the wgrad GEMMs.  colsum != null: colsum[n] += unscale * sum_rows in[row][n]
-// (bias gradients).  Block = 64 tokens x 64 features.
-__global__ __launch_bounds__(256) void k_transpose_f16(const f16* __restrict__ in, int ld_in, int M, f16* __restrict__ out, int ld_out,
-                                                       float* __restrict__ colsum, const float* __restrict__ gscale) {
-    __shared__ f16 tile[64][72];
-    __shared__ float cs[4][64];
-    const int t0 = blockIdx.x * 64, n0 = blockIdx.y * 64, tid = threadIdx.x;
-#pragma unroll
-    for (int q = tid; q < 512; q += 256) {
-        const int r = q >> 3, ch = q & 7;
-        uint4 v = {0, 0, 0, 0};
-        if (t0 + r < M) v = *reinterpret_cast<const uint4*>(in + (size_t)(t0 + r) * ld_in + n0 + ch * 8);
-        *reinterpret_cast<uint4*>(&tile[r][ch * 8]) = v;
-    }
-    __syncthreads();
-    if (colsum) {
-        const int c = tid & 63, part = tid >> 6;
-        float s = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; r++) s += (float)tile[part * 16 + r][c];
-        cs[part][c] = s;
-    }
-#pragma unroll
-    for (int q = tid; q < 512; q += 256) {
-        const int n = q >> 3, ch = q & 7;                   // feature row n, tokens 8 ch .. 8 ch + 7
-        f16x8 v;
-#pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = tile[ch * 8 + j][n];
-        *reinterpret_cast<uint4*>(out + (size_t)(n0 + n) * ld_out + t0 + ch * 8) = __builtin_bit_cast(uint4, v);
-    }
-    if (colsum) {
-        __syncthreads();
-        if (tid < 64) atomicAdd(colsum + n0 + tid, (cs[0][tid] + cs[1][tid] + cs[2][tid] + cs[3][tid]) * gscale[1]);
-    }
+// dgamma / dbeta / dbias += unscale * sum over the blocks of k_ln_bwd, in block order (deterministic)
+__global__ __launch_bounds__(256) void k_ln_bwd_finish(const float* __restrict__ part, int nblocks, const float* __restrict__ gscale,
+                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 3 * MST_D) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; b++) s += part[(size_t)b * (3 * MST_D) + i];
+    const int a = i / MST_D, f = i - a * MST_D;
+    float* dst = a == 0 ? dgamma : (a == 1 ? dbeta : dbias);
+    dst[f] += s * gscale[1];
 }
 
 // [N][K] float32 -> [K][N] f16 (transposed weight copies: the "weights" operand of the dgrad GEMMs)
@@ -1088,7 +1061,7 @@ __global__ __launch_bounds__(512) void k_wgrad_tr(const f16* __restrict__ dY, in
 // colsum[n] += unscale * sum_rows in[row][n]   (bias gradients of linear1 / in_proj); in: [M][N] f16, N % 256 == 0.
 // Block = 256 columns x rows_per_block rows: thread (cg, rl) sums 8 columns (16-byte loads) of every 8th row.
 __global__ __launch_bounds__(256) void k_colsum_f16(const f16* __restrict__ in, int N, int M, int rows_per_block,
-                                                    const float* __restrict__ gscale, float* __restrict__ colsum) {
+                                                    const float* __restrict__ gscale, float* __restrict__ colsum, float* __restrict__ part) {
     __shared__ float red[8][256];
     const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int c0 = blockIdx.x * 256 + cg * 8;
@@ -1107,7 +1080,19 @@ __global__ __launch_bounds__(256) void k_colsum_f16(const f16* __restrict__ in, 
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; i++) t += red[i][threadIdx.x];
-    atomicAdd(colsum + blockIdx.x * 256 + threadIdx.x, t * gscale[1]);
+    // one row block: the only writer of these columns adds straight in; several: partials, summed in order by k_sum_partials
+    if (gridDim.y == 1) colsum[blockIdx.x * 256 + threadIdx.x] += t * gscale[1];
+    else part[(size_t)blockIdx.y * N + blockIdx.x * 256 + threadIdx.x] = t;
+}
+
+// dst[i] += scale * sum_p part[p][i], p in order (the deterministic second stage of the bias-gradient and norm reductions)
+__global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ part, int nparts, int n, const float* __restrict__ gscale,
+                                                      float* __restrict__ dst) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; p++) s += part[(size_t)p * n + i];
+    dst[i] += gscale ? s * gscale[1] : s;
 }
 
 
@@ -1125,7 +1110,7 @@ constexpr int kAdamChunk = 65536;
 
 __global__ __launch_bounds__(256) void k_adamw_multi(const AdamTensor* __restrict__ tensors, const AdamChunk* __restrict__ chunks,
                                                      float lr, float beta1, float beta2, float eps, float wd,
-                                                     float bias1, float bias2_sqrt, float* __restrict__ norms) {
+                                                     float bias1, float bias2_sqrt, float* __restrict__ norm_part) {
     const AdamChunk ck = chunks[blockIdx.x];
     const AdamTensor t = tensors[ck.tensor];
     long long end = ck.start + kAdamChunk;
@@ -1154,9 +1139,23 @@ __global__ __launch_bounds__(256) void k_adamw_multi(const AdamTensor* __restric
     __shared__ float red[2][4];
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sg; red[1][threadIdx.x >> 6] = sp; }
     __syncthreads();
-    if (threadIdx.x == 0 && norms) {
-        atomicAdd(norms + 0, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-        atomicAdd(norms + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    if (threadIdx.x == 0 && norm_part) {                     // per-chunk partials; k_sum_partials adds them in chunk order
+        norm_part[blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        norm_part[gridDim.x + blockIdx.x] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+
+// norms[0..1] += sum over the chunks of k_adamw_multi's partials, in chunk order
+__global__ __launch_bounds__(256) void k_adamw_norms(const float* __restrict__ norm_part, int nchunks, float* __restrict__ norms) {
+    __shared__ float red[2][256];
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < nchunks; i += 256) { a += norm_part[i]; b += norm_part[nchunks + i]; }
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = b;
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        float s = 0.f;
+        for (int i = 0; i < 256; i++) s += red[threadIdx.x][i];
+        norms[threadIdx.x] += s;
     }
 }
 
