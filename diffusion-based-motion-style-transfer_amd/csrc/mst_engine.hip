@@ -161,6 +161,7 @@ struct mst_engine {
     // workspace
     f16* hl = nullptr;        // lo half of the stream (hx is the hi half)
     f16 *hx = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr, *xt = nullptr;
+    float* gelu_tab = nullptr;      // Phi(x) interpolation table of the fused layer tail's GELU stage (TailCfg::GELU_N entries {Phi, dPhi})
     f16* xt_lo = nullptr;     // lo half of the frame rows: the pose embedding multiplies x_t as hi + lo (RowsDirect::Xlo)
     float *temb_hid = nullptr, *temb = nullptr, *textproj = nullptr;
     int temb_cap = 0;
@@ -303,6 +304,17 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     CHECK(dmalloc(&e->hid, (size_t)e->M_pad * MST_FF));
     CHECK(dmalloc(&e->xt, ((size_t)c->max_rows * c->max_frames + 128) * e->kin_pad));
     CHECK(dmalloc(&e->xt_lo, ((size_t)c->max_rows * c->max_frames + 128) * e->kin_pad));
+    {   // Phi in double on the host: entry i = {Phi(x_i), Phi(x_i+1) - Phi(x_i)}, x_i = -6 + i / 128
+        std::vector<float> tab(TailCfg::GELU_TAB_BYTES / 4, 0.f);
+        auto phi = [](double x) { return 0.5 * std::erfc(-x * 0.70710678118654752440); };
+        for (int i = 0; i <= TailCfg::GELU_N; i++) {
+            const double x0 = -6.0 + i / 128.0, p0 = phi(x0), p1 = phi(x0 + 1.0 / 128.0);
+            tab[2 * i] = (float)p0;
+            tab[2 * i + 1] = (float)(p1 - p0);
+        }
+        CHECK(dmalloc(&e->gelu_tab, tab.size()));
+        HIPCHECK(hipMemcpy(e->gelu_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+    }
     e->temb_cap = c->max_rows > 1024 ? c->max_rows : 1024;
     CHECK(dmalloc(&e->temb_hid, (size_t)e->temb_cap * MST_D));
     CHECK(dmalloc(&e->temb, (size_t)e->temb_cap * MST_D));
@@ -356,7 +368,7 @@ extern "C" void mst_engine_destroy(mst_engine* e) {
         for (void* q : p) (void)hipFree(q);
     }
     void* p[] = {e->w_pose_in, e->b_pose_in, e->w_pose_out, e->b_pose_out, e->w_pose_inT, e->w_pose_outT, e->w_t0, e->b_t0, e->w_t2, e->b_t2,
-                 e->w_text, e->b_text, e->pe, e->hl, e->hx, e->qkv, e->att, e->hid, e->xt, e->xt_lo, e->temb_hid, e->temb, e->textproj, e->zacc};
+                 e->w_text, e->b_text, e->pe, e->hl, e->hx, e->qkv, e->att, e->hid, e->xt, e->xt_lo, e->gelu_tab, e->temb_hid, e->temb, e->textproj, e->zacc};
     for (void* q : p) (void)hipFree(q);
     for (int i = 0; i < mst_engine::MAX_SLICES - 1; i++) {
         if (e->aux_stream[i]) (void)hipStreamDestroy(e->aux_stream[i]);
@@ -674,11 +686,11 @@ static WS ws_slice(const mst_engine* e, int r0, int T) {
 }
 
 // K6 + K7 + K8 of one layer as one launch (mst_tail.h): one workgroup per 64-token tile
-static int launch_tail(const LayerW& w, const WS& ws, int M, hipStream_t st) {
+static int launch_tail(const mst_engine* e, const LayerW& w, const WS& ws, int M, hipStream_t st) {
     static_assert(TailCfg::SMEM <= 163840, "fused layer tail exceeds the 160 KiB LDS");
     CHECK(ensure_dyn_lds((const void*)k_layer_tail, TailCfg::SMEM));
     hipLaunchKernelGGL(k_layer_tail, dim3((M + TailCfg::BT - 1) / TailCfg::BT), dim3(512), TailCfg::SMEM, st, ws.att, w.wtail,
-                       w.b_out, w.g1, w.be1, w.b1, w.b2, w.g2, w.be2, ws.hx, ws.hl, M);
+                       w.b_out, w.g1, w.be1, w.b1, w.b2, w.g2, w.be2, ws.hx, ws.hl, e->gelu_tab, M);
     HIPCHECK(hipGetLastError());
     return 0;
 }
@@ -783,7 +795,7 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
         DBG_STOP(2)
         if (e->fuse_tail && !(e->dbg_layer == l && (e->dbg_stage == 3 || e->dbg_stage == 4))) {
             ProfScope ps(e, FAM_TAIL, st);
-            CHECK(launch_tail(w, ws, M, st));
+            CHECK(launch_tail(e, w, ws, M, st));
             DBG_STOP(5)
             continue;
         }

@@ -47,10 +47,14 @@ struct TailCfg {
     static constexpr int OFF_ATT = 0;                    // phase P: att image, 64 x 1 KB
     static constexpr int OFF_H = 0, HBUF = 32 * 1024;    // phase F: GELU output, 2 x (64 x 512 B)
     static constexpr int OFF_CNT = 68 * 1024;            // 4 arrival counters of the FFN chunks (above LN1's half-tile scratch, below OFF_B1)
+    // Phi(x) table of the GELU stage: entry i = {Phi(x_i), Phi(x_i+1) - Phi(x_i)}, x_i = -6 + i / 128, i < 1536 (+ one guard entry),
+    // padded to 13 KB = 13 LDS-DMA pieces.  Linear interpolation error <= h^2 / 8 max|Phi''| = 1.9e-6, far below the f16 store (2^-11).
+    static constexpr int GELU_N = 1536, GELU_TAB_BYTES = 13 * 1024;
+    static constexpr int OFF_TAB = 69 * 1024;
     static constexpr int OFF_B1 = 92 * 1024;             // FFN1 bias (4 KB), staged at kernel start
     static constexpr int OFF_X1 = 96 * 1024;             // LayerNorm1 output, 64 x 1 KB; LN1's half-tile scratch [0, 66 KB) stays below OFF_B1
     static constexpr int SMEM = 160 * 1024;
-    static_assert(32 * LN_LD <= OFF_CNT && OFF_CNT + 16 <= OFF_B1 && 64 * LN_LD <= SMEM && 2 * HBUF <= OFF_CNT, "LDS map");
+    static_assert(32 * LN_LD <= OFF_CNT && OFF_CNT + 16 <= OFF_TAB && OFF_TAB + GELU_TAB_BYTES <= OFF_B1 && 64 * LN_LD <= SMEM && 2 * HBUF <= OFF_CNT, "LDS map");
     static_assert(P_FRAG % D == 0 && F1_FRAG % D == 0 && F2_FRAG % D == 0, "every phase starts on prefetch slot 0");
     static_assert(F1_FRAG == 32 && F2_FRAG == 32, "k_pack_tail's unit arithmetic");
 };
@@ -97,6 +101,15 @@ template <int N> __device__ __forceinline__ void tail_wwait(u32x4& d) { asm vola
 __device__ __forceinline__ void tail_fence() { asm volatile("" ::: "memory"); }
 __device__ __forceinline__ void tail_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }   // LDS only: the stream stays in flight
 
+// GELU(x) = x Phi(x), Phi by linear interpolation in the LDS table (TailCfg::OFF_TAB): 7 VALU ops + one 8-byte LDS read per value
+// instead of the 12 ops + v_rcp + v_exp of gelu_erf.  The tail's FFN phase is bound by the SIMDs' VALU + MFMA issue slots
+// (128 GELU values per lane and tile), so the instruction count is what this buys.  |x| > 6: Phi is 0 / 1 to 1e-9.
+__device__ __forceinline__ float gelu_tab_lds(float x, const char* tab) {
+    const float u = __builtin_amdgcn_fmed3f(fmaf(x, 128.0f, 768.0f), 0.0f, 1535.9999f);
+    const float2 e = *reinterpret_cast<const float2*>(tab + ((unsigned)u << 3));
+    return x * fmaf(e.y, __builtin_amdgcn_fractf(u), e.x);
+}
+
 __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
 __device__ __forceinline__ void tail_glds1(unsigned voff, unsigned long long sbase, unsigned lds_dst) {
@@ -109,7 +122,7 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
                                                     const float* __restrict__ b_out, const float* __restrict__ g1, const float* __restrict__ be1,
                                                     const float* __restrict__ b1, const float* __restrict__ b2,
                                                     const float* __restrict__ g2, const float* __restrict__ be2,
-                                                    f16* __restrict__ hx, f16* __restrict__ hl, int M) {
+                                                    f16* __restrict__ hx, f16* __restrict__ hl, const float* __restrict__ gelu_tab, int M) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using C = TailCfg;
     constexpr int D = C::D;
@@ -124,13 +137,14 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
     //  (1) the att image: token row r of the tile = 1 KB, 16-B chunk c at c ^ (r & 15) (conflict-free ds_read_b128 of the 16x16x32 B
     //      operand: a 16-lane group reads 16 rows at chunks {c, c ^ 1} -> 16 distinct slots of the 256-B bank row).  LDS-DMA writes
     //      lane-linearly, so the swizzle is on the per-lane SOURCE address; wave w fills rows [8 w, 8 w + 8);
-    //  (2) the FFN1 bias (4 KB, waves 0..3): the GELU stage reads it from LDS;
+    //  (2) the FFN1 bias (4 KB, waves 0..3) and the GELU stage's Phi table (13 KB): both are read from LDS;
     //  (3) LayerNorm1's residual for the tile's first 32 tokens: stream rows hi -> [OFF_X1, +32 KB), lo -> [OFF_X1 + 32 KB, +32 KB), row-linear,
     //      wave w its own LN1 rows [4 w, 4 w + 4).  Requested after the out-proj loop instead, these rows cost ~3 us of exposed latency
     //      (the loads queue behind 128 KB of prefetched fragments and then miss L2); the second half's rows ARE requested there, into
     //      registers, and land while the first half is normalised.  The x1 image later overwrites the staging area row by row, each
     //      row by the wave that consumed it.
     float* b1s = reinterpret_cast<float*>(smem + C::OFF_B1);
+    const char* const gtab = smem + C::OFF_TAB;
     unsigned* const arrived = reinterpret_cast<unsigned*>(smem + C::OFF_CNT);      // [chunk]: waves whose GELU output of that chunk is in the H image
     if (tid < 4) arrived[tid] = 0;                                                  // published by the barrier in front of the out-proj loop
 #pragma unroll
@@ -142,6 +156,8 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
         tail_glds1(voff, (unsigned long long)att, __builtin_amdgcn_readfirstlane(smem_base + C::OFF_ATT + r * 1024));
     }
     if (wave < 4) tail_glds1((unsigned)lane * 16u, (unsigned long long)(b1 + 256 * wave), __builtin_amdgcn_readfirstlane(smem_base + C::OFF_B1 + 1024 * wave));
+    tail_glds1((unsigned)lane * 16u, (unsigned long long)(gelu_tab + 256 * wave), __builtin_amdgcn_readfirstlane(smem_base + C::OFF_TAB + 1024 * wave));
+    if (wave < 5) tail_glds1((unsigned)lane * 16u, (unsigned long long)(gelu_tab + 256 * (8 + wave)), __builtin_amdgcn_readfirstlane(smem_base + C::OFF_TAB + 1024 * (8 + wave)));
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         int tok = tok0 + 4 * wave + r;
@@ -371,7 +387,7 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
             const unsigned coff = (unsigned)(((4 * wave + 2 * rb + (q4 >> 1)) ^ t16) << 4) + 8u * (q4 & 1);
             const f32x4 v = acch[rb][tb];
             *reinterpret_cast<uint2*>(smem + C::OFF_H + (hc & 1) * C::HBUF + (16 * tb + t16) * 512 + coff) =
-                pack4_f16(gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3]));
+                pack4_f16(gelu_tab_lds(v[0], gtab), gelu_tab_lds(v[1], gtab), gelu_tab_lds(v[2], gtab), gelu_tab_lds(v[3], gtab));
         };
         auto announce = [&](int hc) {
             tail_fence();

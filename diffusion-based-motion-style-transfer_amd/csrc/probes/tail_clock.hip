@@ -38,7 +38,7 @@ int main(int argc, char** argv) {
         const int iters = rep == 0 ? 100 : 20000;
         hipEventRecord(e0);
         for (int i = 0; i < iters; i++)
-            hipLaunchKernelGGL(k_layer_tail, dim3(grid), dim3(512), C::SMEM, 0, att, wt, v, v, v, v, v, v, v, hx, hl, M);
+            hipLaunchKernelGGL(k_layer_tail, dim3(grid), dim3(512), C::SMEM, 0, att, wt, v, v, v, v, v, v, v, hx, hl, v, M);
         hipEventRecord(e1);
         if (hipEventSynchronize(e1) != hipSuccess) { printf("kernel failed: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
         float ms; hipEventElapsedTime(&ms, e0, e1);
