@@ -388,6 +388,40 @@ def cpu_baseline(w, pe, tab, tmap, B, F, T, NS, sample_steps, seed):
 
 
 # ---------------------------------------------------------------------------------------------- fine-tuning
+def finetune_flops(B):
+    """Algorithmic FLOPs of ONE fine-tune iteration on one rank: every pass of a clip through the trainable
+    denoiser is 7.353 GFLOP forward and twice that backward (dgrad + wgrad); the objective makes B + 6 such passes (the B-clip
+    text-to-motion call and the 6 chained single-clip steps); the frozen motion encoder sees the B clips once, forward (7.3 GFLOP)
+    and backward to its input only (dgrad, as much again)."""
+    return 3 * 7.353e9 * (B + 6) + 2 * 7.3e9 * B
+
+
+def finetune_roofline(B, world, s_per_iter):
+    """Whole-iteration MFMA roofline (the kernels have no per-launch events on the training path) + the dominant kernel by rocprof
+    symbol with its average duration, read from the committed summary of the SAME command under rocprofv3 (tools/finetune_profile.sh
+    -> profiles/r03_finetune_kernel_stats_streams1.csv), when that file is present."""
+    fl = finetune_flops(B)
+    achieved = world * fl / s_per_iter * 1e-12
+    out = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS * world, "unit": "TFLOP/s",
+           "frac": round(achieved / (MFMA_PEAK_TFLOPS * world), 4), "traffic": None,
+           "algorithmic_gflop_per_iteration_per_gpu": round(fl * 1e-9, 1),
+           "kernel": None, "note": "whole iteration (objective + backward + AdamW) over the dense MFMA peak"}
+    path = os.path.join(ROOT, "profiles", "r03_finetune_kernel_stats_streams1.csv")
+    try:
+        import csv
+        rows = list(csv.DictReader(open(path)))
+        rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
+        tot = sum(float(r["TotalDurationNs"]) for r in rows)
+        top = rows[0]
+        out["kernel"] = top["Name"][:120]
+        out["kernel_share_of_device_time"] = round(float(top["TotalDurationNs"]) / tot, 3)
+        out["kernel_avg_launch_us"] = round(float(top["AverageNs"]) * 1e-3, 2)
+        out["kernel_source"] = "profiles/r03_finetune_kernel_stats_streams1.csv (rocprofv3 --kernel-trace --stats of tools/finetune_bench.py)"
+    except (OSError, KeyError, ValueError, IndexError):
+        pass
+    return out
+
+
 def finetune_main(args):
     """BASELINE.json configs[3]: data-parallel few-shot fine-tune iterations (train/finetune_style_diffusion.py's objective,
     diffusion/gaussian_diffusion.py:1317-1399), 64 text-to-motion clips per rank, gradients of the 96 trainable tensors
@@ -480,6 +514,7 @@ def finetune_main(args):
                            "6 chained single-clip steps + frozen motion encoder + backward + AdamW per iteration",
                            "global_batch": world * B, "parallelism": f"dp{world}, 8 per-layer gradient buckets, all-reduce overlapped with backward"},
                 "iterations_per_s": round(args.steps / dt, 3), "final_loss": round(loss, 5), "allreduce": comm}
+        line["roofline"] = finetune_roofline(B, world, dt / args.steps)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
