@@ -138,11 +138,12 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
     //      operand: a 16-lane group reads 16 rows at chunks {c, c ^ 1} -> 16 distinct slots of the 256-B bank row).  LDS-DMA writes
     //      lane-linearly, so the swizzle is on the per-lane SOURCE address; wave w fills rows [8 w, 8 w + 8);
     //  (2) the FFN1 bias (4 KB, waves 0..3) and the GELU stage's Phi table (13 KB): both are read from LDS;
-    //  (3) LayerNorm1's residual for the tile's first 32 tokens: stream rows hi -> [OFF_X1, +32 KB), lo -> [OFF_X1 + 32 KB, +32 KB), row-linear,
-    //      wave w its own LN1 rows [4 w, 4 w + 4).  Requested after the out-proj loop instead, these rows cost ~3 us of exposed latency
-    //      (the loads queue behind 128 KB of prefetched fragments and then miss L2); the second half's rows ARE requested there, into
-    //      registers, and land while the first half is normalised.  The x1 image later overwrites the staging area row by row, each
-    //      row by the wave that consumed it.
+    // LayerNorm1's residual for the tile's first 32 tokens is staged by LDS-DMA too (stream rows hi -> [OFF_X1, +32 KB), lo ->
+    // [OFF_X1 + 32 KB, +32 KB), row-linear, wave w its own LN1 rows [4 w, 4 w + 4)) -- but at the start of the out-proj loop's LAST
+    // pass, not here: in this burst its 64 KB per tile (12.9 MB per launch) delayed the first MFMA by 1.5 us, and requested after the
+    // loop these rows cost ~3 us of exposed latency (the loads queue behind 128 KB of prefetched fragments and then miss L2).  The
+    // second half's rows are requested after the loop, into registers, and land while the first half is normalised.  The x1 image
+    // later overwrites the staging area row by row, each row by the wave that consumed it.
     float* b1s = reinterpret_cast<float*>(smem + C::OFF_B1);
     const char* const gtab = smem + C::OFF_TAB;
     unsigned* const arrived = reinterpret_cast<unsigned*>(smem + C::OFF_CNT);      // [chunk]: waves whose GELU output of that chunk is in the H image
@@ -158,15 +159,18 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
     if (wave < 4) tail_glds1((unsigned)lane * 16u, (unsigned long long)(b1 + 256 * wave), __builtin_amdgcn_readfirstlane(smem_base + C::OFF_B1 + 1024 * wave));
     tail_glds1((unsigned)lane * 16u, (unsigned long long)(gelu_tab + 256 * wave), __builtin_amdgcn_readfirstlane(smem_base + C::OFF_TAB + 1024 * wave));
     if (wave < 5) tail_glds1((unsigned)lane * 16u, (unsigned long long)(gelu_tab + 256 * (8 + wave)), __builtin_amdgcn_readfirstlane(smem_base + C::OFF_TAB + 1024 * (8 + wave)));
+    auto stage_residual = [&]() {                                     // 8 LDS-DMA pieces per wave: its LN1 rows [4 w, 4 w + 4) of the first half, hi and lo
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        int tok = tok0 + 4 * wave + r;
-        if (tok >= M) tok = M - 1;
-        const unsigned voff = (unsigned)tok * (unsigned)(MST_D * 2) + (unsigned)lane * 16u;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + C::OFF_X1 + (4 * wave + r) * 1024);
-        tail_glds1(voff, (unsigned long long)hx, dst);
-        tail_glds1(voff, (unsigned long long)hl, dst + 32768);
-    }
+        for (int r = 0; r < 4; r++) {
+            int tok = tok0 + 4 * wave + r;
+            if (tok >= M) tok = M - 1;
+            const unsigned voff = (unsigned)tok * (unsigned)(MST_D * 2) + (unsigned)lane * 16u;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + C::OFF_X1 + (4 * wave + r) * 1024);
+            tail_glds1(voff, (unsigned long long)hx, dst);
+            tail_glds1(voff, (unsigned long long)hl, dst + 32768);
+        }
+    };
+    constexpr int RES_OPS = 8;
 
     // ---- the weight stream of this wave
     const unsigned w_voff = (unsigned)lane * 16u;
@@ -206,9 +210,13 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
 
     // One unrolled pass = D fragments (`more`: another pass of the same phase follows).  RA fragments per k-step (4: out-proj / FFN2, both feature halves; 2: FFN1), each against the
     // step's four token fragments.  LOAD = false: the stream's last pass (nothing left to request; the waits count down).
+    // loadc: 1 = the pass requests the next D fragments; 0 = the stream's last pass (the waits count down); 1 + 2 E = as 1, and E other
+    // vector-memory operations were issued by this wave right in front of the pass (younger than the D fragments in flight, older
+    // than the ones it requests): every wait of the pass leaves them out.
     auto pass = [&](const char* img, auto rowb, auto rac, auto loadc, int k32base, bool more, auto side) {
         constexpr int RA = decltype(rac)::value;
-        constexpr bool LOAD = decltype(loadc)::value;
+        constexpr bool LOAD = (decltype(loadc)::value & 1) != 0;
+        constexpr int EXTRA = decltype(loadc)::value >> 1;
         constexpr int STEPS = D / RA;
 #pragma unroll
         for (int s = 0; s < STEPS; s++) {
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
                 // static slot index: the switch folds after unrolling
                 auto use = [&](auto jc) {
                     constexpr int J = decltype(jc)::value < D ? decltype(jc)::value : 0;      // (cases >= D are never taken)
-                    if constexpr (LOAD) tail_wwait<D - 1>(q[J]); else tail_wwait<D - 1 - J>(q[J]);
+                    if constexpr (LOAD) tail_wwait<D - 1 + EXTRA>(q[J]); else tail_wwait<D - 1 - J>(q[J]);
                     const f16x8 wf = __builtin_bit_cast(f16x8, q[J]);
                     if constexpr (RA == 4) {
                         constexpr int nh = (J >> 1) & 1, rb = J & 1;
@@ -246,8 +254,8 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
     };
     using RA4 = std::integral_constant<int, 4>;
     using RA2 = std::integral_constant<int, 2>;
-    using LD1 = std::integral_constant<bool, true>;
-    using LD0 = std::integral_constant<bool, false>;
+    using LD1 = std::integral_constant<int, 1>;
+    using LD0 = std::integral_constant<int, 0>;
 
     // =========================================================================================== phase P: out-proj
 #pragma unroll
@@ -262,8 +270,11 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
     {
         const char* img = smem + C::OFF_ATT;
         xread(img, RB1K(), 0, xs[0]);
+        constexpr int NPP = C::P_FRAG / D;
 #pragma unroll 1
-        for (int ps = 0; ps < C::P_FRAG / D; ps++) pass(img, RB1K(), RA4(), LD1(), ps * (D / 4), ps + 1 < C::P_FRAG / D, [](int) {});
+        for (int ps = 0; ps + 1 < NPP; ps++) pass(img, RB1K(), RA4(), LD1(), ps * (D / 4), true, [](int) {});
+        stage_residual();
+        pass(img, RB1K(), RA4(), std::integral_constant<int, 1 + 2 * RES_OPS>(), (NPP - 1) * (D / 4), false, [](int) {});
     }
     TAIL_MARK(2)
 
@@ -308,6 +319,8 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
             for (int r = 0; r < 4; r++) {
                 const char* srow = smem + (4 * wave + r) * C::LN_LD;
                 if (m == 0) {
+                    // this wave's staged rows: requested before the D fragments now in flight (whatever hipcc has issued since is younger still)
+                    if (r == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D) : "memory");
                     const char* stg = x1img + (4 * wave + r) * 1024 + lane * 8;
                     xa[r] = add4_f16(*reinterpret_cast<const uint2*>(stg), *reinterpret_cast<const uint2*>(stg + 32768), *reinterpret_cast<const f32x4*>(srow + fa * 4) + ba);
                     xb[r] = add4_f16(*reinterpret_cast<const uint2*>(stg + 512), *reinterpret_cast<const uint2*>(stg + 32768 + 512), *reinterpret_cast<const f32x4*>(srow + fb * 4) + bb);
