@@ -833,8 +833,10 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
     return 0;
 }
 
-// output projection tiles: 64 frames x (256 * NTO) features, 8 waves as 1 x 8 with 2 x NTO MFMA tiles each
-template <int MODE, int NTO, int NX>
+// output projection tiles: 64 frames x BF features.  8 waves as 1 x 8 with 2 x NTO MFMA tiles each (BF = 256 NTO), or -- for
+// 257..384 features, the HumanML / bandai widths -- as 2 x 4 with 1 x 3 tiles (BF = 384): the 512-row tile streamed and multiplied
+// 37 % zero-padding rows per slab.
+template <int MODE, int BF, int MT, int NT, int NX>
 static int launch_out(mst_engine* e, const WS& ws, int batch, int T, float* out, const StepArgs& sa, hipStream_t st,
                       const f16* w_override = nullptr, const float* b_override = nullptr, int tok_off = 1, bool frames_next = false,
                       bool hi_lo = false) {
@@ -842,23 +844,22 @@ static int launch_out(mst_engine* e, const WS& ws, int batch, int T, float* out,
     RowsFrames xs{ws.hx, MST_D, T, S, batch * T, 64, (size_t)batch * S, tok_off, hi_lo ? ws.hl : nullptr};   // hi_lo: ws.hx / ws.hl are the last stream
     DEpiEmbedOut<MODE> epi{b_override ? b_override : e->b_pose_out, e->cfg.feats, T, batch * T, out, sa};
     if (frames_next) { epi.xt_next = ws.xt; epi.kpad = e->kin_pad; epi.xt_next_lo = ws.xt_lo; }
-    return launch_gemm_dma<64, 256 * NTO, 2, NTO, 4, NX>(dim3((batch * T + 63) / 64, 1), xs, w_override ? w_override : e->w_pose_out, MST_D, MST_D, epi, st);
+    return launch_gemm_dma<64, BF, MT, NT, 4, NX>(dim3((batch * T + 63) / 64, 1), xs, w_override ? w_override : e->w_pose_out, MST_D, MST_D, epi, st);
 }
-template <int MODE, int NTO>
+template <int MODE, int BF, int MT, int NT>
 static int launch_out_nx(mst_engine* e, const WS& ws, int cfg, int batch, int T, float* out, const StepArgs& sa, hipStream_t st,
                          const f16* wo = nullptr, const float* bo = nullptr, int tok_off = 1, bool frames_next = false, bool hi_lo = false) {
-    return cfg ? launch_out<MODE, NTO, 2>(e, ws, batch, T, out, sa, st, wo, bo, tok_off, frames_next, hi_lo)
-               : launch_out<MODE, NTO, 1>(e, ws, batch, T, out, sa, st, wo, bo, tok_off, frames_next, hi_lo);
+    return cfg ? launch_out<MODE, BF, MT, NT, 2>(e, ws, batch, T, out, sa, st, wo, bo, tok_off, frames_next, hi_lo)
+               : launch_out<MODE, BF, MT, NT, 1>(e, ws, batch, T, out, sa, st, wo, bo, tok_off, frames_next, hi_lo);
 }
 template <int MODE>
 static int launch_out_nt(mst_engine* e, const WS& ws, int cfg, int batch, int T, float* out, const StepArgs& sa, hipStream_t st,
                          const f16* wo = nullptr, const float* bo = nullptr, int tok_off = 1, bool frames_next = false, bool hi_lo = false) {
     ProfScope ps(e, FAM_EMBED_OUT, st);
-    switch (e->nt_out) {
-        case 1: return launch_out_nx<MODE, 1>(e, ws, cfg, batch, T, out, sa, st, wo, bo, tok_off, frames_next, hi_lo);
-        case 2: return launch_out_nx<MODE, 2>(e, ws, cfg, batch, T, out, sa, st, wo, bo, tok_off, frames_next, hi_lo);
-    }
-    return fail("output projection: feats %d unsupported", e->cfg.feats);
+    const int rows_out = e->cfg.feats;                   // (also for the pose embedding's backward, which runs this kernel with W_in^T)
+    if (rows_out <= 256) return launch_out_nx<MODE, 256, 2, 1>(e, ws, cfg, batch, T, out, sa, st, wo, bo, tok_off, frames_next, hi_lo);
+    if (rows_out <= 384) return launch_out_nx<MODE, 384, 1, 3>(e, ws, cfg, batch, T, out, sa, st, wo, bo, tok_off, frames_next, hi_lo);
+    return launch_out_nx<MODE, 512, 2, 2>(e, ws, cfg, batch, T, out, sa, st, wo, bo, tok_off, frames_next, hi_lo);
 }
 
 static int check_ready(mst_engine* e, int batch, int frames, int cfg) {
