@@ -199,7 +199,7 @@ struct QATile {
     static constexpr int INSTR = ROWS / RPP;
     static constexpr int PER = (INSTR + 7) / 8;
     static constexpr int RING = NSTAGE * STAGE;
-    static constexpr int XROWS = XR;
+    static constexpr int XROWS = XR, XHI = XR;          // (no lo tensor here)
     static constexpr int KV = NKT * 32 * 256 * 2;       // K and V images afterwards (reuse the ring)
     static constexpr int OFF_BIAS = RING > KV ? RING : KV;   // q | k | v bias of the head (384 floats), staged once at kernel start
     static constexpr int SMEM = OFF_BIAS + 3 * MST_HD * 4;

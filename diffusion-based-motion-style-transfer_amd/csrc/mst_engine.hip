@@ -565,12 +565,13 @@ struct ProfScope {
 };
 
 // ------------------------------------------------------------------------------------------ launches
-template <int BT, int BF, int MT, int NT, int NS, int NX, int BK = 32, class SRC, class EPI>
+template <int BT, int BF, int MT, int NT, int NS, int NX, int BK = 32, int XS = 1, class SRC, class EPI>
 static int launch_gemm_dma(dim3 grid, const SRC& xs, const f16* W, int ldw, int K, const EPI& epi, hipStream_t st, int xcd_ny = 0) {
-    using TL = DTile<BT, BF, MT, NT, NS, NX, BK>;
+    using TL = DTile<BT, BF, MT, NT, NS, NX, BK, XS>;
     static_assert(EPI::template smem_bytes<BT, BF>() <= TL::SMEM, "epilogue tile must fit the ring");
     static_assert(TL::SMEM <= 163840, "ring exceeds the 160 KiB LDS");
-    auto kern = k_gemm_dma<BT, BF, MT, NT, NS, NX, SRC, EPI, BK>;
+    auto kern = k_gemm_dma<BT, BF, MT, NT, NS, NX, SRC, EPI, BK, XS>;
+    if (XS == 2 && !xs.Xlo) return fail("gemm: the split-activation tile needs the lo tensor");
     CHECK(ensure_dyn_lds((const void*)kern, TL::SMEM));
     if (K < BK * (NS - 1) || (K % BK)) return fail("gemm: K=%d unsupported by the %d-slot ring", K, NS);
     hipLaunchKernelGGL(kern, grid, dim3(512), TL::SMEM, st, xs, W, ldw, K, xcd_ny, epi);
@@ -717,8 +718,9 @@ static int assemble_stream(mst_engine* e, const WS& ws, const float* x, int clip
         epi.ct.temb = e->temb; epi.ct.textproj = ws.textproj; epi.ct.ld = lr.ld;
         epi.ct.uniform_row = temb_uniform_row; epi.ct.temb_mod = temb_mod; epi.ct.joff = lr.joff; epi.ct.rows = rows;
         epi.ct.tp_half = rows > clips_x ? clips_x : 0; epi.ct.tp_uncond = rows > clips_x ? tp_uncond : 0;
-        CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1>(dim3((tot + 63) / 64, 1), RowsDirect{ws.xt, e->kin_pad, ws.xt_lo}, e->w_pose_in, e->kin_pad,
-                                                   e->kin_pad, epi, st)));
+        // x_t as hi + lo (RowsDirect::Xlo): both halves of a k-slab beside ONE copy of the weight slab
+        CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1, 32, 2>(dim3((tot + 63) / 64, 1), RowsDirect{ws.xt, e->kin_pad, ws.xt_lo}, e->w_pose_in, e->kin_pad,
+                                                          e->kin_pad, epi, st)));
     }
     return 0;
 }
@@ -836,7 +838,7 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
 // output projection tiles: 64 frames x BF features.  8 waves as 1 x 8 with 2 x NTO MFMA tiles each (BF = 256 NTO), or -- for
 // 257..384 features, the HumanML / bandai widths -- as 2 x 4 with 1 x 3 tiles (BF = 384): the 512-row tile streamed and multiplied
 // 37 % zero-padding rows per slab.
-template <int MODE, int BF, int MT, int NT, int NX>
+template <int MODE, int BF, int MT, int NT, int NX, int XS = 1>
 static int launch_out(mst_engine* e, const WS& ws, int batch, int T, float* out, const StepArgs& sa, hipStream_t st,
                       const f16* w_override = nullptr, const float* b_override = nullptr, int tok_off = 1, bool frames_next = false,
                       bool hi_lo = false) {
@@ -844,11 +846,17 @@ static int launch_out(mst_engine* e, const WS& ws, int batch, int T, float* out,
     RowsFrames xs{ws.hx, MST_D, T, S, batch * T, 64, (size_t)batch * S, tok_off, hi_lo ? ws.hl : nullptr};   // hi_lo: ws.hx / ws.hl are the last stream
     DEpiEmbedOut<MODE> epi{b_override ? b_override : e->b_pose_out, e->cfg.feats, T, batch * T, out, sa};
     if (frames_next) { epi.xt_next = ws.xt; epi.kpad = e->kin_pad; epi.xt_next_lo = ws.xt_lo; }
-    return launch_gemm_dma<64, BF, MT, NT, 4, NX>(dim3((batch * T + 63) / 64, 1), xs, w_override ? w_override : e->w_pose_out, MST_D, MST_D, epi, st);
+    return launch_gemm_dma<64, BF, MT, NT, 4, NX, 32, XS>(dim3((batch * T + 63) / 64, 1), xs, w_override ? w_override : e->w_pose_out, MST_D, MST_D, epi, st);
 }
 template <int MODE, int BF, int MT, int NT>
 static int launch_out_nx(mst_engine* e, const WS& ws, int cfg, int batch, int T, float* out, const StepArgs& sa, hipStream_t st,
                          const f16* wo = nullptr, const float* bo = nullptr, int tok_off = 1, bool frames_next = false, bool hi_lo = false) {
+    // hi + lo stream: both halves of a k-slab beside one copy of the weight slab where that ring fits the LDS (<= 384 rows),
+    // otherwise the K range twice (gemm_mainloop_dma)
+    if constexpr (BF <= 384) {
+        if (hi_lo) return cfg ? launch_out<MODE, BF, MT, NT, 2, 2>(e, ws, batch, T, out, sa, st, wo, bo, tok_off, frames_next, true)
+                              : launch_out<MODE, BF, MT, NT, 1, 2>(e, ws, batch, T, out, sa, st, wo, bo, tok_off, frames_next, true);
+    }
     return cfg ? launch_out<MODE, BF, MT, NT, 2>(e, ws, batch, T, out, sa, st, wo, bo, tok_off, frames_next, hi_lo)
                : launch_out<MODE, BF, MT, NT, 1>(e, ws, batch, T, out, sa, st, wo, bo, tok_off, frames_next, hi_lo);
 }

@@ -20,7 +20,7 @@
 
 namespace mst {
 
-template <int BT, int BF, int MT, int NT, int NS = 4, int NX = 1, int BK = 32>
+template <int BT, int BF, int MT, int NT, int NS = 4, int NX = 1, int BK = 32, int XS = 1>
 struct DTile {
     static_assert(BK == 32 || BK == 64, "slab depth");
     static constexpr int KDEPTH = BK;
@@ -30,7 +30,9 @@ struct DTile {
     static constexpr int WT = BT / (32 * MT);       // wave rows (token direction)
     static constexpr int WN = 8 / WT;               // wave columns (feature direction)
     static_assert(WT * WN == 8 && WN * NT * 32 == BF, "8 waves must tile BT x BF");
-    static constexpr int XROWS = NX * BT;           // NX = 2: a second token group (CFG: the uncond half)
+    static constexpr int XGROUPS = XS * NX;         // NX = 2: a second token group (CFG: the uncond half); XS = 2: every group twice,
+    static constexpr int XROWS = XGROUPS * BT;      // as the hi and the lo half of a split activation (same accumulators, weights staged once)
+    static constexpr int XHI = NX * BT;             // rows [0, XHI): the hi (or only) tensor; [XHI, XROWS): the lo tensor
     static constexpr int ROWS = XROWS + BF;
     static constexpr int STAGE = ROWS * RB;         // bytes per slab
     static constexpr int NSTAGE = NS;               // ring slots: NS - 1 slabs in flight
@@ -86,7 +88,7 @@ template <class TL>
 struct DmaPlan {
     static_assert(TL::PER <= kMaxPer && TL::INSTR >= TL::PER, "piece plan");
     unsigned voff[kMaxPer];
-    bool isx[kMaxPer];
+    unsigned char kind[kMaxPer];            // 0: weight rows, 1: activation rows, 2: activation rows of the lo tensor
     int start;
     // rowbyte(r): byte offset of tile row r inside its operand (X rows for r < XROWS, else W rows)
     template <class F>
@@ -98,18 +100,21 @@ struct DmaPlan {
             if (j < TL::PER) {
                 const int row = (start + j) * TL::RPP + lane / TL::CPR;
                 const int c = TL::RB == 64 ? ((lane & 3) ^ ((row >> 2) & 3)) : ((lane & 7) ^ ((row >> 1) & 7));
-                isx[j] = (start + j) * TL::RPP < TL::XROWS;           // wave-uniform
+                const int r0 = (start + j) * TL::RPP;                 // wave-uniform
+                kind[j] = r0 >= TL::XROWS ? 0 : (r0 < TL::XHI ? 1 : 2);
                 voff[j] = rowbyte(row) + c * 16 + kDmaBias - (j & 3) * 1024;
-            } else { voff[j] = 0; isx[j] = false; }
+            } else { voff[j] = 0; kind[j] = 0; }
         }
     }
     // slab `ksrc` of the operands -> ring slot of slab-sequence position `kt`
-    __device__ __forceinline__ void issue(unsigned smem_base, int kt, int ksrc, const char* xbase, const char* wbase) const {
+    __device__ __forceinline__ void issue(unsigned smem_base, int kt, int ksrc, const char* xbase, const char* wbase,
+                                          const char* xlobase = nullptr) const {
         const unsigned long long sx = (unsigned long long)(xbase + (size_t)ksrc * TL::RB - kDmaBias);
         const unsigned long long sw = (unsigned long long)(wbase + (size_t)ksrc * TL::RB - kDmaBias);
+        const unsigned long long sl = (unsigned long long)((xlobase ? xlobase : xbase) + (size_t)ksrc * TL::RB - kDmaBias);
         unsigned long long sb[kMaxPer];
 #pragma unroll
-        for (int j = 0; j < kMaxPer; j++) sb[j] = isx[j] ? sx : sw;
+        for (int j = 0; j < kMaxPer; j++) sb[j] = kind[j] == 1 ? sx : (kind[j] == 2 ? sl : sw);
         const unsigned base = __builtin_amdgcn_readfirstlane(smem_base + (kt % TL::NSTAGE) * TL::STAGE + start * 1024);
         if constexpr (TL::PER >= 4) glds_group<4>(voff, sb, 0, base);
         else glds_group<TL::PER>(voff, sb, 0, base);
@@ -148,6 +153,8 @@ struct RowsFrames {                       // tile row r = frame (tok0 + r) of th
     }
 };
 
+// TL::XGROUPS = 2 NX (XS = 2): the activation is hi + lo and BOTH halves of a k-slab are staged beside ONE copy of the weight slab
+// (the K-twice form below re-streams the weights: it is what small launches and tiles whose ring would not fit use).
 template <class TL, int BT, int BF, int MT, int NT, int NX, class SRC>
 __device__ __forceinline__ void gemm_mainloop_dma(char* smem, const SRC& xs, const f16* __restrict__ W, int ldw,
                                                   int tok0, int f0, int K, f32x16 (&acc)[NX][MT][NT]) {
@@ -157,16 +164,18 @@ __device__ __forceinline__ void gemm_mainloop_dma(char* smem, const SRC& xs, con
     const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
     DmaPlan<TL> plan;
+    constexpr bool SPLIT = TL::XGROUPS > NX;                 // hi and lo rows in the same slab
     plan.init(wave, lane, [&](int row) {
-        return row < TL::XROWS ? xs.rowbyte(tok0, row) : (unsigned)(f0 + row - TL::XROWS) * (unsigned)ldw * 2u;
+        return row < TL::XROWS ? xs.rowbyte(tok0, row < TL::XHI ? row : row - TL::XHI) : (unsigned)(f0 + row - TL::XROWS) * (unsigned)ldw * 2u;
     });
     const char* xb = xs.base();
     const char* xlo = xs.base_lo();
     const char* wb = reinterpret_cast<const char*>(W);
-    const int KT1 = K / TL::KDEPTH, KT = xlo ? 2 * KT1 : KT1;   // hi + lo operand: the K range twice, weights re-streamed (L2-hot)
+    const int KT1 = K / TL::KDEPTH, KT = (xlo && !SPLIT) ? 2 * KT1 : KT1;   // K-twice form: weights re-streamed (L2-hot)
     constexpr int AHEAD = TL::NSTAGE - 1;                    // slabs in flight
     auto issue = [&](int kt) {
-        if (kt < KT1) plan.issue(smem_base, kt, kt, xb, wb);
+        if (SPLIT) plan.issue(smem_base, kt, kt, xb, wb, xlo);
+        else if (kt < KT1) plan.issue(smem_base, kt, kt, xb, wb);
         else plan.issue(smem_base, kt, kt - KT1, xlo, wb);
     };
 #pragma unroll
@@ -184,20 +193,20 @@ __device__ __forceinline__ void gemm_mainloop_dma(char* smem, const SRC& xs, con
 #pragma unroll
         for (int ks = 0; ks < TL::KDEPTH / 16; ks++) {
             const int c = ks * 2 + (lane >> 5);
-            f16x8 xf[NX][MT], wf[NT];
+            f16x8 xf[TL::XGROUPS][MT], wf[NT];
 #pragma unroll
-            for (int x = 0; x < NX; x++)
+            for (int x = 0; x < TL::XGROUPS; x++)
 #pragma unroll
                 for (int m = 0; m < MT; m++)
                     xf[x][m] = *reinterpret_cast<const f16x8*>(st + ring_off_rb<TL::RB>(x * BT + (wt * MT + m) * 32 + (lane & 31), c));
 #pragma unroll
             for (int n = 0; n < NT; n++) wf[n] = *reinterpret_cast<const f16x8*>(st + ring_off_rb<TL::RB>(TL::XROWS + (wn * NT + n) * 32 + (lane & 31), c));
 #pragma unroll
-            for (int x = 0; x < NX; x++)
+            for (int x = 0; x < TL::XGROUPS; x++)            // group x >= NX = the lo half of group x - NX: same accumulators
 #pragma unroll
                 for (int m = 0; m < MT; m++)
 #pragma unroll
-                    for (int n = 0; n < NT; n++) acc[x][m][n] = mfma_f16(wf[n], xf[x][m], acc[x][m][n]);
+                    for (int n = 0; n < NT; n++) acc[x % NX][m][n] = mfma_f16(wf[n], xf[x][m], acc[x % NX][m][n]);
         }
     }
     __builtin_amdgcn_s_barrier();                           // every wave done reading: smem reusable
@@ -659,10 +668,10 @@ struct DEpiEmbedOut {
     }
 };
 
-template <int BT, int BF, int MT, int NT, int NS, int NX, class SRC, class EPI, int BK = 32>
+template <int BT, int BF, int MT, int NT, int NS, int NX, class SRC, class EPI, int BK = 32, int XS = 1>
 __global__ __launch_bounds__(512) void k_gemm_dma(SRC xs, const f16* __restrict__ W, int ldw, int K, int xcd_ny, EPI epi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using TL = DTile<BT, BF, MT, NT, NS, NX, BK>;
+    using TL = DTile<BT, BF, MT, NT, NS, NX, BK, XS>;
     int bx = blockIdx.x, by = blockIdx.y;
     if (xcd_ny > 0) {
         // XCD-aware order (1-D launch over ceil(nx/8)*8*ny ids): workgroups are dealt round-robin over the
