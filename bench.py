@@ -78,7 +78,7 @@ def family_work(family, rows, clips, T, F):
         "ffn2_ln_gemm": (2.0 * M * D * FF, 2 * op + stream + stream + FF * D * 2),
         "layer_tail_fused": (2.0 * M * D * D + 4.0 * M * FF * D, op + stream + stream + (D * D + 2 * FF * D) * 2),
         "embed_in": (2.0 * clips * T * D * F, clip + rows * T * D * 4.0 + D * F * 2),
-        "embed_out_step": (2.0 * rows * T * F * D, rows * T * D * 2.0 + 3 * clip + clip + F * D * 2),
+        "embed_out_step": (2.0 * rows * T * F * D, rows * T * D * 4.0 + 3 * clip + clip + F * D * 2),      # the last stream is read as hi + lo
         "cond_token": (0.0, rows * D * 4.0 * 2),
     }
     return table[family]
@@ -349,7 +349,7 @@ def pmc_traffic(families, rows):
     keys = {"outproj_ln_gemm": "ln_gemm", "ffn2_ln_gemm": "ln_gemm"}
     if rows != 64:
         return None, None
-    for name in ("r02_pmc_traffic.json", "r01_final_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_final_pmc_traffic.json"):
         try:
             kernels = json.load(open(os.path.join(prof_dir, name)))["kernels"]
         except (OSError, KeyError, ValueError):

@@ -1415,7 +1415,7 @@ static int wgrad(mst_engine* e, const f16* dY, int n_out, const f16* X, int k_in
         hipLaunchKernelGGL(k_colsum_f16, dim3(n_out / 256, nrb), dim3(256), 0, st, dY, n_out, M, rpb, t.gscale, db, t.cs_part);
         HIPCHECK(hipGetLastError());
         if (nrb > 1) {
-            hipLaunchKernelGGL(k_sum_partials, dim3((n_out + 255) / 256), dim3(256), 0, st, t.cs_part, nrb, n_out, t.gscale, db);
+            hipLaunchKernelGGL(k_sum_partials, dim3((n_out + 63) / 64), dim3(256), 0, st, t.cs_part, nrb, n_out, t.gscale, db);
             HIPCHECK(hipGetLastError());
         }
     }
@@ -1443,7 +1443,7 @@ static int train_stack_backward(mst_engine* e, const Tape& t, int rows, int S, f
     const int M = rows * S, nl = e->cfg.num_layers;
     float* gA = w_.g0;      // dz buffers
     float* gB = w_.g1;      // gradient wrt the current layer output
-    const int ln_blocks = (M + 3) / 4 < 512 ? (M + 3) / 4 : 512;
+    const int ln_blocks = (M + 3) / 4 < 256 ? (M + 3) / 4 : 256;      // one per CU; their partial sums are added in block order (k_ln_bwd_finish)
     const bool small = e->small_m > 0 && M <= e->small_m;
     e->prof_now = 0;
     // The dgrad chain (LayerNorm / GELU / attention backward and the four dgrad GEMMs) is serial; the four wgrads of a
@@ -1472,7 +1472,7 @@ static int train_stack_backward(mst_engine* e, const Tape& t, int rows, int S, f
         // LayerNorm2 backward: gB -> dz2 (gA, fp32) and the branch gradient dbr2 (f16); dgamma2, dbeta2, db2
         hipLaunchKernelGGL(k_ln_bwd, dim3(ln_blocks), dim3(256), 0, st, gB, a.z2h, a.z2l, w.g2, M, make_drop(seed, l, 3, p_drop), w_.gscale,
                            gA, dbr2, w_.ln_part);
-        if (wg) hipLaunchKernelGGL(k_ln_bwd_finish, dim3(6), dim3(256), 0, st, w_.ln_part, ln_blocks, w_.gscale, G[10], G[11], G[7]);
+        if (wg) hipLaunchKernelGGL(k_ln_bwd_finish, dim3(3 * MST_D / 64), dim3(256), 0, st, w_.ln_part, ln_blocks, w_.gscale, G[10], G[11], G[7]);
         HIPCHECK(hipGetLastError());
         TO_SIDE()
         if (wg) CHECK(wgrad(e, dbr2, MST_D, a.hid, MST_FF, M, G[6], nullptr, sw));                 // dW2 += dbr2^T hid
@@ -1493,7 +1493,7 @@ static int train_stack_backward(mst_engine* e, const Tape& t, int rows, int S, f
         // LayerNorm1 backward: gB -> dz1 (gA), dbr1 = d(out-proj output); dgamma1, dbeta1, db_out
         hipLaunchKernelGGL(k_ln_bwd, dim3(ln_blocks), dim3(256), 0, st, gB, a.z1h, a.z1l, w.g1, M, make_drop(seed, l, 1, p_drop), w_.gscale,
                            gA, dbr1, w_.ln_part);
-        if (wg) hipLaunchKernelGGL(k_ln_bwd_finish, dim3(6), dim3(256), 0, st, w_.ln_part, ln_blocks, w_.gscale, G[8], G[9], G[3]);
+        if (wg) hipLaunchKernelGGL(k_ln_bwd_finish, dim3(3 * MST_D / 64), dim3(256), 0, st, w_.ln_part, ln_blocks, w_.gscale, G[8], G[9], G[3]);
         HIPCHECK(hipGetLastError());
         TO_SIDE()
         if (wg) CHECK(wgrad(e, dbr1, MST_D, a.att, MST_D, M, G[2], nullptr, sw));                  // dW_out += dbr1^T att
