@@ -172,8 +172,9 @@ struct mst_engine {
     int fuse_qkv_attn = 1;                // K4 + K5 as one kernel per (clip, head); MST_FUSE_QKV_ATTN=0 keeps them apart
     int fuse_tail = 1;                    // K6 + K7 + K8 as one kernel per 64-token tile (mst_tail.h); MST_FUSE_TAIL=0 keeps them apart
     int fuse_frames = 1;                  // sampling loop: a step's epilogue writes the next step's f16 frame rows; MST_FUSE_FRAMES=0 runs k_frames_f16 every step
-    int small_m = 4096;                   // launches of at most this many token rows take the small-tile path (MST_SMALL_M, 0 = never);
-                                          // tools/small_m_ab2.sh, one launch, us per step small / large tiles: 11 clips 512 / 723, 16: 596 / 724, 20: 694 / 727, 24: 813 / 732
+    int small_m = 3200;                   // launches of at most this many token rows take the small-tile path (MST_SMALL_M, 0 = never);
+                                          // tools/small_m_ab2.sh, one launch, us per step small / large tiles: 8 clips 444 / 569, 11: 519 / 571,
+                                          // 14: 560 / 572, 16: 566 / 571, 20: 641 / 575, 24: 718 / 577 (the large-tile step is flat: hand-over at 16 clips)
     float* zacc = nullptr;                // fp32 GEMM result feeding k_ln_rows on that path
     int ln128_min_m = 1 << 30;            // MST_LN128_M=n: launches of >= n token rows use 128-token LayerNorm tiles (half the weight
                                           // re-streaming).  Off by default: wins 16-21 % in gemm_bench, nothing in the pipeline (CFG 39.7 vs
@@ -911,14 +912,6 @@ static int loop_slices_for(const mst_engine* e, int batch, int cfg, int frames) 
         const bool small = e->small_m > 0 && M <= e->small_m;
         const long long waves = ((M + 63) / 64 + 255) / 256;        // rounds of 64-token tiles over the 256 CUs
         n = small ? 3 : (int)(waves < 3 ? waves : 3);
-        // a batch just above the small-tile limit: slices that each fit it run the small-tile kernels side by side, whose step
-        // is shorter than the large-tile step while the batch is small (tools/streams_ab_small.sh, 196 frames: the large-tile
-        // step is ~0.73 ms whatever the batch, k small-tile slices take ~0.29 + 0.017 ms x clips: batch 16 28.3 vs 22.1 clips/s,
-        // 24: 34.0 vs 32.9, 30: 37.2 vs 41.0 -- the crossover is ~26 clips = 5120 token rows)
-        for (int k = 2; !small && n == 1 && e->small_m > 0 && M <= 5120 && k <= 3; k++) {
-            const int per = (rows + k - 1) / k;
-            if (rows / k >= 8 && (long long)per * (frames + 1) <= e->small_m) n = k;
-        }
     }
     while (n > 1 && rows / n < 8) n--;                       // at least 8 rows through the transformer per slice
     return n;

@@ -80,9 +80,10 @@ def test_odd_batch_across_the_two_slices_equals_single_slice():
     from oracle import schedule
     F, T, B = 181, 76, 17
     eng, w, pe = make(F, T, B)
-    # 17 clips x 77 tokens take the small-tile path: sliced (8-clip minimum); 64 clips = 4928 rows sit just under the crossover and run as
-    # two small-tile slices; their CFG batch (9856 rows, 154 large tiles) fits the chip at once: one slice
-    assert eng.loop_slices(B) == 2 and eng.loop_slices(8) == 1 and eng.loop_slices(64) == 2 and eng.loop_slices(64, cfg=True) == 1
+    # 17 clips x 77 tokens take the small-tile path: sliced (8-clip minimum); 64 clips = 4928 rows are past the hand-over (3200 rows:
+    # the large-tile step is flat in the batch and the shorter one from 16 full-length clips on) and fit the chip at once: one slice,
+    # as does their CFG batch (9856 rows, 154 large tiles)
+    assert eng.loop_slices(B) == 2 and eng.loop_slices(8) == 1 and eng.loop_slices(64) == 1 and eng.loop_slices(64, cfg=True) == 1
     shape = (B, F, 1, T)
     tab, tmap = schedule.make("cosine", 1000, "")
     sch = Schedule(tab, tmap, dev())
