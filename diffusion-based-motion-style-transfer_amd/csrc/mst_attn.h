@@ -16,6 +16,10 @@
 #include "mst_common.h"
 #include "mst_gemm_dma.h"   // ring_off, DmaPlan, wait_vmcnt
 
+#ifndef QA_MARK              // probes/attn_clock.hip defines it (under MST_PROBE_BUILD) to stamp the phases; the product build has none
+#define QA_MARK(i)
+#endif
+
 namespace mst {
 
 // K image: 256-B rows, 16-B chunk ch of row `row` at chunk ch ^ (row & 15)  (ds_read_b128, T2)
@@ -212,10 +216,6 @@ __global__ __launch_bounds__(512) void k_qkv_attention(const f16* __restrict__ h
     using TL = QATile<NKT>;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifndef QA_MARK              // probes/attn_clock.hip defines it (under MST_PROBE_BUILD) to stamp the phases; the product build has none
-#define QA_MARK(i)
-#define QA_MARK_DEFAULTED
-#endif
     QA_MARK(0)
     // Workgroups are dealt round-robin over the 8 XCDs (id % 8).  The four heads of a clip read the SAME token rows, so give
     // them the same id % 8: the rows are then fetched into one XCD's L2 once instead of into four (PMC: 55 MB of HBM reads per
@@ -446,10 +446,279 @@ __global__ __launch_bounds__(512) void k_qkv_attention(const f16* __restrict__ h
         }
     }
     QA_MARK(4)
-#ifdef QA_MARK_DEFAULTED
-#undef QA_MARK
-#undef QA_MARK_DEFAULTED
-#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Round 3: the same fusion with the operand roles of the projection swapped.
+//
+// In k_qkv_attention a wave owns a 32-token tile and multiplies it with all 384 weight rows of the head, so the WEIGHTS are
+// the operand every wave reads: 384 KB of weight slabs + 224 KB of token slabs go through the LDS-DMA ring (ten pieces per
+// wave and slab in front of its MFMAs: in-kernel stamps, 17.9 us = 8.1 us of DMA + 10.4 us of MFMA, in series) and every wave
+// reads every weight slab back (3 MB of ds_read per workgroup = the LDS read peak for ~10 us).  Here a wave owns 48 of the 384
+// weight rows for ALL tokens of the clip:
+//   * its weights are wave-private, so they never touch the LDS: W_in is pre-packed per (head, wave) as 48 fragments of 1 KB in
+//     the 16x16x32 A-operand lane order (k_pack_qkv) and streamed L2 -> VGPR with hand-counted waits, as in the layer tail;
+//   * only the token rows go through the ring (26 KB per 64-deep slab at S = 197: 4 pieces per wave instead of 10), and the LDS
+//     reads drop to 8 x 208 KB;
+//   * 16-token MFMA tiles: 197 tokens pad to 208, not 224 (7 % fewer MFMAs), and all 8 waves carry the same 39 tiles.
+// q, k and v then all go to LDS images (a wave holds 48 features of every token, not a query tile): [K | V | Q | 16 pad rows],
+// 16 NT16 rows each.  The attention core reads 32-row tiles; when NT16 is odd its last tile runs 16 rows into the next image:
+// K's into V rows 0..15 (keys >= S, masked to -inf), V's into Q rows 0..15 (finite numbers times P = 0), Q's into the pad rows
+// (queries >= S, never stored).
+//
+// vmcnt bookkeeping (everything a wave issues is hand-counted; P = DMA pieces per wave and slab; R(k)a / R(k)b = the three weight
+// fragments of slab k's first / second k-step; D(k) = the DMA pieces of token slab k; completion is in issue order):
+//     prologue   R(0)a R(0)b D(0) D(1) D(2)
+//     slab kt    wait D(kt), barrier | wait R(kt)a, 39 MFMAs, load R(kt+1)a | wait R(kt)b, 39 MFMAs, load R(kt+1)b | issue D(kt+3)
+// A wait names the number of operations issued BEHIND the awaited one.  D(kt+3) goes out at the END of slab kt so that the first
+// wait that forces it (R(kt+2)a, loaded behind it) comes two slabs later.
+// ------------------------------------------------------------------------------------------------------------
+template <int NT16>
+struct QA2Tile {
+    static constexpr int KDEPTH = 64, RB = 128, RPP = 8, CPR = 8;      // 64-deep token slabs, 128-B rows (see DTile)
+    static constexpr int ROWS = 16 * NT16, XROWS = ROWS, XHI = ROWS;    // every ring row is a token row
+    static constexpr int STAGE = ROWS * RB, NSTAGE = 4, INSTR = ROWS / RPP, PER = (INSTR + 7) / 8, RING = NSTAGE * STAGE;
+    static constexpr int KT = MST_D / KDEPTH;                           // 8 slabs
+    static constexpr int NKT = (NT16 + 1) / 2;                          // 32-key tiles of the attention core
+    static constexpr int IMG = ROWS * 256;
+    static constexpr int OFF_K = 0, OFF_V = IMG, OFF_Q = 2 * IMG, OFF_BIAS = 3 * IMG;   // bias: 1.5 KB at the head of the 16 pad rows
+    static constexpr int SMEM = 3 * IMG + 16 * 256;
+    static constexpr int WAVE_FRAGS = 3 * (MST_D / 32);                 // 48 fragments of 1 KB per wave: [k32][16-row group]
+    static constexpr size_t LAYER_BYTES = (size_t)MST_H * 8 * WAVE_FRAGS * 1024;        // = 3 x 512 x 512 f16
+    static_assert(RING <= OFF_BIAS && SMEM <= 163840 && NT16 >= 1 && NT16 <= 13, "LDS map");
+};
+
+// W_in ([1536][512] f16, torch in_proj layout: q rows | k rows | v rows) -> per (head, wave) fragment streams.  Fragment
+// (k32, i) of wave w, lane l = 8 consecutive k (32 k32 + 8 (l >> 4) ..) of row 48 w + 16 i + (l & 15) of the head's q|k|v rows.
+__global__ __launch_bounds__(256) void k_pack_qkv(const f16* __restrict__ w_in, f16* __restrict__ dst) {
+    constexpr int NF = 3 * (MST_D / 32);
+    const int total = MST_H * 8 * NF * 64;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int lane = i & 63, f = (i >> 6) % NF, wave = ((i >> 6) / NF) & 7, head = (i >> 6) / (NF * 8);
+        const int k32 = f / 3, g = f % 3;
+        const int r = 48 * wave + 16 * g + (lane & 15);                 // 0..383: q | k | v row of the head
+        const int row = (r >> 7) * MST_D + head * MST_HD + (r & 127);
+        reinterpret_cast<uint4*>(dst)[i] = *reinterpret_cast<const uint4*>(w_in + (size_t)row * MST_D + 32 * k32 + 8 * (lane >> 4));
+    }
+}
+
+template <int N> __device__ __forceinline__ void qa_wwait3(u32x4& a, u32x4& b, u32x4& c) {
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N));
+}
+__device__ __forceinline__ void qa_glds1(unsigned voff, unsigned long long sbase, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
+}
+
+template <int NT16>
+__global__ __launch_bounds__(512) void k_qkv_attention2(const f16* __restrict__ hx, const f16* __restrict__ wq,
+                                                        const float* __restrict__ b_in, f16* __restrict__ out, int S) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using TL = QA2Tile<NT16>;
+    constexpr int NKT = TL::NKT, P = TL::PER, KT = TL::KT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    QA_MARK(0)
+    // (clip, head) of this workgroup: the four heads of a clip share id % 8 = one XCD's L2 (see k_qkv_attention)
+    const int nclip = gridDim.x / MST_H, full = (nclip / 8) * 8 * MST_H;
+    int clip, head;
+    if ((int)blockIdx.x < full) {
+        const int grp = blockIdx.x >> 5, within = blockIdx.x & 31;
+        clip = grp * 8 + (within & 7);
+        head = within >> 3;
+    } else {
+        const int r = blockIdx.x - full;
+        clip = (nclip / 8) * 8 + r / MST_H;
+        head = r % MST_H;
+    }
+    const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const char* xb = reinterpret_cast<const char*>(hx + (size_t)clip * S * MST_D);
+    // the head's q | k | v bias (3 x 512 B) -> LDS by two DMA pieces of wave 0: the oldest operations of its queue
+    if (wave == 0) {
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int reg = 2 * p + (lane >> 5) < 2 ? 2 * p + (lane >> 5) : 2;
+            qa_glds1((unsigned)((reg * MST_D + head * MST_HD) * 4 + (lane & 31) * 16), (unsigned long long)b_in,
+                     __builtin_amdgcn_readfirstlane(smem_base + TL::OFF_BIAS + p * 1024));
+        }
+    }
+    // weight stream of this wave: fragment n at byte 1024 n
+    const unsigned long long wbase = (unsigned long long)(reinterpret_cast<const char*>(wq) + (size_t)(head * 8 + wave) * TL::WAVE_FRAGS * 1024);
+    const unsigned wvoff = lane * 16;
+    u32x4 q[6];
+#define QA2_LOAD(slot, n) tail_wload<((n) & 3) * 1024>(q[slot], wvoff, wbase + (unsigned long long)(((n) & ~3) * 1024))
+    QA2_LOAD(0, 0); QA2_LOAD(1, 1); QA2_LOAD(2, 2); QA2_LOAD(3, 3); QA2_LOAD(4, 4); QA2_LOAD(5, 5);
+    DmaPlan<TL> plan;
+    plan.init(wave, lane, [&](int row) { return (unsigned)(row < S ? row : S - 1) * (unsigned)(MST_D * 2); });
+#pragma unroll
+    for (int s = 0; s < 3; s++) plan.issue(smem_base, s, s, xb, xb);
+
+    f32x4 acc[3][NT16];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int t = 0; t < NT16; t++) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // token fragment of tile t, k-step j of a slab: row 16 t + (lane & 15), 16-B chunk 4 j + (lane >> 4)
+    const int r15 = lane & 15, q4 = lane >> 4;
+    const int xoff0 = r15 * 128 + (((0 + q4) ^ (r15 >> 1)) << 4), xoff1 = r15 * 128 + (((4 + q4) ^ (r15 >> 1)) << 4);
+    auto kstep = [&](const char* st, int xo, const u32x4& w0, const u32x4& w1, const u32x4& w2) {
+        const f16x8 a0 = __builtin_bit_cast(f16x8, w0), a1 = __builtin_bit_cast(f16x8, w1), a2 = __builtin_bit_cast(f16x8, w2);
+#pragma unroll
+        for (int t = 0; t < NT16; t++) {
+            const f16x8 xf = *reinterpret_cast<const f16x8*>(st + xo + t * 2048);
+            acc[0][t] = mfma16(a0, xf, acc[0][t]);
+            acc[1][t] = mfma16(a1, xf, acc[1][t]);
+            acc[2][t] = mfma16(a2, xf, acc[2][t]);
+        }
+    };
+    auto slab = [&](auto kt_tag) {
+        constexpr int kt = decltype(kt_tag)::value;
+        constexpr int dprev = (kt >= 1 && kt + 2 < KT) ? P : 0;             // D(kt+2) went out at the end of slab kt-1
+        constexpr int top = kt == 0 ? 2 * P : kt == 1 ? 2 * P + 6 : 12 + P * ((kt + 1 < KT ? 1 : 0) + (kt + 2 < KT ? 1 : 0));
+        constexpr int w0 = kt == 0 ? 3 + 3 * P : 3 + dprev;
+        constexpr int w1 = kt == 0 ? 3 + 3 * P : dprev + (kt + 1 < KT ? 3 : 0);
+        wait_vmcnt<top>();
+        __builtin_amdgcn_s_barrier();
+        const char* st = smem + (kt % TL::NSTAGE) * TL::STAGE;
+        qa_wwait3<w0>(q[0], q[1], q[2]);
+        kstep(st, xoff0, q[0], q[1], q[2]);
+        if constexpr (kt + 1 < KT) { QA2_LOAD(0, 6 * (kt + 1)); QA2_LOAD(1, 6 * (kt + 1) + 1); QA2_LOAD(2, 6 * (kt + 1) + 2); }
+        qa_wwait3<w1>(q[3], q[4], q[5]);
+        kstep(st, xoff1, q[3], q[4], q[5]);
+        if constexpr (kt + 1 < KT) { QA2_LOAD(3, 6 * (kt + 1) + 3); QA2_LOAD(4, 6 * (kt + 1) + 4); QA2_LOAD(5, 6 * (kt + 1) + 5); }
+        if constexpr (kt + 3 < KT) plan.issue(smem_base, kt + 3, kt + 3, xb, xb);
+    };
+    static_assert(KT == 8, "eight slabs, written out");
+    slab(std::integral_constant<int, 0>()); slab(std::integral_constant<int, 1>()); slab(std::integral_constant<int, 2>());
+    slab(std::integral_constant<int, 3>()); slab(std::integral_constant<int, 4>()); slab(std::integral_constant<int, 5>());
+    slab(std::integral_constant<int, 6>()); slab(std::integral_constant<int, 7>());
+#undef QA2_LOAD
+    __builtin_amdgcn_s_barrier();                       // ring dead: the images take its place
+    QA_MARK(1)
+
+    char* ks_img = smem + TL::OFF_K;
+    char* vs_img = smem + TL::OFF_V;
+    char* qs_img = smem + TL::OFF_Q;
+    {
+        const float scale = 0.08838834764831845f;       // 1/sqrt(128), applied to q in fp32 before rounding
+        const float* bias_s = reinterpret_cast<const float*>(smem + TL::OFF_BIAS);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const int f0 = 48 * wave + 16 * i;          // wave-uniform: the 16-row group lies inside q, k or v
+            const int region = f0 >> 7, d = (f0 & 127) + 4 * q4;
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + region * MST_HD + d);
+            if (region == 0) {
+#pragma unroll
+                for (int t = 0; t < NT16; t++) {
+                    const f32x4 v = (acc[i][t] + b4) * scale;
+                    *reinterpret_cast<uint2*>(qs_img + k_off(16 * t + r15, d >> 3) + (d & 7) * 2) = pack4_f16(v[0], v[1], v[2], v[3]);
+                }
+            } else if (region == 1) {
+#pragma unroll
+                for (int t = 0; t < NT16; t++) {
+                    const f32x4 v = acc[i][t] + b4;
+                    *reinterpret_cast<uint2*>(ks_img + k_off(16 * t + r15, d >> 3) + (d & 7) * 2) = pack4_f16(v[0], v[1], v[2], v[3]);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT16; t++) {
+                    const f32x4 v = acc[i][t] + b4;
+                    uint2 vv = pack4_f16(v[0], v[1], v[2], v[3]);
+                    if (16 * t + r15 >= S) vv = make_uint2(0u, 0u);      // key rows beyond S must be zero (P = 0 there, never 0 * garbage)
+                    *reinterpret_cast<uint2*>(vs_img + v_off8(16 * t + r15, d)) = vv;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    QA_MARK(2)
+    if (wave >= NKT) return;
+
+    // ---- attention core (k_attention's; q from its image, natural d order)
+    const int hh = lane >> 5, l31 = lane & 31;
+    const int tok = wave * 32 + l31;                    // this lane's query
+    f16x8 qf[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++) qf[s] = *reinterpret_cast<const f16x8*>(qs_img + k_off(tok, 2 * s + hh));
+    f32x16 sc[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; kt++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) sc[kt][r] = 0.f;
+        const int row = kt * 32 + l31;
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            f16x8 kf = *reinterpret_cast<const f16x8*>(ks_img + k_off(row, 2 * s + hh));
+            sc[kt] = mfma_f16(kf, qf[s], sc[kt]);
+        }
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; kt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float v = sc[kt][r];
+            if (kt == NKT - 1) {
+                int key = kt * 32 + mfma_row(r, lane);
+                if (key >= S) v = -INFINITY;
+            }
+            sc[kt][r] = v;
+            m = fmaxf(m, v);
+        }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; kt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float p = __expf(sc[kt][r] - m);
+            sc[kt][r] = p;
+            l += p;
+        }
+    l += __shfl_xor(l, 32);
+    const float inv_l = 1.0f / l;
+    QA_MARK(3)
+    f16x8 pf[NKT][2];
+#pragma unroll
+    for (int kt = 0; kt < NKT; kt++)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) pf[kt][s2][j] = (f16)sc[kt][8 * s2 + j];
+
+    const int i16 = lane & 15, g16 = lane >> 4;
+    const int key_lane = 4 * hh + (i16 >> 2);
+    const int d_lane = 16 * (g16 & 1) + 4 * (i16 & 3);
+    const int q_ld = tok < S ? tok : S - 1;
+    f16* orow = out + ((size_t)clip * S + q_ld) * MST_D + head * MST_HD;
+#pragma unroll
+    for (int dt = 0; dt < 4; dt++) {
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; kt++)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) {
+                int key = kt * 32 + 16 * s2 + key_lane;
+                int d = dt * 32 + d_lane;
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vs_img + v_off8(key, d)));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vs_img + v_off8(key + 8, d)));
+                const f16x4 lo_h = __builtin_bit_cast(f16x4, lo), hi_h = __builtin_bit_cast(f16x4, hi);
+                f16x8 vf = __builtin_shufflevector(lo_h, hi_h, 0, 1, 2, 3, 4, 5, 6, 7);
+                o = mfma_f16(vf, pf[kt][s2], o);
+            }
+        if (tok < S) {
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                int dd = dt * 32 + 8 * gq + 4 * hh;
+                *reinterpret_cast<uint2*>(orow + dd) =
+                    pack4_f16(o[4 * gq] * inv_l, o[4 * gq + 1] * inv_l, o[4 * gq + 2] * inv_l, o[4 * gq + 3] * inv_l);
+            }
+        }
+    }
+    QA_MARK(4)
 }
 
 }  // namespace mst

@@ -59,6 +59,18 @@ template <int HI> __device__ __forceinline__ float sub_half(unsigned packed, flo
     else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(packed), "v"(acc));
     return d;
 }
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// One weight fragment: issued and counted by hand.  hipcc would batch plain loads (all D at the end of an unrolled pass,
+// vmcnt(0) at its head) and expose the L2 latency once per pass; it also cannot count loads it does not see, so NO
+// compiler-visible global load or store may be issued between a fragment's load and its wait (cdna guide 5.7 item 1) -- the
+// kernels that stream (mst_tail.h, mst_attn.h) keep theirs behind `tail_fence()`, where every outstanding fragment is OLDER than anything hipcc then counts.
+template <int OFF> __device__ __forceinline__ void tail_wload(u32x4& d, unsigned voff, unsigned long long sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(d) : "v"(voff), "s"(sbase), "n"(OFF));
+}
+template <int N> __device__ __forceinline__ void tail_wwait(u32x4& d) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(d) : "n"(N)); }
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
 // y -> (hi, lo) f16 pairs with hi = f16(y), lo = f16(y - hi): the stream's storage format (~22 significant bits)
 __device__ __forceinline__ void split4_f16(const f32x4& y, uint2& hi, uint2& lo) {
     f16x4 h = {(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};

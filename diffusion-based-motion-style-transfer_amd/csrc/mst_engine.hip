@@ -121,6 +121,7 @@ struct LayerW {
     // [in][out] f16 copies: the "weights" operand of the dgrad GEMMs (training path)
     f16 *w_inT = nullptr, *w_outT = nullptr, *w1T = nullptr, *w2T = nullptr;
     f16* wtail = nullptr;           // W_out | W1 | W2 as the fused layer tail's slab stream (mst_tail.h, k_pack_tail)
+    f16* wqkv = nullptr;            // W_in as the fused QKV+attention kernel's per-(head, wave) fragment streams (mst_attn.h, k_pack_qkv)
 };
 
 // engine-owned scratch of the backward pass, allocated on the first training call
@@ -284,6 +285,7 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
         CHECK(dmalloc(&w.w1T, (size_t)MST_FF * MST_D));
         CHECK(dmalloc(&w.w2T, (size_t)MST_D * MST_FF));
         CHECK(dmalloc(&w.wtail, TailCfg::LAYER_BYTES / 2));
+        CHECK(dmalloc(&w.wqkv, (size_t)3 * MST_D * MST_D));
     }
     CHECK(dmalloc(&e->w_pose_in, (size_t)MST_D * e->kin_pad));
     CHECK(dmalloc(&e->b_pose_in, MST_D));
@@ -331,7 +333,7 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
         int n = atoi(v);
         e->nsplit = n < 1 ? 1 : (n > 3 ? 3 : n);
     }
-    if (const char* v = getenv("MST_FUSE_QKV_ATTN")) e->fuse_qkv_attn = atoi(v) != 0;
+    if (const char* v = getenv("MST_FUSE_QKV_ATTN")) e->fuse_qkv_attn = atoi(v);
     if (const char* v = getenv("MST_FUSE_TAIL")) e->fuse_tail = atoi(v) != 0;
     if (const char* v = getenv("MST_FUSE_FRAMES")) e->fuse_frames = atoi(v) != 0;
     if (const char* v = getenv("MST_WGRAD_STREAM")) e->wgrad_stream_on = atoi(v) != 0;
@@ -356,7 +358,7 @@ extern "C" void mst_engine_destroy(mst_engine* e) {
     for (int l = 0; l < e->cfg.num_layers; l++) {
         LayerW& w = e->L[l];
         void* p[] = {w.w_in, w.w_out, w.w1, w.w2, w.b_in, w.b_out, w.b1, w.b2, w.g1, w.be1, w.g2, w.be2,
-                     w.w_inT, w.w_outT, w.w1T, w.w2T, w.wtail};
+                     w.w_inT, w.w_outT, w.w1T, w.w2T, w.wtail, w.wqkv};
         for (void* q : p) (void)hipFree(q);
     }
     {
@@ -443,6 +445,10 @@ extern "C" int mst_load_weight(mst_engine* e, const char* name, const float* src
         VEC("norm2.bias", MST_D, w.be2)
 #undef MAT
 #undef VEC
+        if (rc == 0 && r == "self_attn.in_proj_weight") {
+            hipLaunchKernelGGL(k_pack_qkv, dim3(384), dim3(256), 0, st, w.w_in, w.wqkv);
+            HIPCHECK(hipGetLastError());
+        }
         if (rc == 0 && repack) {      // the fused layer tail reads W_out | W1 | W2 as one pre-packed slab stream (same stream: ordered behind the conversion)
             hipLaunchKernelGGL(k_pack_tail, dim3(640), dim3(256), 0, st, w.w_out, w.w1, w.w2, w.wtail);
             HIPCHECK(hipGetLastError());
@@ -632,6 +638,31 @@ static int launch_qkv_attn(const f16* hx, const f16* w_in, const float* b_in, f1
     return fail("attention: S=%d unsupported", S);
 }
 
+template <int NT16>
+static int launch_qkv_attn2_n(const f16* hx, const f16* wq, const float* b_in, f16* out, int S, int rows, hipStream_t st) {
+    auto kern = k_qkv_attention2<NT16>;
+    constexpr int smem = QA2Tile<NT16>::SMEM;
+    CHECK(ensure_dyn_lds((const void*)kern, smem));
+    hipLaunchKernelGGL(kern, dim3(rows * MST_H), dim3(512), smem, st, hx, wq, b_in, out, S);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+// The role-swapped kernel holds K, V and Q images of 16 ceil(S / 16) rows in LDS: up to S = 208 (the model's 196 frames + 1).
+static bool qkv_attn2_fits(int S) { return S <= 208; }
+static int launch_qkv_attn2(const f16* hx, const f16* wq, const float* b_in, f16* out, int S, int rows, hipStream_t st) {
+    const int n16 = (S + 15) / 16;
+    switch (n16 == 13 ? 13 : (n16 + 1) / 2 * 2) {
+        case 2: return launch_qkv_attn2_n<2>(hx, wq, b_in, out, S, rows, st);
+        case 4: return launch_qkv_attn2_n<4>(hx, wq, b_in, out, S, rows, st);
+        case 6: return launch_qkv_attn2_n<6>(hx, wq, b_in, out, S, rows, st);
+        case 8: return launch_qkv_attn2_n<8>(hx, wq, b_in, out, S, rows, st);
+        case 10: return launch_qkv_attn2_n<10>(hx, wq, b_in, out, S, rows, st);
+        case 12: return launch_qkv_attn2_n<12>(hx, wq, b_in, out, S, rows, st);
+        case 13: return launch_qkv_attn2_n<13>(hx, wq, b_in, out, S, rows, st);
+    }
+    return fail("attention: S=%d unsupported", S);
+}
+
 static int launch_attn(const f16* qkv, f16* out, int S, int rows, hipStream_t st, int qsplit = 0, f16* out_lo = nullptr) {
     switch ((S + 31) / 32) {
         case 1: return launch_attn_n<1>(qkv, out, S, rows, st, qsplit, out_lo);
@@ -782,7 +813,10 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
         const LayerW& w = e->L[l];
         if (e->fuse_qkv_attn && !(e->dbg_layer == l && e->dbg_stage == 1)) {
             ProfScope ps(e, FAM_QKV_ATTN, st);
-            CHECK(launch_qkv_attn(ws.hx, w.w_in, w.b_in, ws.att, S, rows, st));
+            // 1 (default): weights streamed to registers, tokens through the ring; 2: round 2's kernel (both operands through the ring),
+            // which also takes S = 209..224
+            if (e->fuse_qkv_attn == 1 && qkv_attn2_fits(S)) CHECK(launch_qkv_attn2(ws.hx, w.wqkv, w.b_in, ws.att, S, rows, st));
+            else CHECK(launch_qkv_attn(ws.hx, w.w_in, w.b_in, ws.att, S, rows, st));
         } else {
             {
                 ProfScope ps(e, FAM_QKV, st);

@@ -36,8 +36,6 @@
 
 namespace mst {
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
 struct TailCfg {
     static constexpr int BT = 64;                        // tokens per workgroup
     static constexpr int D = 16;                         // weight fragments in flight per wave (64 VGPRs; 128 KB per CU).  8 measures the same (43.2 vs 43.1 us)
@@ -90,14 +88,6 @@ __global__ __launch_bounds__(256) void k_pack_tail(const f16* __restrict__ w_out
     }
 }
 
-// One weight fragment: issued and counted by hand.  hipcc would batch plain loads (all D at the end of an unrolled pass,
-// vmcnt(0) at its head) and expose the L2 latency once per pass; it also cannot count loads it does not see, so NO
-// compiler-visible global load or store may be issued between a fragment's load and its wait (cdna guide 5.7 item 1) -- the
-// phases below keep theirs behind `tail_fence()`, where every outstanding fragment is OLDER than anything hipcc then counts.
-template <int OFF> __device__ __forceinline__ void tail_wload(u32x4& d, unsigned voff, unsigned long long sbase) {
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(d) : "v"(voff), "s"(sbase), "n"(OFF));
-}
-template <int N> __device__ __forceinline__ void tail_wwait(u32x4& d) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(d) : "n"(N)); }
 __device__ __forceinline__ void tail_fence() { asm volatile("" ::: "memory"); }
 __device__ __forceinline__ void tail_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }   // LDS only: the stream stays in flight
 
@@ -109,8 +99,6 @@ __device__ __forceinline__ float gelu_tab_lds(float x, const char* tab) {
     const float2 e = *reinterpret_cast<const float2*>(tab + ((unsigned)u << 3));
     return x * fmaf(e.y, __builtin_amdgcn_fractf(u), e.x);
 }
-
-__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
 __device__ __forceinline__ void tail_glds1(unsigned voff, unsigned long long sbase, unsigned lds_dst) {
     unsigned keep;

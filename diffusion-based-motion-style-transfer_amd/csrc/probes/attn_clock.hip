@@ -25,14 +25,17 @@ int main(int argc, char** argv) {
     hipMemcpy(hx, h.data(), nx * 2, hipMemcpyHostToDevice);
     hipMemcpy(w, h.data(), (size_t)3 * MST_D * MST_D * 2, hipMemcpyHostToDevice);
     hipMemset(b, 0, 3 * MST_D * 4);
-    auto kern = k_qkv_attention<NKT>;
-    using TL = QATile<NKT>;
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TL::SMEM);
+    // attn_clock [B] [1]: a second argument times round 2's kernel (weights through the ring) instead of the role-swapped one
+    const bool old = argc > 2 && atoi(argv[2]) == 1;
+    auto kern = old ? k_qkv_attention<NKT> : k_qkv_attention2<13>;
+    const int SMEM = old ? QATile<NKT>::SMEM : QA2Tile<13>::SMEM;
+    printf("%s\n", old ? "k_qkv_attention<7> (round 2)" : "k_qkv_attention2<13>");
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; rep++) {
         const int iters = rep == 0 ? 200 : 40000;        // rep 0: cold; rep 1, 2: ~1.4 s each, sustained
         hipEventRecord(e0);
-        for (int i = 0; i < iters; i++) hipLaunchKernelGGL(kern, dim3(B * MST_H), dim3(512), TL::SMEM, 0, hx, w, b, out, S);
+        for (int i = 0; i < iters; i++) hipLaunchKernelGGL(kern, dim3(B * MST_H), dim3(512), SMEM, 0, hx, w, b, out, S);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         static unsigned long long st[1024][10];
