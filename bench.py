@@ -47,7 +47,7 @@ D, FF, H = 512, 1024, 4
 SYMBOL = {
     "outproj_ln_gemm": "k_gemm_dma<64,512,2,2,2,1,RowsDirect,DEpiResidLN,64>",
     "ffn2_ln_gemm": "k_gemm_dma<64,512,2,2,2,1,RowsDirect,DEpiResidLN,64>",
-    "qkv_attention_fused": "k_qkv_attention<7>",
+    "qkv_attention_fused": "k_qkv_attention2<13>",
     "ffn1_gelu_gemm": "k_gemm_dma<128,256,2,2,3,1,RowsDirect,DEpiBiasF16<true>,32>",
     "layer_tail_fused": "k_layer_tail",
     "embed_out_step": "k_gemm_dma<64,512,2,2,4,NX,RowsFrames,DEpiEmbedOut<1>,32>",

@@ -571,6 +571,10 @@ __global__ __launch_bounds__(512) void k_qkv_attention2(const f16* __restrict__ 
             acc[1][t] = mfma16(a1, xf, acc[1][t]);
             acc[2][t] = mfma16(a2, xf, acc[2][t]);
         }
+        // (Measured and rejected: pinning the issue order with sched_group_barrier so that four token fragments are read ahead of
+        // their MFMAs -- hipcc keeps two in flight -- makes the projection 14.6 -> 13.7 us in the back-to-back probe and the 64-clip
+        // loop 2 % SLOWER: this kernel 26.0 -> 26.5 us, the layer tail behind it 43.8 -> 44.8 us.  The package is at its power
+        // limit; stalls removed without work removed are paid back in clock.)
     };
     auto slab = [&](auto kt_tag) {
         constexpr int kt = decltype(kt_tag)::value;

@@ -74,6 +74,25 @@ def test_forward_and_loop_on_ragged_shapes(F, T, B):
         assert np.array_equal(got.cpu().numpy()[m], motion[m])
 
 
+@pytest.mark.parametrize("T", [15, 40, 100, 127, 150, 191, 196, 207, 208, 223])
+def test_fused_qkv_attention_every_tile_count(T, monkeypatch):
+    """The large-tile path's fused QKV + attention kernel is instantiated per token-tile count (16-token tiles: 2, 4, .. 12, 13 for
+    S = T + 1 <= 208; S = 209..224 falls back to round 2's kernel, whose 32-row images fit those): one forward per instantiation
+    against the oracle, with the small-tile path switched off so that two clips take it."""
+    from oracle import denoiser
+    monkeypatch.setenv("MST_SMALL_M", "0")
+    F, B = 263, 2
+    eng, w, pe = make(F, T, B)
+    x = syn.normal(SEED, f"xq{T}", (B, F, 1, T))
+    txt = syn.normal(SEED, "txtq", (B, 512))
+    t = np.array([17, 803])
+    eng.set_text(cu(txt))
+    out = eng.forward(cu(x), cu(t)).cpu().numpy()
+    err = rel_l2(out, denoiser.forward(w, pe, x, t, txt).numpy())
+    print(f"fused QKV+attention at S = {T + 1}: {err:.3e}")
+    assert err < TOL
+
+
 def test_odd_batch_across_the_two_slices_equals_single_slice():
     """Batch 17 is split 9 + 8 over two streams (8-clip minimum per slice); results must not depend on the split."""
     from mst_amd.engine import Schedule, SAMPLER_DDPM

@@ -2,7 +2,7 @@
 import csv, glob, sys, collections, re
 def short(n):
     n = re.sub(r"^_ZN3mst\d+", "", n)
-    for a, b in (("k_qkv_attentionILi7E", "qkv_attention_fused"), ("k_layer_tail", "layer_tail_fused"), ("k_gemm_dmaILi64ELi512ELi2ELi2ELi4ELi1ENS_10RowsDirectENS_11DEpiResidLNE", "gemm_ln(outproj/ffn2)"), ("DEpiBiasF16ILb1E", "ffn1_gelu_gemm"),
+    for a, b in (("k_qkv_attention", "qkv_attention_fused"), ("k_layer_tail", "layer_tail_fused"), ("k_gemm_dmaILi64ELi512ELi2ELi2ELi4ELi1ENS_10RowsDirectENS_11DEpiResidLNE", "gemm_ln(outproj/ffn2)"), ("DEpiBiasF16ILb1E", "ffn1_gelu_gemm"),
                  ("DEpiEmbedInE", "embed_in_gemm"), ("DEpiEmbedOutILi1E", "embed_out_ddpm_step")):
         if a in n: return b
     return n[:40]
