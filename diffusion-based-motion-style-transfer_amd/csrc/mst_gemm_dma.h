@@ -590,44 +590,84 @@ struct DEpiEmbedOut {
         const bool use_noise = !sa.philox && sa.noise != nullptr;
         const bool vec = (T & 3) == 0;                       // 4 consecutive frames never straddle a clip
         constexpr int TG = BT / 4;
+        if (vec && MODE != 0) {
+            // Three items per thread and pass, loads first: one item at a time the loop is a chain of dependent global loads (x, the row
+            // flag, then mask / motion) per iteration, nine iterations deep at F = 263 -- latency, not bandwidth.
+            constexpr int U = 3;
+            for (int it0 = threadIdx.x; it0 < F * TG; it0 += 512 * U) {
+                bool ok[U];
+                int fu[U], tgu[U], clipu[U], tu[U], rf[U];
+                size_t idx[U];
+                float bu[U];
+                f32x4 xv[U], nz[U], mk[U], mot[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int it = it0 + 512 * u;
+                    fu[u] = it / TG;
+                    tgu[u] = it - fu[u] * TG;
+                    const int tok = tok0 + tgu[u] * 4;
+                    ok[u] = it < F * TG && tok < total;
+                    clipu[u] = tok / T;
+                    tu[u] = tok - clipu[u] * T;
+                    idx[u] = ((size_t)clipu[u] * F + fu[u]) * T + tu[u];
+                    xv[u] = nz[u] = mk[u] = mot[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    rf[u] = 2;                                          // 0: mask row all zeros, 1: all ones, 2: read it
+                    bu[u] = 0.f;
+                    if (ok[u]) {
+                        xv[u] = *reinterpret_cast<const f32x4*>(sa.x + idx[u]);
+                        if (sa.rowflag) rf[u] = sa.rowflag[clipu[u] * F + fu[u]];
+                        bu[u] = bias[fu[u]];
+                        if (use_noise) nz[u] = *reinterpret_cast<const f32x4*>(sa.noise + idx[u]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    if (!ok[u]) continue;
+                    if (use_mask) {
+                        if (rf[u] == 2) mk[u] = *reinterpret_cast<const f32x4*>(sa.mask + idx[u]);
+                        else if (rf[u] == 1) mk[u] = f32x4{1.f, 1.f, 1.f, 1.f};
+                    }
+                    if (blend && rf[u] != 0) mot[u] = *reinterpret_cast<const f32x4*>(sa.motion + idx[u]);   // mask 0: motion * 0 is +-0 whatever it holds
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    if (!ok[u]) continue;
+                    const f32x4 acc4 = *reinterpret_cast<const f32x4*>(tile + fu[u] * LDT + tgu[u] * 4);
+                    f32x4 mo;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) mo[j] = acc4[j] + bu[u];
+                    if (sa.philox) {
+                        float nrm[4];
+                        philox_normal4((unsigned)(tu[u] >> 2), (unsigned)fu[u], (unsigned)clipu[u] + sa.clip0, sa.step, sa.seed, nrm);
+#pragma unroll
+                        for (int j = 0; j < 4; j++) nz[u][j] = nrm[j];
+                    }
+                    f32x4 nx, pred;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        float p;
+                        nx[j] = step_update<MODE == 2 ? 1 : 0>(sc, mo[j], xv[u][j], nz[u][j], blend, mk[u][j], mot[u][j], sa.mask_noise && use_mask, sa.clip, &p);
+                        pred[j] = p;
+                    }
+                    *reinterpret_cast<f32x4*>(sa.sample + idx[u]) = nx;
+                    if (sa.xstart) *reinterpret_cast<f32x4*>(sa.xstart + idx[u]) = pred;
+                    if (xt_next) *reinterpret_cast<f32x4*>(tile + fu[u] * LDT + tgu[u] * 4) = nx;      // this item's own slot of the tile
+                }
+            }
+        } else
         for (int it = threadIdx.x; it < F * TG; it += 512) {
             const int f = it / TG, tg = it - f * TG;
             const int tok = tok0 + tg * 4;
             if (tok >= total) continue;
             const f32x4 acc4 = *reinterpret_cast<const f32x4*>(tile + f * LDT + tg * 4);
             const float b = bias[f];
-            if (vec) {
+            if (vec) {                                                  // MODE 0: the plain output projection
                 const int clip = tok / T, t = tok - clip * T;
                 const size_t idx = ((size_t)clip * F + f) * T + t;
                 f32x4 mo;
 #pragma unroll
                 for (int j = 0; j < 4; j++) mo[j] = acc4[j] + b;
-                if (MODE == 0) { *reinterpret_cast<f32x4*>(out + idx) = mo; continue; }
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(sa.x + idx);
-                f32x4 mk = {0.f, 0.f, 0.f, 0.f}, mot = mk, nz = mk;
-                const int rf = sa.rowflag ? sa.rowflag[clip * F + f] : 2;      // 0: mask row all zeros, 1: all ones, 2: read it
-                if (use_mask) {
-                    if (rf == 2) mk = *reinterpret_cast<const f32x4*>(sa.mask + idx);
-                    else if (rf == 1) mk = f32x4{1.f, 1.f, 1.f, 1.f};
-                }
-                if (blend && rf != 0) mot = *reinterpret_cast<const f32x4*>(sa.motion + idx);   // mask 0: motion * 0 is +-0 whatever it holds
-                if (use_noise) nz = *reinterpret_cast<const f32x4*>(sa.noise + idx);
-                if (sa.philox) {
-                    float nrm[4];
-                    philox_normal4((unsigned)(t >> 2), (unsigned)f, (unsigned)clip + sa.clip0, sa.step, sa.seed, nrm);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) nz[j] = nrm[j];
-                }
-                f32x4 nx, pred;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    float p;
-                    nx[j] = step_update<MODE == 2 ? 1 : 0>(sc, mo[j], xv[j], nz[j], blend, mk[j], mot[j], sa.mask_noise && use_mask, sa.clip, &p);
-                    pred[j] = p;
-                }
-                *reinterpret_cast<f32x4*>(sa.sample + idx) = nx;
-                if (sa.xstart) *reinterpret_cast<f32x4*>(sa.xstart + idx) = pred;
-                if (MODE != 0 && xt_next) *reinterpret_cast<f32x4*>(tile + f * LDT + tg * 4) = nx;      // this item's own slot of the tile
+                *reinterpret_cast<f32x4*>(out + idx) = mo;
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {

@@ -126,38 +126,39 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
     //      operand: a 16-lane group reads 16 rows at chunks {c, c ^ 1} -> 16 distinct slots of the 256-B bank row).  LDS-DMA writes
     //      lane-linearly, so the swizzle is on the per-lane SOURCE address; wave w fills rows [8 w, 8 w + 8);
     //  (2) the FFN1 bias (4 KB, waves 0..3) and the GELU stage's Phi table (13 KB): both are read from LDS;
-    //  (3) LayerNorm1's residual, the stream rows of the tile.  LayerNorm1 runs in the ACCUMULATOR layout (no transposition through an
-    //      fp32 scratch: that was 700 KB of LDS traffic per tile, 6 us), so the residual is needed as (token, 4 features) pieces per
-    //      lane: the rows are staged in [OFF_X1, +64 KB) in the same image layout as att and read with 8-byte LDS loads.  hi + lo
-    //      is 128 KB and the att image is alive until the loop ends, so the two halves take turns: lo is requested in front of the loop's first pass
-    //      and added to the accumulators after its second, hi follows into the same 64 KB during the last two and is added behind the loop; LayerNorm1's x1 image then overwrites hi slot by slot, each slot by the lane that read it.
+    // LayerNorm1's residual for the tile's first 32 tokens is staged by LDS-DMA too (stream rows hi -> [OFF_X1, +32 KB), lo ->
+    // [OFF_X1 + 32 KB, +32 KB), row-linear, wave w its own LN1 rows [4 w, 4 w + 4)) -- but at the start of the out-proj loop's LAST
+    // pass, not here: in this burst its 64 KB per tile (12.9 MB per launch) delayed the first MFMA by 1.5 us, and requested after the
+    // loop these rows cost ~3 us of exposed latency (the loads queue behind 128 KB of prefetched fragments and then miss L2).  The
+    // second half's rows are requested after the loop, into registers, and land while the first half is normalised.  The x1 image
+    // later overwrites the staging area row by row, each row by the wave that consumed it.
     float* b1s = reinterpret_cast<float*>(smem + C::OFF_B1);
     const char* const gtab = smem + C::OFF_TAB;
     unsigned* const arrived = reinterpret_cast<unsigned*>(smem + C::OFF_CNT);      // [chunk]: waves whose GELU output of that chunk is in the H image
-    if (tid < 4) arrived[tid] = 0;                                                  // published by the barriers in front of the out-proj loop
-    // residual rows of the tile -> [OFF_X1, +64 KB) in the att / x1 image layout; wave w fills rows [8 w, 8 w + 8)
-    auto stage_rows = [&](const f16* src) {
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int r = 8 * wave + j;
-            int tok = tok0 + r;
-            if (tok >= M) tok = M - 1;                                // last tile: clamp (rows beyond M are never stored)
-            const unsigned voff = (unsigned)tok * (unsigned)(MST_D * 2) + (unsigned)((lane ^ (r & 15)) << 4);
-            tail_glds1(voff, (unsigned long long)src, __builtin_amdgcn_readfirstlane(smem_base + C::OFF_X1 + r * 1024));
-        }
-    };
-    constexpr int ROW_OPS = 8;
+    if (tid < 4) arrived[tid] = 0;                                                  // published by the barrier in front of the out-proj loop
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const int r = 8 * wave + j;
         int tok = tok0 + r;
-        if (tok >= M) tok = M - 1;
+        if (tok >= M) tok = M - 1;                                    // last tile: clamp (rows beyond M are never stored)
         const unsigned voff = (unsigned)tok * (unsigned)(MST_D * 2) + (unsigned)((lane ^ (r & 15)) << 4);
         tail_glds1(voff, (unsigned long long)att, __builtin_amdgcn_readfirstlane(smem_base + C::OFF_ATT + r * 1024));
     }
     if (wave < 4) tail_glds1((unsigned)lane * 16u, (unsigned long long)(b1 + 256 * wave), __builtin_amdgcn_readfirstlane(smem_base + C::OFF_B1 + 1024 * wave));
     tail_glds1((unsigned)lane * 16u, (unsigned long long)(gelu_tab + 256 * wave), __builtin_amdgcn_readfirstlane(smem_base + C::OFF_TAB + 1024 * wave));
     if (wave < 5) tail_glds1((unsigned)lane * 16u, (unsigned long long)(gelu_tab + 256 * (8 + wave)), __builtin_amdgcn_readfirstlane(smem_base + C::OFF_TAB + 1024 * (8 + wave)));
+    auto stage_residual = [&]() {                                     // 8 LDS-DMA pieces per wave: its LN1 rows [4 w, 4 w + 4) of the first half, hi and lo
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int tok = tok0 + 4 * wave + r;
+            if (tok >= M) tok = M - 1;
+            const unsigned voff = (unsigned)tok * (unsigned)(MST_D * 2) + (unsigned)lane * 16u;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + C::OFF_X1 + (4 * wave + r) * 1024);
+            tail_glds1(voff, (unsigned long long)hx, dst);
+            tail_glds1(voff, (unsigned long long)hl, dst + 32768);
+        }
+    };
+    constexpr int RES_OPS = 8;
 
     // ---- the weight stream of this wave
     const unsigned w_voff = (unsigned)lane * 16u;
@@ -245,127 +246,114 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
     using LD0 = std::integral_constant<int, 0>;
 
     // =========================================================================================== phase P: out-proj
-    // accumulator slot (nh, rb, tb) of this lane in an image with 1-KB rows: token row 16 tb + t16, features 256 nh + 32 w + 16 rb + 4 q4 .. + 3
-    // = 8-byte half (q4 & 1) of 16-byte chunk 32 nh + 4 w + 2 rb + (q4 >> 1), stored at chunk ^ (row & 15)
-    auto slot1k = [&](int nh, int rb, int tb) {
-        return (unsigned)((16 * tb + t16) * 1024 + (((32 * nh + 4 * wave + 2 * rb + (q4 >> 1)) ^ t16) << 4) + 8 * (q4 & 1));
-    };
 #pragma unroll
     for (int nh = 0; nh < 2; nh++)
 #pragma unroll
         for (int rb = 0; rb < 2; rb++)
 #pragma unroll
             for (int tb = 0; tb < 4; tb++) acc[nh][rb][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D + 1) : "memory");       // this wave's att rows have landed (behind them: 1 .. 3 table pieces and the D fragments)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D) : "memory");          // this wave's att rows have landed (the D fragments behind them may fly on)
     tail_barrier();                                                    // ... and everybody's
     TAIL_MARK(1)
     {
         const char* img = smem + C::OFF_ATT;
         xread(img, RB1K(), 0, xs[0]);
         constexpr int NPP = C::P_FRAG / D;
-        static_assert(NPP == 4, "passes 0 | 1: the lo rows land, 2 | 3: the hi rows");
-        // Neither half of the residual is part of the kernel-start burst: there, 64 KB more in front of (or behind) the att image
-        // delay the first MFMA by 1.5 us (measured both ways).  Requested in front of a pass, the rows travel beside the weight stream.
-        stage_rows(hl);
-        pass(img, RB1K(), RA4(), std::integral_constant<int, 1 + 2 * ROW_OPS>(), 0, true, [](int) {});
-        pass(img, RB1K(), RA4(), LD1(), D / 4, true, [](int) {});
-        // the lo rows are older than the fragments requested by pass 0, which pass 1 has consumed: landed
-        tail_barrier();
-        {
-            const char* stg = smem + C::OFF_X1;
-#pragma unroll
-            for (int nh = 0; nh < 2; nh++)
-#pragma unroll
-                for (int rb = 0; rb < 2; rb++)
-#pragma unroll
-                    for (int tb = 0; tb < 4; tb++) {
-                        const uint2 l = *reinterpret_cast<const uint2*>(stg + slot1k(nh, rb, tb));
-                        f32x4& a = acc[nh][rb][tb];
-                        a = f32x4{add_half<0>(l.x, a[0]), add_half<1>(l.x, a[1]), add_half<0>(l.y, a[2]), add_half<1>(l.y, a[3])};
-                    }
-        }
-        tail_barrier();                                                // everybody has read lo: hi may overwrite it
-        stage_rows(hx);
-        pass(img, RB1K(), RA4(), std::integral_constant<int, 1 + 2 * ROW_OPS>(), 2 * (D / 4), true, [](int) {});
-        pass(img, RB1K(), RA4(), LD1(), 3 * (D / 4), false, [](int) {});
+#pragma unroll 1
+        for (int ps = 0; ps + 1 < NPP; ps++) pass(img, RB1K(), RA4(), LD1(), ps * (D / 4), true, [](int) {});
+        stage_residual();
+        pass(img, RB1K(), RA4(), std::integral_constant<int, 1 + 2 * RES_OPS>(), (NPP - 1) * (D / 4), false, [](int) {});
     }
     TAIL_MARK(2)
 
-    // =========================================================================================== LayerNorm1 (accumulator layout)
-    // A lane holds, for each of its four tokens (tb), 16 of the row's 512 values; a wave holds 64 (its 2 x 2 x 16 features).  Row statistics:
-    // two-pass mean / M2 over the wave's 64 values (in-lane + the three other q4 groups), then the eight waves' (mean, M2) pairs
-    // meet in LDS and are merged exactly (M2 = sum M2_w + 64 sum (mean_w - mean)^2).  The normalised row stays in the accumulators as
-    // FFN2's initial value (the x1 residual of LayerNorm2) and goes to the x1 image as f16, the FFN1 operand.
+    // =========================================================================================== LayerNorm1
+    // Rows of this wave in a half: 4 w + r, r < 4; a lane holds features [4 lane, +4) and [256 + 4 lane, +4) of each.
     tail_fence();
-    tail_barrier();                                                    // every wave's hi rows are in place (each waited for its own fragments behind them); att is dead
+    tail_barrier();                                                    // every wave is done with the att image: the scratch overlays it
     {
+        const int fa = lane * 4, fb = 256 + lane * 4;
+        const f32x4 ba = *reinterpret_cast<const f32x4*>(b_out + fa), bb = *reinterpret_cast<const f32x4*>(b_out + fb);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(g1 + fa), gb = *reinterpret_cast<const f32x4*>(g1 + fb);
+        const f32x4 ea = *reinterpret_cast<const f32x4*>(be1 + fa), eb = *reinterpret_cast<const f32x4*>(be1 + fb);
         char* x1img = smem + C::OFF_X1;
-        float2* exch = reinterpret_cast<float2*>(smem + C::OFF_ATT);   // [token][wave]
-        float mw[4], m2[4];
+        // the stream rows (hi + lo) of the second half: requested now, consumed after the first half (its rows wait in LDS)
+        uint2 rh_a[4], rl_a[4], rh_b[4], rl_b[4];
 #pragma unroll
-        for (int nh = 0; nh < 2; nh++)
+        for (int r = 0; r < 4; r++) {
+            const int tok = tok0 + 32 + 4 * wave + r;
+            const size_t off = (size_t)(tok < M ? tok : M - 1) * MST_D;
+            rh_a[r] = *reinterpret_cast<const uint2*>(hx + off + fa);
+            rl_a[r] = *reinterpret_cast<const uint2*>(hl + off + fa);
+            rh_b[r] = *reinterpret_cast<const uint2*>(hx + off + fb);
+            rl_b[r] = *reinterpret_cast<const uint2*>(hl + off + fb);
+        }
 #pragma unroll
-            for (int rb = 0; rb < 2; rb++) {
-                const f32x4 bo = *reinterpret_cast<const f32x4*>(b_out + 256 * nh + 32 * wave + 16 * rb + 4 * q4);
+        for (int m = 0; m < 2; m++) {
+            // accumulators of token blocks 2 m, 2 m + 1 -> scratch rows [0, 32)
 #pragma unroll
-                for (int tb = 0; tb < 4; tb++) {
-                    const uint2 h = *reinterpret_cast<const uint2*>(x1img + slot1k(nh, rb, tb));
-                    const f32x4 a = acc[nh][rb][tb] + bo;
-                    acc[nh][rb][tb] = f32x4{add_half<0>(h.x, a[0]), add_half<1>(h.x, a[1]), add_half<0>(h.y, a[2]), add_half<1>(h.y, a[3])};
-                }
+            for (int tbl = 0; tbl < 2; tbl++) {
+                char* trow = smem + (16 * tbl + t16) * C::LN_LD;
+#pragma unroll
+                for (int nh = 0; nh < 2; nh++)
+#pragma unroll
+                    for (int rb = 0; rb < 2; rb++)
+                        *reinterpret_cast<f32x4*>(trow + (256 * nh + 32 * wave + 16 * rb + 4 * q4) * 4) = acc[nh][rb][2 * m + tbl];
             }
-        auto quad_sum = [](float v) {                                  // over the four q4 groups (lanes l, l ^ 16, l ^ 32, l ^ 48)
-            v += __shfl_xor(v, 16);
-            return v + __shfl_xor(v, 32);
-        };
+            tail_barrier();
+            TAIL_MARK(6 + 3 * m)
+            f32x4 xa[4], xb[4];
+            float mean[4], rstd[4];
 #pragma unroll
-        for (int tb = 0; tb < 4; tb++) {
-            f32x4 t = (acc[0][0][tb] + acc[0][1][tb]) + (acc[1][0][tb] + acc[1][1][tb]);
-            mw[tb] = quad_sum((t[0] + t[1]) + (t[2] + t[3])) * (1.0f / 64.0f);
-        }
-#pragma unroll
-        for (int tb = 0; tb < 4; tb++) {
-            f32x4 sq = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int nh = 0; nh < 2; nh++)
-#pragma unroll
-                for (int rb = 0; rb < 2; rb++) {
-                    const f32x4 d = acc[nh][rb][tb] - mw[tb];
-                    sq += d * d;
+            for (int r = 0; r < 4; r++) {
+                const char* srow = smem + (4 * wave + r) * C::LN_LD;
+                if (m == 0) {
+                    // this wave's staged rows: requested before the D fragments now in flight (whatever hipcc has issued since is younger still)
+                    if (r == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D) : "memory");
+                    const char* stg = x1img + (4 * wave + r) * 1024 + lane * 8;
+                    xa[r] = add4_f16(*reinterpret_cast<const uint2*>(stg), *reinterpret_cast<const uint2*>(stg + 32768), *reinterpret_cast<const f32x4*>(srow + fa * 4) + ba);
+                    xb[r] = add4_f16(*reinterpret_cast<const uint2*>(stg + 512), *reinterpret_cast<const uint2*>(stg + 32768 + 512), *reinterpret_cast<const f32x4*>(srow + fb * 4) + bb);
+                } else {
+                    xa[r] = add4_f16(rh_a[r], rl_a[r], *reinterpret_cast<const f32x4*>(srow + fa * 4) + ba);
+                    xb[r] = add4_f16(rh_b[r], rl_b[r], *reinterpret_cast<const f32x4*>(srow + fb * 4) + bb);
                 }
-            m2[tb] = quad_sum((sq[0] + sq[1]) + (sq[2] + sq[3]));
-            if (q4 == 0) exch[(16 * tb + t16) * 8 + wave] = make_float2(mw[tb], m2[tb]);
-        }
-        tail_barrier();
-        TAIL_MARK(6)
-        float mean[4], rstd[4];
-#pragma unroll
-        for (int tb = 0; tb < 4; tb++) {
-            const f32x4* e = reinterpret_cast<const f32x4*>(exch + (16 * tb + t16) * 8);
-            const f32x4 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];     // (mean_w, M2_w) of waves 0 .. 7
-            const float mu = (((e0[0] + e0[2]) + (e1[0] + e1[2])) + ((e2[0] + e2[2]) + (e3[0] + e3[2]))) * 0.125f;
-            const float d0 = e0[0] - mu, d1 = e0[2] - mu, d2 = e1[0] - mu, d3 = e1[2] - mu, d4 = e2[0] - mu, d5 = e2[2] - mu, d6 = e3[0] - mu, d7 = e3[2] - mu;
-            const float within = ((e0[1] + e0[3]) + (e1[1] + e1[3])) + ((e2[1] + e2[3]) + (e3[1] + e3[3]));
-            const float between = ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + ((d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7));
-            mean[tb] = mu;
-            rstd[tb] = ln_rstd(fmaf(64.0f, between, within));
-        }
-#pragma unroll
-        for (int nh = 0; nh < 2; nh++)
-#pragma unroll
-            for (int rb = 0; rb < 2; rb++) {
-                const int f = 256 * nh + 32 * wave + 16 * rb + 4 * q4;
-                const f32x4 g = *reinterpret_cast<const f32x4*>(g1 + f), be = *reinterpret_cast<const f32x4*>(be1 + f);
-#pragma unroll
-                for (int tb = 0; tb < 4; tb++) {
-                    const f32x4 y = (acc[nh][rb][tb] - mean[tb]) * (g * rstd[tb]) + be;
-                    acc[nh][rb][tb] = y;
-                    *reinterpret_cast<uint2*>(x1img + slot1k(nh, rb, tb)) = pack4_f16(y[0], y[1], y[2], y[3]);
-                }
+                const f32x4 t = xa[r] + xb[r];
+                mean[r] = wave_sum((t[0] + t[1]) + (t[2] + t[3])) * (1.0f / MST_D);
             }
-        TAIL_MARK(7)
-        tail_barrier();                                                // the x1 image is complete; the exchange area is free (the H image overlays it)
-        TAIL_MARK(8)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                xa[r] -= mean[r];
+                xb[r] -= mean[r];
+                const f32x4 sq = xa[r] * xa[r] + xb[r] * xb[r];
+                rstd[r] = ln_rstd(wave_sum((sq[0] + sq[1]) + (sq[2] + sq[3])));
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                xa[r] = xa[r] * (ga * rstd[r]) + ea;
+                xb[r] = xb[r] * (gb * rstd[r]) + eb;
+                const int row = 4 * wave + r, trow = 32 * m + row;
+                // x1: fp32 back into the scratch row (FFN2's initial accumulator), f16 into the operand image
+                char* srow = smem + row * C::LN_LD;
+                *reinterpret_cast<f32x4*>(srow + fa * 4) = xa[r];
+                *reinterpret_cast<f32x4*>(srow + fb * 4) = xb[r];
+                char* irow = x1img + trow * 1024 + 8 * (lane & 1);
+                *reinterpret_cast<uint2*>(irow + ((((lane >> 1)) ^ (trow & 15)) << 4)) = pack4_f16(xa[r][0], xa[r][1], xa[r][2], xa[r][3]);
+                *reinterpret_cast<uint2*>(irow + (((32 + (lane >> 1)) ^ (trow & 15)) << 4)) = pack4_f16(xb[r][0], xb[r][1], xb[r][2], xb[r][3]);
+            }
+            TAIL_MARK(7 + 3 * m)
+            tail_barrier();
+#pragma unroll
+            for (int tbl = 0; tbl < 2; tbl++) {
+                const char* trow = smem + (16 * tbl + t16) * C::LN_LD;
+#pragma unroll
+                for (int nh = 0; nh < 2; nh++)
+#pragma unroll
+                    for (int rb = 0; rb < 2; rb++) {
+                        acc[nh][rb][2 * m + tbl] = *reinterpret_cast<const f32x4*>(trow + (256 * nh + 32 * wave + 16 * rb + 4 * q4) * 4);
+                    }
+            }
+            tail_barrier();                                            // scratch free: the next half / the H image may overwrite it
+            TAIL_MARK(8 + 3 * m)
+        }
     }
     tail_fence();
     TAIL_MARK(3)

@@ -11,7 +11,7 @@
 __device__ unsigned long long g_tail_stamp[1024][8][48];
 #define TAIL_MARK(i) if ((threadIdx.x & 63) == 0) { g_tail_stamp[blockIdx.x][threadIdx.x >> 6][2 * (i)] = __builtin_amdgcn_s_memtime(); g_tail_stamp[blockIdx.x][threadIdx.x >> 6][2 * (i) + 1] = __builtin_amdgcn_s_memrealtime(); }
 #ifndef TAIL_HEADER
-#define TAIL_HEADER "../mst_tail.h"
+#define TAIL_HEADER "../mst_tail_old.h"
 #endif
 #include TAIL_HEADER
 using namespace mst;
@@ -68,15 +68,15 @@ int main(int argc, char** argv) {
                 }
                 for (int j = 0; j < 5; j++) ff[j].push_back(a[j] * 0.01 / 8);
             }
-            { const unsigned long long seq[5] = {rt[2], rt[6], rt[7], rt[8], rt[3]};
-              for (int p = 0; p < 4; p++) ln[p].push_back(((double)seq[p + 1] - (double)seq[p]) * 0.01); }
+            { const unsigned long long seq[8] = {rt[2], rt[6], rt[7], rt[8], rt[9], rt[10], rt[11], rt[3]};
+              for (int p = 0; p < 7; p++) ln[p].push_back(((double)seq[p + 1] - (double)seq[p]) * 0.01); }
         }
         auto med = [](std::vector<double>& x) { std::sort(x.begin(), x.end()); return x[x.size() / 2]; };
         printf("rep %d: %.2f us/launch over %d launches | in-kernel (median over %zu workgroups of the last launch, boundaries = last wave): clock %.3f GHz, "
                "workgroup %.2f us = att image %.2f + out-proj %.2f + LN1 %.2f + FFN %.2f + LN2/store %.2f us\n",
                rep, ms * 1e3 / iters, iters, ghz.size(), med(ghz), med(tot), med(ph[0]), med(ph[1]), med(ph[2]), med(ph[3]), med(ph[4]));
-        printf("        LN1: barrier + bias + residual + wave statistics + barrier %.2f, merge + normalise + x1 image %.2f, barrier %.2f, rest %.2f us\n",
-               med(ln[0]), med(ln[1]), med(ln[2]), med(ln[3]));
+        printf("        LN1: half 0: transpose + barrier %.2f, rows %.2f, barrier + read-back + barrier %.2f | half 1: %.2f, %.2f, %.2f | rest %.2f us\n",
+               med(ln[0]), med(ln[1]), med(ln[2]), med(ln[3]), med(ln[4]), med(ln[5]), med(ln[6]));
         printf("        FFN per wave (mean of 8): 4 x FFN1 %.2f, GELU(0) alone %.2f, 3 x [FFN2 with the next chunk's GELU inside] %.2f, FFN2(3) + final barrier %.2f, waits on the arrival counters %.2f us\n",
                med(ff[0]), med(ff[1]), med(ff[3]), med(ff[4]), med(ff[2]));
     }
