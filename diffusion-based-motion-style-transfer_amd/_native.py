@@ -82,6 +82,7 @@ SIGNATURES = {
     "mst_profile_event_overhead_us": (C.c_float, [C.c_void_p]),
     "mst_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int32),
                                    C.c_int32]),
+    "mst_set_precise": (C.c_int, [C.c_void_p, C.c_int32]),
     "mst_debug_stop_after": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "mst_debug_copy": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p]),
 }

@@ -15,6 +15,16 @@ __global__ void k_convert_pad(const float* __restrict__ src, int N, int K, f16* 
     }
 }
 
+// the lo half of the same matrix: f16(w - f16(w)), the second term of a hi + lo WEIGHT operand (precise mode)
+__global__ void k_convert_pad_lo(const float* __restrict__ src, int N, int K, f16* __restrict__ dst, int Npad, int Kpad) {
+    size_t total = (size_t)Npad * Kpad;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int n = (int)(i / Kpad), k = (int)(i - (size_t)n * Kpad);
+        float v = (n < N && k < K) ? src[(size_t)n * K + k] : 0.f;
+        dst[i] = (f16)(v - (float)(f16)v);
+    }
+}
+
 __global__ void k_copy_pad_f32(const float* __restrict__ src, int n, float* __restrict__ dst, int npad) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < npad) dst[i] = i < n ? src[i] : 0.f;

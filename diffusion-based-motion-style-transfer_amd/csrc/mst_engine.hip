@@ -121,6 +121,7 @@ struct LayerW {
     // [in][out] f16 copies: the "weights" operand of the dgrad GEMMs (training path)
     f16 *w_inT = nullptr, *w_outT = nullptr, *w1T = nullptr, *w2T = nullptr;
     f16* wtail = nullptr;           // W_out | W1 | W2 as the fused layer tail's slab stream (mst_tail.h, k_pack_tail)
+    f16 *w_in_lo = nullptr, *w_out_lo = nullptr, *w1_lo = nullptr, *w2_lo = nullptr;   // f16(w - f16(w)): the weights' lo halves (precise mode)
     f16* wqkv = nullptr;            // W_in as the fused QKV+attention kernel's per-(head, wave) fragment streams (mst_attn.h, k_pack_qkv)
 };
 
@@ -155,6 +156,7 @@ struct mst_engine {
     int S_max = 0, M_pad = 0, kin_pad = 0, nt_out = 0, fout_pad = 0;
     LayerW L[16];
     f16 *w_pose_in = nullptr, *w_pose_out = nullptr;
+    f16 *w_pose_in_lo = nullptr, *w_pose_out_lo = nullptr;      // lo halves (precise mode)
     f16 *w_pose_inT = nullptr, *w_pose_outT = nullptr;   // [fout_pad][512] and [512][kin_pad]: the projections' dgrad operands
     float *b_pose_in = nullptr, *b_pose_out = nullptr;
     float *w_t0 = nullptr, *b_t0 = nullptr, *w_t2 = nullptr, *b_t2 = nullptr, *w_text = nullptr, *b_text = nullptr;
@@ -173,6 +175,8 @@ struct mst_engine {
     int fuse_qkv_attn = 1;                // K4 + K5 as one kernel per (clip, head); MST_FUSE_QKV_ATTN=0 keeps them apart
     int fuse_tail = 1;                    // K6 + K7 + K8 as one kernel per 64-token tile (mst_tail.h); MST_FUSE_TAIL=0 keeps them apart
     int fuse_frames = 1;                  // sampling loop: a step's epilogue writes the next step's f16 frame rows; MST_FUSE_FRAMES=0 runs k_frames_f16 every step
+    int precise = 0;                      // mst_set_precise / MST_PRECISE=1: every layer GEMM of the sampling path multiplies its activation as hi + lo (the small-tile
+                                          // kernels at any size, ~2x their MFMA work): for checkpoints whose outlier channels put f16 operands above the 1e-3 bar
     int small_m = 3200;                   // launches of at most this many token rows take the small-tile path (MST_SMALL_M, 0 = never);
                                           // tools/small_m_ab2.sh, one launch, us per step small / large tiles: 8 clips 444 / 569, 11: 519 / 571,
                                           // 14: 560 / 572, 16: 566 / 571, 20: 641 / 575, 24: 718 / 577 (the large-tile step is flat: hand-over at 16 clips)
@@ -286,8 +290,14 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
         CHECK(dmalloc(&w.w2T, (size_t)MST_D * MST_FF));
         CHECK(dmalloc(&w.wtail, TailCfg::LAYER_BYTES / 2));
         CHECK(dmalloc(&w.wqkv, (size_t)3 * MST_D * MST_D));
+        CHECK(dmalloc(&w.w_in_lo, (size_t)3 * MST_D * MST_D));
+        CHECK(dmalloc(&w.w_out_lo, (size_t)MST_D * MST_D));
+        CHECK(dmalloc(&w.w1_lo, (size_t)MST_FF * MST_D));
+        CHECK(dmalloc(&w.w2_lo, (size_t)MST_D * MST_FF));
     }
     CHECK(dmalloc(&e->w_pose_in, (size_t)MST_D * e->kin_pad));
+    CHECK(dmalloc(&e->w_pose_in_lo, (size_t)MST_D * e->kin_pad));
+    CHECK(dmalloc(&e->w_pose_out_lo, (size_t)e->fout_pad * MST_D));
     CHECK(dmalloc(&e->b_pose_in, MST_D));
     CHECK(dmalloc(&e->w_pose_out, (size_t)e->fout_pad * MST_D));
     CHECK(dmalloc(&e->b_pose_out, e->fout_pad));
@@ -338,6 +348,7 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     if (const char* v = getenv("MST_FUSE_FRAMES")) e->fuse_frames = atoi(v) != 0;
     if (const char* v = getenv("MST_WGRAD_STREAM")) e->wgrad_stream_on = atoi(v) != 0;
     if (const char* v = getenv("MST_SMALL_M")) e->small_m = atoi(v);
+    if (const char* v = getenv("MST_PRECISE")) e->precise = atoi(v) != 0;
     if (const char* v = getenv("MST_LN128_M")) e->ln128_min_m = atoi(v);
     CHECK(dmalloc(&e->zacc, (size_t)e->M_pad * MST_D));
     CHECK(dmalloc(&e->ld_dev, 1));
@@ -358,7 +369,7 @@ extern "C" void mst_engine_destroy(mst_engine* e) {
     for (int l = 0; l < e->cfg.num_layers; l++) {
         LayerW& w = e->L[l];
         void* p[] = {w.w_in, w.w_out, w.w1, w.w2, w.b_in, w.b_out, w.b1, w.b2, w.g1, w.be1, w.g2, w.be2,
-                     w.w_inT, w.w_outT, w.w1T, w.w2T, w.wtail, w.wqkv};
+                     w.w_inT, w.w_outT, w.w1T, w.w2T, w.wtail, w.wqkv, w.w_in_lo, w.w_out_lo, w.w1_lo, w.w2_lo};
         for (void* q : p) (void)hipFree(q);
     }
     {
@@ -370,7 +381,7 @@ extern "C" void mst_engine_destroy(mst_engine* e) {
         for (int i = 0; i < 2; i++) if (t.ev_side[i]) (void)hipEventDestroy(t.ev_side[i]);
         for (void* q : p) (void)hipFree(q);
     }
-    void* p[] = {e->w_pose_in, e->b_pose_in, e->w_pose_out, e->b_pose_out, e->w_pose_inT, e->w_pose_outT, e->w_t0, e->b_t0, e->w_t2, e->b_t2,
+    void* p[] = {e->w_pose_in_lo, e->w_pose_out_lo, e->w_pose_in, e->b_pose_in, e->w_pose_out, e->b_pose_out, e->w_pose_inT, e->w_pose_outT, e->w_t0, e->b_t0, e->w_t2, e->b_t2,
                  e->w_text, e->b_text, e->pe, e->hl, e->hx, e->qkv, e->att, e->hid, e->xt, e->xt_lo, e->gelu_tab, e->temb_hid, e->temb, e->textproj, e->zacc};
     for (void* q : p) (void)hipFree(q);
     for (int i = 0; i < mst_engine::MAX_SLICES - 1; i++) {
@@ -394,8 +405,9 @@ extern "C" void mst_engine_destroy(mst_engine* e) {
 }
 
 // ------------------------------------------------------------------------------------------ weights
-static int put_matrix(const float* src, int N, int K, f16* dst, int Npad, int Kpad, hipStream_t st) {
+static int put_matrix(const float* src, int N, int K, f16* dst, int Npad, int Kpad, hipStream_t st, f16* dst_lo = nullptr) {
     hipLaunchKernelGGL(k_convert_pad, dim3(1024), dim3(256), 0, st, src, N, K, dst, Npad, Kpad);
+    if (dst_lo) hipLaunchKernelGGL(k_convert_pad_lo, dim3(1024), dim3(256), 0, st, src, N, K, dst_lo, Npad, Kpad);
     HIPCHECK(hipGetLastError());
     return 0;
 }
@@ -428,7 +440,7 @@ extern "C" int mst_load_weight(mst_engine* e, const char* name, const float* src
         if (layer < 0 || layer >= e->cfg.num_layers) return fail("mst_load_weight: layer %d out of range", layer);
         LayerW& w = e->L[layer];
         std::string r(rest);
-#define MAT(key, N_, K_, dst) if (r == key) { if (!shape_is(shape, ndim, N_, K_)) return fail("mst_load_weight: %s: bad shape", name); rc = put_matrix(src, N_, K_, dst, N_, K_, st); if (!rc) rc = put_matrix_t(src, N_, K_, dst##T, st); repack = dst != w.w_in; }
+#define MAT(key, N_, K_, dst) if (r == key) { if (!shape_is(shape, ndim, N_, K_)) return fail("mst_load_weight: %s: bad shape", name); rc = put_matrix(src, N_, K_, dst, N_, K_, st, dst##_lo); if (!rc) rc = put_matrix_t(src, N_, K_, dst##T, st); repack = dst != w.w_in; }
         bool repack = false;
 #define VEC(key, N_, dst) if (r == key) { if (!shape_is(shape, ndim, N_)) return fail("mst_load_weight: %s: bad shape", name); rc = put_vector(src, N_, dst, N_, st); }
         MAT("self_attn.in_proj_weight", 3 * MST_D, MST_D, w.w_in)
@@ -455,7 +467,7 @@ extern "C" int mst_load_weight(mst_engine* e, const char* name, const float* src
         }
     } else if (n == "input_process.poseEmbedding.weight") {
         if (!shape_is(shape, ndim, MST_D, F)) return fail("mst_load_weight: %s: bad shape", name);
-        rc = put_matrix(src, MST_D, F, e->w_pose_in, MST_D, e->kin_pad, st);
+        rc = put_matrix(src, MST_D, F, e->w_pose_in, MST_D, e->kin_pad, st, e->w_pose_in_lo);
         if (!rc) {      // [512][F] -> [F (padded to fout_pad)][512]
             hipLaunchKernelGGL(k_convert_transpose, dim3((F + 31) / 32, (MST_D + 31) / 32), dim3(256), 0, st, src, MST_D, F, e->w_pose_inT, MST_D);
             HIPCHECK(hipGetLastError());
@@ -465,7 +477,7 @@ extern "C" int mst_load_weight(mst_engine* e, const char* name, const float* src
         rc = put_vector(src, MST_D, e->b_pose_in, MST_D, st);
     } else if (n == "output_process.poseFinal.weight") {
         if (!shape_is(shape, ndim, F, MST_D)) return fail("mst_load_weight: %s: bad shape", name);
-        rc = put_matrix(src, F, MST_D, e->w_pose_out, e->fout_pad, MST_D, st);
+        rc = put_matrix(src, F, MST_D, e->w_pose_out, e->fout_pad, MST_D, st, e->w_pose_out_lo);
         if (!rc) {      // [F][512] -> [512][F (padded to kin_pad)]
             hipLaunchKernelGGL(k_convert_transpose, dim3((MST_D + 31) / 32, (F + 31) / 32), dim3(256), 0, st, src, F, MST_D, e->w_pose_outT, e->kin_pad);
             HIPCHECK(hipGetLastError());
@@ -751,8 +763,8 @@ static int assemble_stream(mst_engine* e, const WS& ws, const float* x, int clip
         epi.ct.uniform_row = temb_uniform_row; epi.ct.temb_mod = temb_mod; epi.ct.joff = lr.joff; epi.ct.rows = rows;
         epi.ct.tp_half = rows > clips_x ? clips_x : 0; epi.ct.tp_uncond = rows > clips_x ? tp_uncond : 0;
         // x_t as hi + lo (RowsDirect::Xlo): both halves of a k-slab beside ONE copy of the weight slab
-        CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1, 32, 2>(dim3((tot + 63) / 64, 1), RowsDirect{ws.xt, e->kin_pad, ws.xt_lo}, e->w_pose_in, e->kin_pad,
-                                                          e->kin_pad, epi, st)));
+        CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1, 32, 2>(dim3((tot + 63) / 64, 1), RowsDirect{ws.xt, e->kin_pad, ws.xt_lo, e->precise ? e->w_pose_in_lo : nullptr},
+                                                          e->w_pose_in, e->kin_pad, e->kin_pad, epi, st)));
     }
     return 0;
 }
@@ -764,12 +776,12 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
     CHECK(assemble_stream(e, ws, x, clips_x, rows, T, temb_uniform_row, temb_mod, st, tp_uncond, lr));
     if (e->dbg_stage == 0) return 0;
 #define DBG_STOP(stage) if (e->dbg_layer == l && e->dbg_stage == stage) return 0;
-    const bool small = e->small_m > 0 && M <= e->small_m;
+    const bool small = e->precise || (e->small_m > 0 && M <= e->small_m);
     // Clips of at most 16 frames: so few values are averaged per output that the f16 rounding of the ACTIVATION operands shows at the
     // 1e-3 bar (oracle rounding model, classifier-free guidance: 1.07e-3 mean over seeds at 1 frame, 9.1e-4 at 5 frames, 7.6e-4 at
     // 196).  Those launches -- a handful of tiles, nowhere near a throughput regime -- multiply every activation as hi + lo
     // (RowsDirect::Xlo; the lo halves of att and hid borrow the idle hid / qkv buffers): 6.5e-4 mean in the same model.
-    const bool precise = small && T <= 16;
+    const bool precise = e->precise || (small && T <= 16);
     f16* const att_lo = precise ? ws.hid : nullptr;
     f16* const hid_lo = precise ? ws.qkv : nullptr;
     const f16* const hl_in = precise ? ws.hl : nullptr;
@@ -778,7 +790,7 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
         {
             ProfScope ps(e, FAM_QKV, st);
             DEpiBiasF16<false> epi{w.b_in, ws.qkv, 3 * MST_D, M};
-            CHECK(launch_small(M, 3 * MST_D, RowsDirect{ws.hx, MST_D, hl_in}, w.w_in, MST_D, MST_D, epi, st));
+            CHECK(launch_small(M, 3 * MST_D, RowsDirect{ws.hx, MST_D, hl_in, e->precise ? w.w_in_lo : nullptr}, w.w_in, MST_D, MST_D, epi, st));
         }
         DBG_STOP(1)
         {
@@ -789,7 +801,7 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
         {
             ProfScope ps(e, FAM_OUTPROJ_LN, st);
             DEpiPlainF32 epi{ws.zacc, MST_D, M};
-            CHECK(launch_small(M, MST_D, RowsDirect{ws.att, MST_D, att_lo}, w.w_out, MST_D, MST_D, epi, st));
+            CHECK(launch_small(M, MST_D, RowsDirect{ws.att, MST_D, att_lo, e->precise ? w.w_out_lo : nullptr}, w.w_out, MST_D, MST_D, epi, st));
             hipLaunchKernelGGL(k_ln_rows, dim3((M + 3) / 4), dim3(256), 0, st, ws.zacc, w.b_out, w.g1, w.be1, ws.hx, ws.hl, M);
             HIPCHECK(hipGetLastError());
         }
@@ -797,13 +809,13 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
         {
             ProfScope ps(e, FAM_FFN1, st);
             DEpiBiasF16<true> epi{w.b1, ws.hid, MST_FF, M, hid_lo};
-            CHECK(launch_small(M, MST_FF, RowsDirect{ws.hx, MST_D, hl_in}, w.w1, MST_D, MST_D, epi, st));
+            CHECK(launch_small(M, MST_FF, RowsDirect{ws.hx, MST_D, hl_in, e->precise ? w.w1_lo : nullptr}, w.w1, MST_D, MST_D, epi, st));
         }
         DBG_STOP(4)
         {
             ProfScope ps(e, FAM_FFN2_LN, st);
             DEpiPlainF32 epi{ws.zacc, MST_D, M};
-            CHECK(launch_small(M, MST_D, RowsDirect{ws.hid, MST_FF, hid_lo}, w.w2, MST_FF, MST_FF, epi, st));
+            CHECK(launch_small(M, MST_D, RowsDirect{ws.hid, MST_FF, hid_lo, e->precise ? w.w2_lo : nullptr}, w.w2, MST_FF, MST_FF, epi, st));
             hipLaunchKernelGGL(k_ln_rows, dim3((M + 3) / 4), dim3(256), 0, st, ws.zacc, w.b2, w.g2, w.be2, ws.hx, ws.hl, M);
             HIPCHECK(hipGetLastError());
         }
@@ -878,7 +890,8 @@ static int launch_out(mst_engine* e, const WS& ws, int batch, int T, float* out,
                       const f16* w_override = nullptr, const float* b_override = nullptr, int tok_off = 1, bool frames_next = false,
                       bool hi_lo = false) {
     const int S = T + tok_off;
-    RowsFrames xs{ws.hx, MST_D, T, S, batch * T, 64, (size_t)batch * S, tok_off, hi_lo ? ws.hl : nullptr};   // hi_lo: ws.hx / ws.hl are the last stream
+    RowsFrames xs{ws.hx, MST_D, T, S, batch * T, 64, (size_t)batch * S, tok_off, hi_lo ? ws.hl : nullptr,   // hi_lo: ws.hx / ws.hl are the last stream
+                  hi_lo && e->precise && !w_override ? e->w_pose_out_lo : nullptr};
     DEpiEmbedOut<MODE> epi{b_override ? b_override : e->b_pose_out, e->cfg.feats, T, batch * T, out, sa};
     if (frames_next) { epi.xt_next = ws.xt; epi.kpad = e->kin_pad; epi.xt_next_lo = ws.xt_lo; }
     return launch_gemm_dma<64, BF, MT, NT, 4, NX, 32, XS>(dim3((batch * T + 63) / 64, 1), xs, w_override ? w_override : e->w_pose_out, MST_D, MST_D, epi, st);
@@ -943,7 +956,7 @@ static int loop_slices_for(const mst_engine* e, int batch, int cfg, int frames) 
     int n = e->nsplit;
     if (n == 0) {
         const long long M = (long long)rows * (frames + 1);
-        const bool small = e->small_m > 0 && M <= e->small_m;
+        const bool small = e->precise || (e->small_m > 0 && M <= e->small_m);
         const long long waves = ((M + 63) / 64 + 255) / 256;        // rounds of 64-token tiles over the 256 CUs
         n = small ? 3 : (int)(waves < 3 ? waves : 3);
     }
@@ -1821,6 +1834,12 @@ extern "C" int mst_recover_from_ric(const float* sample, const float* mean, cons
     hipLaunchKernelGGL(k_recover_from_ric, dim3(batch), dim3(256), sizeof(float) * 5 * frames, (hipStream_t)stream, sample, mean, stdv,
                        feats, frames, joints, out);
     HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mst_set_precise(mst_engine* e, int32_t on) {
+    if (!e) return fail("mst_set_precise: null engine");
+    e->precise = on != 0;
     return 0;
 }
 

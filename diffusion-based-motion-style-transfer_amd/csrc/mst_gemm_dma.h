@@ -131,19 +131,24 @@ struct DmaPlan {
 // disappears.  Used where it is nearly free and pays most: the pose embedding (the rounding of x_t perturbs everything
 // behind it) and the output projection (the rounding of the last stream goes straight into the result): one 64-clip
 // forward 4.8e-4 -> 3.6e-4, classifier-free guidance 7.3e-4 -> 5.5e-4 relative L2 in the oracle's rounding model.
+// `Wlo` (optional, the weight matrix's layout): the weights are a hi + lo pair too -- one more pass of the K range, X . Wlo.  Precise
+// mode only (mst_set_precise): with the activations split, what is left of the operand rounding is the weights' (oracle rounding
+// model on weights with outlier statistics: 1.2e-3 all operands f16, 9.7e-4 activations exact, 4.0e-4 weights exact as well).
 struct RowsDirect {                       // tile row r = matrix row tok0 + r
-    const f16* X; int ld; const f16* Xlo = nullptr;
+    const f16* X; int ld; const f16* Xlo = nullptr; const f16* Wlo = nullptr;
     __device__ __forceinline__ const char* base() const { return reinterpret_cast<const char*>(X); }
     __device__ __forceinline__ const char* base_lo() const { return reinterpret_cast<const char*>(Xlo); }
+    __device__ __forceinline__ const char* base_wlo() const { return reinterpret_cast<const char*>(Wlo); }
     __device__ __forceinline__ unsigned rowbyte(int tok0, int r) const { return (unsigned)(tok0 + r) * (unsigned)ld * 2u; }
 };
 struct RowsFrames {                       // tile row r = frame (tok0 + r) of the token stream, conditioning token skipped;
     const f16* X; int ld; int T, S, total;   // rows >= BT (second group) come from the uncond half (+cfg_rows)
     int BT; size_t cfg_rows;
     int tok_off = 1;                          // tokens in front of the frames: 1 (conditioning token) or 2 (the motion encoder's mu / sigma queries)
-    const f16* Xlo = nullptr;
+    const f16* Xlo = nullptr; const f16* Wlo = nullptr;
     __device__ __forceinline__ const char* base() const { return reinterpret_cast<const char*>(X); }
     __device__ __forceinline__ const char* base_lo() const { return reinterpret_cast<const char*>(Xlo); }
+    __device__ __forceinline__ const char* base_wlo() const { return reinterpret_cast<const char*>(Wlo); }
     __device__ __forceinline__ unsigned rowbyte(int tok0, int r) const {
         int half = r >= BT ? 1 : 0;
         int tok = tok0 + r - half * BT;
@@ -170,11 +175,17 @@ __device__ __forceinline__ void gemm_mainloop_dma(char* smem, const SRC& xs, con
     });
     const char* xb = xs.base();
     const char* xlo = xs.base_lo();
+    const char* wlo = xs.base_wlo();
     const char* wb = reinterpret_cast<const char*>(W);
-    const int KT1 = K / TL::KDEPTH, KT = (xlo && !SPLIT) ? 2 * KT1 : KT1;   // K-twice form: weights re-streamed (L2-hot)
+    // passes over the K range: X . W, then (K-twice form) Xlo . W, then (split weights) X . Wlo -- the weights are re-streamed (L2-hot).
+    // In the SPLIT form a pass stages hi and lo rows together, so the weight-lo pass multiplies (X + Xlo) . Wlo: the extra term is 2^-22.
+    const int KT1 = K / TL::KDEPTH;
+    const int KTX = (xlo && !SPLIT) ? 2 * KT1 : KT1;         // end of the passes against W
+    const int KT = wlo ? KTX + KT1 : KTX;
     constexpr int AHEAD = TL::NSTAGE - 1;                    // slabs in flight
     auto issue = [&](int kt) {
-        if (SPLIT) plan.issue(smem_base, kt, kt, xb, wb, xlo);
+        if (kt >= KTX) plan.issue(smem_base, kt, kt - KTX, xb, wlo, SPLIT ? xlo : nullptr);
+        else if (SPLIT) plan.issue(smem_base, kt, kt, xb, wb, xlo);
         else if (kt < KT1) plan.issue(smem_base, kt, kt, xb, wb);
         else plan.issue(smem_base, kt, kt - KT1, xlo, wb);
     };

@@ -319,6 +319,13 @@ float mst_profile_event_overhead_us(const mst_engine* e);   /* what an empty HIP
 int mst_profile_read(mst_engine* e, const char** names, float* total_ms, int32_t* launches,
                      int32_t cap);
 
+/* Precise mode (no reference counterpart: the reference computes in fp32, model/mdm_forstyledataset.py:539-546).  on != 0: every
+ * layer GEMM of the sampling path (mst_forward, mst_sample_loop) multiplies its activation operand as hi + lo -- f16(x) and
+ * f16(x - hi), ~22 significant bits -- instead of f16(x): for checkpoints whose statistics (LayerNorm-gain outlier channels, large
+ * FFN / attention weights) put plain f16 operands above the 1e-3 relative-L2 bar.  Takes the small-tile kernels at any batch size
+ * (about half the throughput of the default path at 64 clips); default off, also MST_PRECISE=1. */
+int mst_set_precise(mst_engine* e, int32_t on);
+
 /* Debug / test hooks (no reference counterpart): stop the encoder stack after (layer, stage) --
  * stage 0 = token stream assembled, 1 = QKV, 2 = attention, 3 = out-proj + LayerNorm1, 4 = FFN1,
  * 5 = FFN2 + LayerNorm2; layer = stage = -1 runs everything -- and copy a workspace buffer

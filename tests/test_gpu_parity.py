@@ -160,6 +160,16 @@ def test_forward_with_ill_conditioned_weights(stress):
             e_model = max(e_model, rel_l2(denoiser.forward(w, pe, xp, t, txt, dt=torch.float16).numpy(), denoiser.forward(w, pe, xp, t, txt).numpy()))
     print("ill-conditioned", stress, "engine", e_eng, "operand-rounding model", e_model)
     assert e_eng <= 1.5 * e_model + 2e-4, (e_eng, e_model)
+    # the remedy for such checkpoints: activations AND weights as f16 hi + lo pairs in every GEMM (engine.set_precise; measured 2.7e-4 /
+    # 3.5e-4 / 0.066 for the three cases -- with the activations alone split it was 8.8e-4 / 1.01e-3: what is left is the weights' rounding)
+    eng.set_precise(True)
+    e_prec = rel_l2(eng.forward(cu(xs), cu(t)).cpu().numpy(), ref)
+    eng.set_precise(False)
+    print("ill-conditioned", stress, "precise mode", e_prec)
+    if stress != "everything":
+        assert e_prec < 5e-4, (stress, e_prec)      # the north_star bar (1e-3) with a factor of two to spare
+    else:
+        assert e_prec <= 0.5 * e_eng, (e_prec, e_eng)
 
 
 @pytest.mark.parametrize("tag", ["hml", "xia"])
