@@ -9,7 +9,7 @@ step "bench precise mode"; MST_PRECISE=1 timeout -k 10 300 python bench.py --ste
 step "finetune bench"; timeout -k 10 300 python bench.py --mode finetune --steps 10 --warmup 3 > $O/bench_ft.log 2>&1 || exit 1; tail -1 $O/bench_ft.log > $O/r03_finetune_bench_1gpu.json; cut -c1-300 $O/r03_finetune_bench_1gpu.json
 step "kernel stats, one slice"
 MST_STREAMS=1 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-boundary > $O/prof_bench.log 2>&1 || exit 1
-tail -1 $O/prof_bench.log > $O/r03_bench_under_rocprof_streams1.json
+grep "^{\"metric\"" $O/prof_bench.log | tail -1 > $O/r03_bench_under_rocprof_streams1.json
 cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/r03_kernel_stats_bench_steps1_streams1.csv; find $O/prof -name "*kernel_trace.csv" -delete
 head -6 $O/r03_kernel_stats_bench_steps1_streams1.csv | cut -c1-160
 step "pmc traffic"
