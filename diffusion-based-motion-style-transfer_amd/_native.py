@@ -139,7 +139,12 @@ def lib():
                 "The HIP library is the only implementation of the denoising path; there is no fallback.")
         l = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(l, name)
+            try:
+                fn = getattr(l, name)
+            except AttributeError:
+                if not custom:
+                    raise
+                continue        # an OLDER build named by MST_ENGINE_LIB (same-box A/B, tools/lib_ab.sh): entry points added since are simply absent
             fn.restype = res
             fn.argtypes = args
         if not custom and l.mst_source_hash().decode() != source_hash():
