@@ -946,8 +946,8 @@ extern "C" int mst_forward(mst_engine* e, const float* x, const int64_t* t, cons
 }
 
 // How many independent clip slices a loop over `batch` clips of `frames` frames runs as.  Measured, same box, interleaved
-// (tools/streams_ab.sh, tools/streams_ab_configs.sh), final round-2 kernels at 196 frames: a batch whose tiles are all resident at
-// once on the large-tile path wants ONE slice (batch 64: 82.0 / 81.6 / 80.6 clips/s at 1 / 2 / 3 slices; batch 32: 43.8 vs 39.7
+// (tools/streams_ab.sh, tools/streams_ab_configs.sh), round-2 kernels at 196 frames: a batch whose tiles are all resident at
+// once on the large-tile path wanted ONE slice (batch 64: 82.0 / 81.6 / 80.6 clips/s at 1 / 2 / 3 slices; batch 32: 43.8 vs 39.7
 // at 3 -- slices would drop to the small-tile kernels); more tiles than CUs want one slice per round of tiles (batch 128 = 394
 // tiles: 78.5 / 91.2 / 88.0 at 1 / 2 / 3; CFG at 64 clips: 39.8 / 45.5 / 44.6); the small-tile path (batch 16: 22.1 vs 28.8) up to three.
 static int loop_slices_for(const mst_engine* e, int batch, int cfg, int frames) {
@@ -957,8 +957,13 @@ static int loop_slices_for(const mst_engine* e, int batch, int cfg, int frames) 
     if (n == 0) {
         const long long M = (long long)rows * (frames + 1);
         const bool small = e->precise || (e->small_m > 0 && M <= e->small_m);
-        const long long waves = ((M + 63) / 64 + 255) / 256;        // rounds of 64-token tiles over the 256 CUs
+        const long long tiles = (M + 63) / 64, waves = (tiles + 255) / 256;      // rounds of 64-token tiles over the 256 CUs
         n = small ? 3 : (int)(waves < 3 ? waves : 3);
+        // Round 3: a batch that fills most of the chip in ONE round (the headline: 64 clips = 197 tiles) runs every workgroup through the
+        // same phase at the same time; three slices of it (each still on the large-tile path) decorrelate them.  Same-box, interleaved,
+        // 1 vs 3 slices at 64 clips: 96.9 vs 98.9 clips/s on a slow box (three rounds), 103.2 vs 104.1 on a fast one; at 48 clips
+        // (148 tiles) two slices are a wash (84.0 vs 83.7) and three fall to the small-tile kernels.
+        if (!small && waves == 1 && tiles >= 192) n = 3;
     }
     while (n > 1 && rows / n < 8) n--;                       // at least 8 rows through the transformer per slice
     return n;
