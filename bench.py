@@ -15,7 +15,7 @@ randn_like on the device inside its loop.
 The JSON line also carries
   roofline      the dominant kernel by device time PER ROCPROF SYMBOL (out-proj and FFN2 launches are one symbol, the
                 LayerNorm-epilogue GEMM): algorithmic FLOPs per launch / average launch duration measured with HIP
-                events on the launch stream inside the timed region (every 16th denoise step is instrumented), against
+                events on the launch stream inside the timed region (every 50th denoise step is instrumented), against
                 the dense f16/bf16 MFMA peak; `families` lists every kernel family with its MFMA fraction and its
                 achieved algorithmic HBM GB/s (the bandwidth-bound ones: embed_in, embed_out_step, the LN GEMMs).
   boundary      the same workload called through the drop-in surface (`diffusion.p_sample_loop(model, shape,
@@ -232,7 +232,7 @@ def sample_main(args):
     for k in range(args.warmup):
         one_pass(k)
     if eng is not None:
-        eng.profile(True, 16)
+        eng.profile(True, 50)
     barrier()
     t0 = time.perf_counter()
     last = None
