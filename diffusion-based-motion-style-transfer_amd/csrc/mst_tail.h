@@ -19,11 +19,11 @@
 //     start), x1 (64 KB f16 image written by LayerNorm1; no global round trip any more), the GELU output (32 KB per 256-feature
 //     chunk, double-buffered: ONE barrier per chunk instead of one per 32-KB weight slab).
 //   * 16x16x32 tiles instead of 32x32x16: same registers, same LDS bytes, +16 % in the probe at the clock the chip holds.
-//   * LayerNorm1's fp32 output re-enters the accumulators (through the LayerNorm scratch) as FFN2's initial value, so the residual
-//     of LayerNorm2 costs no registers during the FFN.
+//   * LayerNorm1 runs in the accumulator layout (statistics: wave-level sums + a 4 KB exchange between the eight waves): its fp32
+//     output stays in the accumulators as FFN2's initial value, so the residual of LayerNorm2 costs no registers during the FFN.
 //
 //   phase P   16 k-steps of 32: acc[nh][rb][tb] += W_out[256 nh + 32 w + 16 rb .., k] . att[16 tb .., k]^T            (4 fragments / step)
-//   LN1       two 32-token halves: accumulators -> scratch -> rows (+ b_out + stream) -> LayerNorm -> x1: f16 image + fp32 back
+//   LN1       in the accumulators: + b_out + stream (hi / lo rows staged in the x1 image area during phase P) -> LayerNorm -> x1: f16 image, fp32 stays
 //   phase F   4 chunks of 256 hidden features: FFN1 16 k-steps (2 fragments / step) -> GELU -> H image -> barrier -> FFN2 8 k-steps (4)
 //   LN2       accumulators (x1 + FFN2) -> scratch -> rows (+ b2) -> LayerNorm -> the stream (hi/lo), in place for the next layer
 #pragma once
@@ -44,15 +44,15 @@ struct TailCfg {
     static constexpr int LN_LD = MST_D * 4 + 16;         // LayerNorm scratch row: 512 fp32 + 16 B (conflict-free 16-B accesses)
     static constexpr int OFF_ATT = 0;                    // phase P: att image, 64 x 1 KB
     static constexpr int OFF_H = 0, HBUF = 32 * 1024;    // phase F: GELU output, 2 x (64 x 512 B)
-    static constexpr int OFF_CNT = 68 * 1024;            // 4 arrival counters of the FFN chunks (above LN1's half-tile scratch, below OFF_B1)
+    static constexpr int OFF_CNT = 68 * 1024;            // 4 arrival counters of the FFN chunks (above the att / H images, below OFF_TAB)
     // Phi(x) table of the GELU stage: entry i = {Phi(x_i), Phi(x_i+1) - Phi(x_i)}, x_i = -6 + i / 128, i < 1536 (+ one guard entry),
     // padded to 13 KB = 13 LDS-DMA pieces.  Linear interpolation error <= h^2 / 8 max|Phi''| = 1.9e-6, far below the f16 store (2^-11).
     static constexpr int GELU_N = 1536, GELU_TAB_BYTES = 13 * 1024;
     static constexpr int OFF_TAB = 69 * 1024;
     static constexpr int OFF_B1 = 92 * 1024;             // FFN1 bias (4 KB), staged at kernel start
-    static constexpr int OFF_X1 = 96 * 1024;             // LayerNorm1 output, 64 x 1 KB; LN1's half-tile scratch [0, 66 KB) stays below OFF_B1
+    static constexpr int OFF_X1 = 96 * 1024;             // LayerNorm1 output, 64 x 1 KB; during phase P the residual rows (lo, then hi) are staged here
     static constexpr int SMEM = 160 * 1024;
-    static_assert(32 * LN_LD <= OFF_CNT && OFF_CNT + 16 <= OFF_TAB && OFF_TAB + GELU_TAB_BYTES <= OFF_B1 && 64 * LN_LD <= SMEM && 2 * HBUF <= OFF_CNT, "LDS map");
+    static_assert(64 * 1024 <= OFF_CNT && OFF_CNT + 16 <= OFF_TAB && OFF_TAB + GELU_TAB_BYTES <= OFF_B1 && 64 * LN_LD <= SMEM && 2 * HBUF <= OFF_CNT, "LDS map");
     static_assert(P_FRAG % D == 0 && F1_FRAG % D == 0 && F2_FRAG % D == 0, "every phase starts on prefetch slot 0");
     static_assert(F1_FRAG == 32 && F2_FRAG == 32, "k_pack_tail's unit arithmetic");
 };
@@ -126,11 +126,13 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
     //      operand: a 16-lane group reads 16 rows at chunks {c, c ^ 1} -> 16 distinct slots of the 256-B bank row).  LDS-DMA writes
     //      lane-linearly, so the swizzle is on the per-lane SOURCE address; wave w fills rows [8 w, 8 w + 8);
     //  (2) the FFN1 bias (4 KB, waves 0..3) and the GELU stage's Phi table (13 KB): both are read from LDS;
-    //  (3) LayerNorm1's residual, the stream rows of the tile.  LayerNorm1 runs in the ACCUMULATOR layout (no transposition through an
-    //      fp32 scratch: that was 700 KB of LDS traffic per tile, 6 us), so the residual is needed as (token, 4 features) pieces per
-    //      lane: the rows are staged in [OFF_X1, +64 KB) in the same image layout as att and read with 8-byte LDS loads.  hi + lo
-    //      is 128 KB and the att image is alive until the loop ends, so the two halves take turns: lo is requested in front of the loop's first pass
-    //      and added to the accumulators after its second, hi follows into the same 64 KB during the last two and is added behind the loop; LayerNorm1's x1 image then overwrites hi slot by slot, each slot by the lane that read it.
+    //  (3) NOT in this burst: LayerNorm1's residual, the stream rows of the tile.  LayerNorm1 runs in the ACCUMULATOR layout (no
+    //      transposition through an fp32 scratch: that was 700 KB of LDS traffic per tile, 6 us), so the residual is needed as
+    //      (token, 4 features) pieces per lane: the rows are staged in [OFF_X1, +64 KB) in the same image layout as att and read
+    //      with 8-byte LDS loads.  hi + lo is 128 KB and the att image is alive until the loop ends, so the two halves take turns: lo
+    //      is requested in front of the loop's first pass and added to the accumulators after its second, hi follows into the same
+    //      64 KB during the last two and is added behind the loop; LayerNorm1's x1 image then overwrites hi slot by slot, each slot
+    //      by the lane that read it.
     float* b1s = reinterpret_cast<float*>(smem + C::OFF_B1);
     const char* const gtab = smem + C::OFF_TAB;
     unsigned* const arrived = reinterpret_cast<unsigned*>(smem + C::OFF_CNT);      // [chunk]: waves whose GELU output of that chunk is in the H image
