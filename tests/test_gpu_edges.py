@@ -93,6 +93,46 @@ def test_fused_qkv_attention_every_tile_count(T, monkeypatch):
     assert err < TOL
 
 
+def test_precise_mode_forward_cfg_and_loop():
+    """Precise mode (hi + lo activations AND weights in every GEMM of the sampling path, any batch size on the small-tile kernels):
+    forward, classifier-free guidance and a short DDPM / DDIM loop against the oracle -- with both operands split the error is the
+    fp32 summation order plus the f16 roundings inside attention, well under the default path's 4e-4."""
+    from mst_amd.engine import Schedule, SAMPLER_DDPM, SAMPLER_DDIM
+    from oracle import denoiser, diffusion, schedule
+    F, T, B = 263, 60, 3
+    eng, w, pe = make(F, T, 2 * B)
+    eng.set_precise(True)
+    shape = (B, F, 1, T)
+    x = syn.normal(SEED, "xp", shape)
+    txt = syn.normal(SEED, "txtp", (B, 512))
+    t = np.array([3, 998, 512])
+    eng.set_text(cu(txt))
+    e_fwd = rel_l2(eng.forward(cu(x), cu(t)).cpu().numpy(), denoiser.forward(w, pe, x, t, txt).numpy())
+    eng.set_text(cu(txt), cfg=True)
+    sc = np.array([1.5, 2.0, 2.5], np.float32)
+    e_cfg = rel_l2(eng.forward(cu(x), cu(t), scale=cu(sc), cfg=True).cpu().numpy(), denoiser.cfg_forward(w, pe, x, t, txt, sc).numpy())
+    print(f"precise mode: forward {e_fwd:.3e}, cfg {e_cfg:.3e}")
+    assert e_fwd < 1e-4 and e_cfg < 2e-4                 # measured 4.7e-5 / 1.0e-4 (default path: 4.0e-4 / 5.9e-4)
+    mask = syn.root_horizontal_mask(B, F, T)
+    motion = syn.normal(SEED, "motionp", shape)
+    tab, tmap = schedule.make("cosine", 1000, "ddim20")
+    sch = Schedule(tab, tmap, dev())
+    eng.set_text(cu(txt))
+    for sampler, name, eta in ((SAMPLER_DDPM, "ddpm", 0.0), (SAMPLER_DDIM, "ddim", 0.3)):
+        nz = np.stack([syn.normal(SEED, f"nzp{k}", shape) for k in range(5)])
+        x4 = sch.q_sample(cu(motion), cu(np.full(B, 3)), cu(nz[0]), cu(mask))
+        got, dump = eng.sample_loop(sch, x4, 3, 0, sampler, eta, mask=cu(mask), motion=cu(motion), noise=cu(nz[1:]), dump_xstart=True)
+        ref = diffusion.sample_loop(lambda xx, tt: denoiser.forward(w, pe, xx, tt, txt), tab, tmap, shape,
+                                    lambda k: torch.from_numpy(nz[k]), name, True, mask, motion, init_image=motion,
+                                    skip_timesteps=16, eta=eta, dump_all_xstart=True)
+        err = rel_l2(dump.cpu().numpy(), torch.stack(ref).numpy())
+        print(f"precise mode {name} loop: {err:.3e}")
+        assert err < 1e-4, (name, err)                    # measured 4.3e-5 / 4.4e-5
+        m = mask.astype(bool)
+        assert np.array_equal(got.cpu().numpy()[m], motion[m])            # masked entries bit-exact
+    eng.set_precise(False)
+
+
 def test_odd_batch_across_the_two_slices_equals_single_slice():
     """Batch 17 is split 9 + 8 over two streams (8-clip minimum per slice); results must not depend on the split."""
     from mst_amd.engine import Schedule, SAMPLER_DDPM
