@@ -1,3 +1,5 @@
+# NOTE: round-2 recipe.  The *_NODMA / *_NOMMA / ... ablation builds of the probes it replays were removed from the product headers in
+# round 3 (VERDICT hygiene item); it runs against the round-2 tree (git history), its output is profiles/r02_power_by_component.txt.
 # Package power and shader clock while ONE kernel (or one of its ablation builds) is replayed back to back: what each consumer of a
 # main-loop step -- LDS-DMA stream, fragment reads, MFMAs -- costs in watts.  rocm-smi sampled at 2 Hz beside three runs of the probe.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
