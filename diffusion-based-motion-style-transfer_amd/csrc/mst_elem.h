@@ -6,22 +6,16 @@
 
 namespace mst {
 
-// float32 [N][K] -> f16 [Npad][Kpad], zero padded
-__global__ void k_convert_pad(const float* __restrict__ src, int N, int K, f16* __restrict__ dst, int Npad, int Kpad) {
+// float32 [N][K] -> f16 [Npad][Kpad], zero padded; dst_lo != null: also the lo half f16(w - f16(w)), the second term of a hi + lo
+// WEIGHT operand (precise mode), in the same pass (one launch per matrix: weight re-uploads sit on the fine-tune loop's critical path)
+__global__ void k_convert_pad(const float* __restrict__ src, int N, int K, f16* __restrict__ dst, int Npad, int Kpad, f16* __restrict__ dst_lo) {
     size_t total = (size_t)Npad * Kpad;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         int n = (int)(i / Kpad), k = (int)(i - (size_t)n * Kpad);
-        dst[i] = (n < N && k < K) ? (f16)src[(size_t)n * K + k] : (f16)0.0f;
-    }
-}
-
-// the lo half of the same matrix: f16(w - f16(w)), the second term of a hi + lo WEIGHT operand (precise mode)
-__global__ void k_convert_pad_lo(const float* __restrict__ src, int N, int K, f16* __restrict__ dst, int Npad, int Kpad) {
-    size_t total = (size_t)Npad * Kpad;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        int n = (int)(i / Kpad), k = (int)(i - (size_t)n * Kpad);
-        float v = (n < N && k < K) ? src[(size_t)n * K + k] : 0.f;
-        dst[i] = (f16)(v - (float)(f16)v);
+        const float v = (n < N && k < K) ? src[(size_t)n * K + k] : 0.f;
+        const f16 h = (f16)v;
+        dst[i] = h;
+        if (dst_lo) dst_lo[i] = (f16)(v - (float)h);
     }
 }
 

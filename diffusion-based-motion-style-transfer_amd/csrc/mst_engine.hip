@@ -122,6 +122,7 @@ struct LayerW {
     f16 *w_inT = nullptr, *w_outT = nullptr, *w1T = nullptr, *w2T = nullptr;
     f16* wtail = nullptr;           // W_out | W1 | W2 as the fused layer tail's slab stream (mst_tail.h, k_pack_tail)
     f16 *w_in_lo = nullptr, *w_out_lo = nullptr, *w1_lo = nullptr, *w2_lo = nullptr;   // f16(w - f16(w)): the weights' lo halves (precise mode)
+    bool tail_dirty = true, qkv_dirty = true;   // wtail / wqkv are older than w_out | w1 | w2 / w_in: repacked by ensure_packed() before the next sampling launch
     f16* wqkv = nullptr;            // W_in as the fused QKV+attention kernel's per-(head, wave) fragment streams (mst_attn.h, k_pack_qkv)
 };
 
@@ -406,8 +407,7 @@ extern "C" void mst_engine_destroy(mst_engine* e) {
 
 // ------------------------------------------------------------------------------------------ weights
 static int put_matrix(const float* src, int N, int K, f16* dst, int Npad, int Kpad, hipStream_t st, f16* dst_lo = nullptr) {
-    hipLaunchKernelGGL(k_convert_pad, dim3(1024), dim3(256), 0, st, src, N, K, dst, Npad, Kpad);
-    if (dst_lo) hipLaunchKernelGGL(k_convert_pad_lo, dim3(1024), dim3(256), 0, st, src, N, K, dst_lo, Npad, Kpad);
+    hipLaunchKernelGGL(k_convert_pad, dim3(1024), dim3(256), 0, st, src, N, K, dst, Npad, Kpad, dst_lo);
     HIPCHECK(hipGetLastError());
     return 0;
 }
@@ -457,14 +457,10 @@ extern "C" int mst_load_weight(mst_engine* e, const char* name, const float* src
         VEC("norm2.bias", MST_D, w.be2)
 #undef MAT
 #undef VEC
-        if (rc == 0 && r == "self_attn.in_proj_weight") {
-            hipLaunchKernelGGL(k_pack_qkv, dim3(384), dim3(256), 0, st, w.w_in, w.wqkv);
-            HIPCHECK(hipGetLastError());
-        }
-        if (rc == 0 && repack) {      // the fused layer tail reads W_out | W1 | W2 as one pre-packed slab stream (same stream: ordered behind the conversion)
-            hipLaunchKernelGGL(k_pack_tail, dim3(640), dim3(256), 0, st, w.w_out, w.w1, w.w2, w.wtail);
-            HIPCHECK(hipGetLastError());
-        }
+        // The fused kernels' packed copies (k_pack_qkv, k_pack_tail) are made once per re-upload and layer, and only if a sampling launch
+        // follows (ensure_packed): a fine-tune iteration re-uploads all 96 tensors and its training node reads the plain matrices.
+        if (rc == 0 && r == "self_attn.in_proj_weight") w.qkv_dirty = true;
+        if (rc == 0 && repack) w.tail_dirty = true;
     } else if (n == "input_process.poseEmbedding.weight") {
         if (!shape_is(shape, ndim, MST_D, F)) return fail("mst_load_weight: %s: bad shape", name);
         rc = put_matrix(src, MST_D, F, e->w_pose_in, MST_D, e->kin_pad, st, e->w_pose_in_lo);
@@ -730,6 +726,24 @@ static WS ws_slice(const mst_engine* e, int r0, int T) {
               e->xt_lo + (size_t)r0 * T * e->kin_pad};
 }
 
+// Packed weight copies of the two fused kernels, refreshed where stale: on the stream the sampling launch is about to use (the caller
+// orders that stream behind its weight uploads, as for the plain matrices).
+static int ensure_packed(mst_engine* e, hipStream_t st) {
+    for (int l = 0; l < e->cfg.num_layers; l++) {
+        LayerW& w = e->L[l];
+        if (w.qkv_dirty) {
+            hipLaunchKernelGGL(k_pack_qkv, dim3(384), dim3(256), 0, st, w.w_in, w.wqkv);
+            w.qkv_dirty = false;
+        }
+        if (w.tail_dirty) {
+            hipLaunchKernelGGL(k_pack_tail, dim3(640), dim3(256), 0, st, w.w_out, w.w1, w.w2, w.wtail);
+            w.tail_dirty = false;
+        }
+    }
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
 // K6 + K7 + K8 of one layer as one launch (mst_tail.h): one workgroup per 64-token tile
 static int launch_tail(const mst_engine* e, const LayerW& w, const WS& ws, int M, hipStream_t st) {
     static_assert(TailCfg::SMEM <= 163840, "fused layer tail exceeds the 160 KiB LDS");
@@ -936,6 +950,7 @@ extern "C" int mst_forward(mst_engine* e, const float* x, const int64_t* t, cons
     hipStream_t st = (hipStream_t)stream;
     ON_DEVICE(e->cfg.device);
     e->prof_now = e->prof_on;
+    CHECK(ensure_packed(e, st));
     CHECK(timestep_rows(e, (const long long*)t, batch, st));
     const int rows = cfg ? 2 * batch : batch;
     const WS ws = ws_slice(e, 0, frames);
@@ -1054,6 +1069,7 @@ extern "C" int mst_sample_loop(mst_engine* e, const mst_schedule* s, const mst_l
     const int nrun = a->t_start - a->t_end + 1;
     // K1 hoisted: the timestep MLP for every index this loop visits (row j <-> index t_end + j)
     e->prof_now = 0;
+    CHECK(ensure_packed(e, st));
     CHECK(timestep_rows(e, s->tmap + a->t_end, nrun, st));
     // Clips are independent, so the batch runs as `nsplit` slices on separate streams: one slice's kernels fill
     // the CUs the other leaves idle in its prologues, tails and launch gaps (per-launch time is per-CU bound and
