@@ -612,17 +612,27 @@ __global__ __launch_bounds__(512) void k_qkv_attention2(const f16* __restrict__ 
             const int f0 = 48 * wave + 16 * i;          // wave-uniform: the 16-row group lies inside q, k or v
             const int region = f0 >> 7, d = (f0 & 127) + 4 * q4;
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + region * MST_HD + d);
-            if (region == 0) {
+            if (region < 2) {
+                // q (scaled) and k: TWO token tiles per store.  v_permlane16_swap trades the odd 16-lane rows of one tile's packed
+                // values with the even rows of the next tile's (lane map: csrc/probes/probe_permlane.hip), after which a lane holds 8
+                // consecutive features of ONE token: rows q4 = 0, 2 of tile t, rows 1, 3 of tile t + 1.  One ds_write_b128 per lane
+                // instead of two ds_write_b64 -- and conflict-free: 8-byte stores of 16 consecutive rows meet two by two on the
+                // 128-byte bank row of LDS writes whatever 16-byte-chunk swizzle the image has (all of this kernel's bank-conflict
+                // cycles were these stores, profiles/r03_pmc_lds_by_phase.txt).
+                char* img = region == 0 ? qs_img : ks_img;
+                const float mul = region == 0 ? scale : 1.0f;
+                const int ch = ((f0 & 127) >> 3) + (q4 >> 1);
 #pragma unroll
-                for (int t = 0; t < NT16; t++) {
-                    const f32x4 v = (acc[i][t] + b4) * scale;
-                    *reinterpret_cast<uint2*>(qs_img + k_off(16 * t + r15, d >> 3) + (d & 7) * 2) = pack4_f16(v[0], v[1], v[2], v[3]);
+                for (int t = 0; t + 1 < NT16; t += 2) {
+                    const f32x4 va = (acc[i][t] + b4) * mul, vb = (acc[i][t + 1] + b4) * mul;
+                    const uint2 pa = pack4_f16(va[0], va[1], va[2], va[3]), pb = pack4_f16(vb[0], vb[1], vb[2], vb[3]);
+                    const auto r0 = __builtin_amdgcn_permlane16_swap(pa.x, pb.x, false, false);
+                    const auto r1 = __builtin_amdgcn_permlane16_swap(pa.y, pb.y, false, false);
+                    *reinterpret_cast<uint4*>(img + k_off(16 * (t + (q4 & 1)) + r15, ch)) = uint4{r0[0], r1[0], r0[1], r1[1]};
                 }
-            } else if (region == 1) {
-#pragma unroll
-                for (int t = 0; t < NT16; t++) {
-                    const f32x4 v = acc[i][t] + b4;
-                    *reinterpret_cast<uint2*>(ks_img + k_off(16 * t + r15, d >> 3) + (d & 7) * 2) = pack4_f16(v[0], v[1], v[2], v[3]);
+                if (NT16 & 1) {
+                    const f32x4 v = (acc[i][NT16 - 1] + b4) * mul;
+                    *reinterpret_cast<uint2*>(img + k_off(16 * (NT16 - 1) + r15, d >> 3) + (d & 7) * 2) = pack4_f16(v[0], v[1], v[2], v[3]);
                 }
             } else {
 #pragma unroll
