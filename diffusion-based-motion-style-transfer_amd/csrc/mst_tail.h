@@ -302,7 +302,7 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
     tail_barrier();                                                    // every wave's hi rows are in place (each waited for its own fragments behind them); att is dead
     {
         char* x1img = smem + C::OFF_X1;
-        float2* exch = reinterpret_cast<float2*>(smem + C::OFF_ATT);   // [token][wave]
+        float2* exch = reinterpret_cast<float2*>(smem + C::OFF_ATT);   // [wave][token]: a 16-lane group writes / reads 128 contiguous bytes (no bank conflict)
         float mw[4], m2[4];
 #pragma unroll
         for (int nh = 0; nh < 2; nh++)
@@ -336,18 +336,18 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
                     sq += d * d;
                 }
             m2[tb] = quad_sum((sq[0] + sq[1]) + (sq[2] + sq[3]));
-            if (q4 == 0) exch[(16 * tb + t16) * 8 + wave] = make_float2(mw[tb], m2[tb]);
+            if (q4 == 0) exch[wave * 64 + 16 * tb + t16] = make_float2(mw[tb], m2[tb]);
         }
         tail_barrier();
         TAIL_MARK(6)
         float mean[4], rstd[4];
 #pragma unroll
         for (int tb = 0; tb < 4; tb++) {
-            const f32x4* e = reinterpret_cast<const f32x4*>(exch + (16 * tb + t16) * 8);
-            const f32x4 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];     // (mean_w, M2_w) of waves 0 .. 7
-            const float mu = (((e0[0] + e0[2]) + (e1[0] + e1[2])) + ((e2[0] + e2[2]) + (e3[0] + e3[2]))) * 0.125f;
-            const float d0 = e0[0] - mu, d1 = e0[2] - mu, d2 = e1[0] - mu, d3 = e1[2] - mu, d4 = e2[0] - mu, d5 = e2[2] - mu, d6 = e3[0] - mu, d7 = e3[2] - mu;
-            const float within = ((e0[1] + e0[3]) + (e1[1] + e1[3])) + ((e2[1] + e2[3]) + (e3[1] + e3[3]));
+            const float2* e = exch + 16 * tb + t16;
+            const float2 e0 = e[0], e1 = e[64], e2 = e[128], e3 = e[192], e4 = e[256], e5 = e[320], e6 = e[384], e7 = e[448];   // (mean_w, M2_w) of waves 0 .. 7
+            const float mu = (((e0.x + e1.x) + (e2.x + e3.x)) + ((e4.x + e5.x) + (e6.x + e7.x))) * 0.125f;
+            const float d0 = e0.x - mu, d1 = e1.x - mu, d2 = e2.x - mu, d3 = e3.x - mu, d4 = e4.x - mu, d5 = e5.x - mu, d6 = e6.x - mu, d7 = e7.x - mu;
+            const float within = ((e0.y + e1.y) + (e2.y + e3.y)) + ((e4.y + e5.y) + (e6.y + e7.y));
             const float between = ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + ((d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7));
             mean[tb] = mu;
             rstd[tb] = ln_rstd(fmaf(64.0f, between, within));
