@@ -50,8 +50,9 @@ SYMBOL = {
     "qkv_attention_fused": "k_qkv_attention2<13>",
     "ffn1_gelu_gemm": "k_gemm_dma<128,256,2,2,3,1,RowsDirect,DEpiBiasF16<true>,32>",
     "layer_tail_fused": "k_layer_tail",
-    "embed_out_step": "k_gemm_dma<64,512,2,2,4,NX,RowsFrames,DEpiEmbedOut<1>,32>",
-    "embed_in": "k_gemm_dma<64,512,2,2,4,1,RowsDirect,DEpiEmbedIn,32> (writes the conditioning tokens too; + k_frames_f16 on the first step of a loop, later steps get their f16 frame rows from the previous step's epilogue)",
+    # (as rocprofv3 prints them at 263 features: 384-row output tile, split hi + lo activation operand XS = 2; NX = 2 under CFG)
+    "embed_out_step": "k_gemm_dma<64,384,1,3,4,1,RowsFrames,DEpiEmbedOut<1>,32,2>",
+    "embed_in": "k_gemm_dma<64,512,2,2,4,1,RowsDirect,DEpiEmbedIn,32,2> (writes the conditioning tokens too; + k_frames_f16 on the first step of a loop, later steps get their f16 frame rows from the previous step's epilogue)",
     "cond_token": "k_cond_token",
     "qkv_gemm": "k_gemm_dma<...,DEpiBiasF16<false>>",
     "attention": "k_attention<7>",
@@ -272,7 +273,7 @@ def sample_main(args):
             "value": round(value, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16 MFMA operands, fp32 accumulate/stream", "data": "synthetic",
-            "config": {"workload": ("configs[2]" if args.cfg else "configs[1]") +
+            "config": {"workload": workload_label(B, args.cfg) +
                        f": batch {B}/GPU x (263,1,196), {NS}-step DDPM p_sample_loop, 8-layer/512-dim denoiser, "
                        "root_horizontal inpainting" + (", classifier-free guidance scale 2.5 (doubled batch)" if args.cfg else "") +
                        (f", called through diffusion.p_sample_loop ({args.via_boundary} noise)" if args.via_boundary else ""),
@@ -291,6 +292,17 @@ def sample_main(args):
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def workload_label(B, cfg):
+    """Which BASELINE.json config a (batch per GPU, CFG) pair is; anything else is named as what it is, not as a config."""
+    if cfg:
+        return "configs[2]" if B == 64 else f"configs[2]'s path at batch {B} (not a BASELINE size)"
+    if B == 64:
+        return "configs[1]"
+    if B == 128:
+        return "configs[4]'s per-GPU share (1024 clips over 8 GPUs = 128 per GPU; the trainable stack as the denoiser)"
+    return f"configs[1]'s path at batch {B} (not a BASELINE size)"
 
 
 def roofline(prof, rows, clips, T, F, value, flops_per_clip, slices, ev_us=0.0):
@@ -349,15 +361,22 @@ def pmc_traffic(families, rows):
     keys = {"outproj_ln_gemm": "ln_gemm", "ffn2_ln_gemm": "ln_gemm"}
     if rows != 64:
         return None, None
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_final_pmc_traffic.json"):
+    # Only a collection made with THIS build of the kernels counts: tools/pmc_traffic.py records the library's source hash, and a
+    # file from another build (any csrc/ change since) reads as "no traffic figure", never as a stale number.
+    from mst_amd import _native
+    have = _native.built_hash()
+    for name in ("r04_pmc_traffic.json",):
         try:
-            kernels = json.load(open(os.path.join(prof_dir, name)))["kernels"]
+            doc = json.load(open(os.path.join(prof_dir, name)))
+            kernels = doc["kernels"]
         except (OSError, KeyError, ValueError):
             continue
+        if not have or doc.get("source_hash") != have:
+            return None, f"profiles/{name} was collected with library build {doc.get('source_hash')}, this run is {have}: not quoted"
         for f in families:
             k = kernels.get(keys.get(f, f))
             if k:
-                return k["hbm_bytes"], f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 64-clip launches)"
+                return k["hbm_bytes"], f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 64-clip launches, same library build {have})"
     return None, None
 
 
@@ -406,19 +425,26 @@ def finetune_roofline(B, world, s_per_iter):
            "frac": round(achieved / (MFMA_PEAK_TFLOPS * world), 4), "traffic": None,
            "algorithmic_gflop_per_iteration_per_gpu": round(fl * 1e-9, 1),
            "kernel": None, "note": "whole iteration (objective + backward + AdamW) over the dense MFMA peak"}
-    path = os.path.join(ROOT, "profiles", "r03_finetune_kernel_stats_streams1.csv")
-    try:
-        import csv
-        rows = list(csv.DictReader(open(path)))
-        rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
-        tot = sum(float(r["TotalDurationNs"]) for r in rows)
-        top = rows[0]
-        out["kernel"] = top["Name"][:120]
-        out["kernel_share_of_device_time"] = round(float(top["TotalDurationNs"]) / tot, 3)
-        out["kernel_avg_launch_us"] = round(float(top["AverageNs"]) * 1e-3, 2)
-        out["kernel_source"] = "profiles/r03_finetune_kernel_stats_streams1.csv (rocprofv3 --kernel-trace --stats of tools/finetune_bench.py)"
-    except (OSError, KeyError, ValueError, IndexError):
-        pass
+    # The dominant kernel is NOT measured in this run: what follows is read from a committed rocprofv3 summary of another command
+    # (tools/finetune_bench.py under the profiler), possibly another build -- kept apart under `reference_profile`, with the file's hash.
+    for name in ("r04_finetune_kernel_stats_streams1.csv", "r03_finetune_kernel_stats_streams1.csv"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            import csv
+            import hashlib
+            raw = open(path, "rb").read()
+            rows = list(csv.DictReader(raw.decode().splitlines()))
+            rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
+            tot = sum(float(r["TotalDurationNs"]) for r in rows)
+            top = rows[0]
+            out["reference_profile"] = {
+                "file": f"profiles/{name}", "sha256_16": hashlib.sha256(raw).hexdigest()[:16],
+                "what": "rocprofv3 --kernel-trace --stats of tools/finetune_bench.py, an EARLIER run (not this one)",
+                "kernel": top["Name"][:120], "kernel_share_of_device_time": round(float(top["TotalDurationNs"]) / tot, 3),
+                "kernel_avg_launch_us": round(float(top["AverageNs"]) * 1e-3, 2)}
+            break
+        except (OSError, KeyError, ValueError, IndexError):
+            continue
     return out
 
 

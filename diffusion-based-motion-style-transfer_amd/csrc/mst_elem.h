@@ -196,7 +196,8 @@ __global__ void k_step_epilogue(const float* __restrict__ tab, int nsteps, float
 template <int SAMPLER>
 __global__ void k_step_backward(const float* __restrict__ tab, int nsteps, float eta, const float* __restrict__ g_sample,
                                 const float* __restrict__ g_pred, const float* __restrict__ mask, int has_blend,
-                                const long long* __restrict__ t, long long per_clip, float* __restrict__ d_out) {
+                                const long long* __restrict__ t, long long per_clip, const float* __restrict__ pred_clipped,
+                                float* __restrict__ d_out) {
     const int clip = blockIdx.y;
     const StepCoef sc = step_coef(tab, nsteps, (int)t[clip], eta);
     const float dsdp = SAMPLER == 0 ? sc.c1 : sc.sq_abp - sc.dir / sc.srm1ac;
@@ -206,6 +207,10 @@ __global__ void k_step_backward(const float* __restrict__ tab, int nsteps, float
         float g = g_pred ? g_pred[idx] : 0.f;
         if (g_sample) g += g_sample[idx] * dsdp;
         if (has_blend) g *= 1.0f - mask[idx];
+        // clip_denoised (gaussian_diffusion.py:389-395: x.clamp(-1, 1) on the blended prediction, the reference signature's default):
+        // clamp passes the gradient only where it did not saturate.  `pred_clipped` is the forward's x0-hat; a value that came out
+        // at exactly +-1 is taken as saturated (an unclamped prediction of exactly +-1.0f has measure zero).
+        if (pred_clipped && !(fabsf(pred_clipped[idx]) < 1.0f)) g = 0.f;
         d_out[idx] = g;
     }
 }

@@ -170,11 +170,15 @@ struct mst_engine {
     float *temb_hid = nullptr, *temb = nullptr, *textproj = nullptr;
     int temb_cap = 0;
     std::vector<std::string> loaded;
+    std::set<std::string> lo_missing;     // GEMM weights uploaded while precise mode was off: their lo halves f16(w - f16(w)) were not written
+                                          // (a fine-tune iteration re-uploads all 96 tensors and never reads them); precise mode refuses to run on those
     int text_batch = 0, text_cfg = 0;
     TrainWS tw;
     int dbg_layer = -1, dbg_stage = -1;   // stop the trunk after (layer, stage); -1 = run everything
     int fuse_qkv_attn = 1;                // K4 + K5 as one kernel per (clip, head); MST_FUSE_QKV_ATTN=0 keeps them apart
     int fuse_tail = 1;                    // K6 + K7 + K8 as one kernel per 64-token tile (mst_tail.h); MST_FUSE_TAIL=0 keeps them apart
+    int tail_ntb = 0;                     // fused layer tail: 16-token blocks per tile; 0 = per launch (launch_tail), MST_TAIL_NTB=2..4 fixes it
+    int cur_slices = 1;                   // clip slices the launches being enqueued share the chip with (mst_sample_loop; 1 = a lone launch sequence)
     int fuse_frames = 1;                  // sampling loop: a step's epilogue writes the next step's f16 frame rows; MST_FUSE_FRAMES=0 runs k_frames_f16 every step
     int precise = 0;                      // mst_set_precise / MST_PRECISE=1: every layer GEMM of the sampling path multiplies its activation as hi + lo (the small-tile
                                           // kernels at any size, ~2x their MFMA work): for checkpoints whose outlier channels put f16 operands above the 1e-3 bar
@@ -187,9 +191,9 @@ struct mst_engine {
                                           // 39.9, batch 128 77.2 vs 77.1 clips/s; forced at batch 64: 58.7 vs 68.3) -- kept, parity-tested
     int wgrad_stream_on = 1;              // training: wgrads on a second stream beside the dgrad chain (MST_WGRAD_STREAM=0: one stream)
     int nsplit = 0;                       // clip slices of a sampling loop on separate streams: 0 = chosen per call (loop_slices_for), 1..3 = MST_STREAMS
-    static constexpr int MAX_SLICES = 4;
-    hipStream_t aux_stream[MAX_SLICES - 1] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[MAX_SLICES - 1] = {nullptr, nullptr, nullptr};
+    static constexpr int MAX_SLICES = 8;
+    hipStream_t aux_stream[MAX_SLICES - 1] = {nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_SLICES - 1] = {nullptr};
     // sampling-loop state in device memory + the captured step graph (mst_sample_loop)
     LoopDev* ld_dev = nullptr;
     unsigned char* rowflag = nullptr;     // [max_rows][feats] summary of the loop's inpainting mask (k_mask_rowflags)
@@ -342,11 +346,12 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
         // At most three concurrent slices: ROCm maps streams onto four hardware queues by default and the caller's stream holds
         // one, so a fourth slice stream shares a queue with another and the two serialise (measured: 77.1 clips/s at 3, 40.9 at 4).
         int n = atoi(v);
-        e->nsplit = n < 1 ? 1 : (n > 3 ? 3 : n);
+        e->nsplit = n < 1 ? 1 : (n > mst_engine::MAX_SLICES ? mst_engine::MAX_SLICES : n);
     }
     if (const char* v = getenv("MST_FUSE_QKV_ATTN")) e->fuse_qkv_attn = atoi(v);
     if (const char* v = getenv("MST_FUSE_TAIL")) e->fuse_tail = atoi(v) != 0;
     if (const char* v = getenv("MST_FUSE_FRAMES")) e->fuse_frames = atoi(v) != 0;
+    if (const char* v = getenv("MST_TAIL_NTB")) { int n = atoi(v); e->tail_ntb = (n >= 2 && n <= 4) ? n : 0; }
     if (const char* v = getenv("MST_WGRAD_STREAM")) e->wgrad_stream_on = atoi(v) != 0;
     if (const char* v = getenv("MST_SMALL_M")) e->small_m = atoi(v);
     if (const char* v = getenv("MST_PRECISE")) e->precise = atoi(v) != 0;
@@ -440,8 +445,8 @@ extern "C" int mst_load_weight(mst_engine* e, const char* name, const float* src
         if (layer < 0 || layer >= e->cfg.num_layers) return fail("mst_load_weight: layer %d out of range", layer);
         LayerW& w = e->L[layer];
         std::string r(rest);
-#define MAT(key, N_, K_, dst) if (r == key) { if (!shape_is(shape, ndim, N_, K_)) return fail("mst_load_weight: %s: bad shape", name); rc = put_matrix(src, N_, K_, dst, N_, K_, st, dst##_lo); if (!rc) rc = put_matrix_t(src, N_, K_, dst##T, st); repack = dst != w.w_in; }
-        bool repack = false;
+#define MAT(key, N_, K_, dst) if (r == key) { if (!shape_is(shape, ndim, N_, K_)) return fail("mst_load_weight: %s: bad shape", name); rc = put_matrix(src, N_, K_, dst, N_, K_, st, e->precise ? dst##_lo : nullptr); if (!rc) rc = put_matrix_t(src, N_, K_, dst##T, st); repack = dst != w.w_in; is_gemm_w = true; }
+        bool repack = false, is_gemm_w = false;
 #define VEC(key, N_, dst) if (r == key) { if (!shape_is(shape, ndim, N_)) return fail("mst_load_weight: %s: bad shape", name); rc = put_vector(src, N_, dst, N_, st); }
         MAT("self_attn.in_proj_weight", 3 * MST_D, MST_D, w.w_in)
         VEC("self_attn.in_proj_bias", 3 * MST_D, w.b_in)
@@ -461,9 +466,11 @@ extern "C" int mst_load_weight(mst_engine* e, const char* name, const float* src
         // follows (ensure_packed): a fine-tune iteration re-uploads all 96 tensors and its training node reads the plain matrices.
         if (rc == 0 && r == "self_attn.in_proj_weight") w.qkv_dirty = true;
         if (rc == 0 && repack) w.tail_dirty = true;
+        if (rc == 0 && is_gemm_w) { if (e->precise) e->lo_missing.erase(n); else e->lo_missing.insert(n); }
     } else if (n == "input_process.poseEmbedding.weight") {
         if (!shape_is(shape, ndim, MST_D, F)) return fail("mst_load_weight: %s: bad shape", name);
-        rc = put_matrix(src, MST_D, F, e->w_pose_in, MST_D, e->kin_pad, st, e->w_pose_in_lo);
+        rc = put_matrix(src, MST_D, F, e->w_pose_in, MST_D, e->kin_pad, st, e->precise ? e->w_pose_in_lo : nullptr);
+        if (!rc) { if (e->precise) e->lo_missing.erase(n); else e->lo_missing.insert(n); }
         if (!rc) {      // [512][F] -> [F (padded to fout_pad)][512]
             hipLaunchKernelGGL(k_convert_transpose, dim3((F + 31) / 32, (MST_D + 31) / 32), dim3(256), 0, st, src, MST_D, F, e->w_pose_inT, MST_D);
             HIPCHECK(hipGetLastError());
@@ -473,7 +480,8 @@ extern "C" int mst_load_weight(mst_engine* e, const char* name, const float* src
         rc = put_vector(src, MST_D, e->b_pose_in, MST_D, st);
     } else if (n == "output_process.poseFinal.weight") {
         if (!shape_is(shape, ndim, F, MST_D)) return fail("mst_load_weight: %s: bad shape", name);
-        rc = put_matrix(src, F, MST_D, e->w_pose_out, e->fout_pad, MST_D, st, e->w_pose_out_lo);
+        rc = put_matrix(src, F, MST_D, e->w_pose_out, e->fout_pad, MST_D, st, e->precise ? e->w_pose_out_lo : nullptr);
+        if (!rc) { if (e->precise) e->lo_missing.erase(n); else e->lo_missing.insert(n); }
         if (!rc) {      // [F][512] -> [512][F (padded to kin_pad)]
             hipLaunchKernelGGL(k_convert_transpose, dim3((MST_D + 31) / 32, (F + 31) / 32), dim3(256), 0, st, src, F, MST_D, e->w_pose_outT, e->kin_pad);
             HIPCHECK(hipGetLastError());
@@ -733,23 +741,43 @@ static int ensure_packed(mst_engine* e, hipStream_t st) {
         LayerW& w = e->L[l];
         if (w.qkv_dirty) {
             hipLaunchKernelGGL(k_pack_qkv, dim3(384), dim3(256), 0, st, w.w_in, w.wqkv);
+            HIPCHECK(hipGetLastError());                  // a flag is cleared only behind a launch that was accepted
             w.qkv_dirty = false;
         }
         if (w.tail_dirty) {
             hipLaunchKernelGGL(k_pack_tail, dim3(640), dim3(256), 0, st, w.w_out, w.w1, w.w2, w.wtail);
+            HIPCHECK(hipGetLastError());
             w.tail_dirty = false;
         }
     }
-    HIPCHECK(hipGetLastError());
     return 0;
 }
 
 // K6 + K7 + K8 of one layer as one launch (mst_tail.h): one workgroup per 64-token tile
 static int launch_tail(const mst_engine* e, const LayerW& w, const WS& ws, int M, hipStream_t st) {
     static_assert(TailCfg::SMEM <= 163840, "fused layer tail exceeds the 160 KiB LDS");
-    CHECK(ensure_dyn_lds((const void*)k_layer_tail, TailCfg::SMEM));
-    hipLaunchKernelGGL(k_layer_tail, dim3((M + TailCfg::BT - 1) / TailCfg::BT), dim3(512), TailCfg::SMEM, st, ws.att, w.wtail,
-                       w.b_out, w.g1, w.be1, w.b1, w.b2, w.g2, w.be2, ws.hx, ws.hl, e->gelu_tab, M);
+    // Tile height (16 NTB tokens; mst_tail.h).  A launch that has the chip to itself and does not fill it runs on more, lower tiles; the
+    // clip slices of a sampling loop share the chip (3 x 68 tiles of 64 tokens at the headline batch) and keep the 64-token tile: 48-token
+    // tiles measured 99.4 against 105.3 clips/s there, 32-token tiles 88.3 (tools/r4_ntb_ab.sh).
+    int ntb = e->tail_ntb;
+    if (ntb == 0) {
+        ntb = 4;
+        if (e->cur_slices == 1) {
+            if ((M + 31) / 32 <= 256) ntb = 2;
+            else if ((M + 47) / 48 <= 256) ntb = 3;
+        }
+    }
+    const int grid = (M + 16 * ntb - 1) / (16 * ntb);
+#define TAIL_LAUNCH(N_)                                                                                                          \
+    do {                                                                                                                         \
+        CHECK(ensure_dyn_lds((const void*)k_layer_tail<N_>, TailCfg::SMEM));                                                     \
+        hipLaunchKernelGGL(k_layer_tail<N_>, dim3(grid), dim3(512), TailCfg::SMEM, st, ws.att, w.wtail, w.b_out, w.g1, w.be1,     \
+                           w.b1, w.b2, w.g2, w.be2, ws.hx, ws.hl, e->gelu_tab, M);                                               \
+    } while (0)
+    if (ntb == 2) TAIL_LAUNCH(2);
+    else if (ntb == 3) TAIL_LAUNCH(3);
+    else TAIL_LAUNCH(4);
+#undef TAIL_LAUNCH
     HIPCHECK(hipGetLastError());
     return 0;
 }
@@ -938,6 +966,9 @@ static int check_ready(mst_engine* e, int batch, int frames, int cfg) {
     if (frames < 1 || frames > e->cfg.max_frames) return fail("frames %d outside 1..%d", frames, e->cfg.max_frames);
     int rows = cfg ? 2 * batch : batch;
     if (batch < 1 || rows > e->cfg.max_rows) return fail("batch %d (rows %d) exceeds max_rows %d", batch, rows, e->cfg.max_rows);
+    if (e->precise && !e->lo_missing.empty())
+        return fail("precise mode: %zu weight matrices (first: %s) were uploaded while it was off, without their lo halves: upload them again",
+                    e->lo_missing.size(), e->lo_missing.begin()->c_str());
     if (e->text_batch != batch || e->text_cfg != (cfg ? 1 : 0))
         return fail("mst_set_text was not called for batch %d cfg %d (have %d/%d)", batch, cfg, e->text_batch, e->text_cfg);
     return 0;
@@ -950,6 +981,7 @@ extern "C" int mst_forward(mst_engine* e, const float* x, const int64_t* t, cons
     hipStream_t st = (hipStream_t)stream;
     ON_DEVICE(e->cfg.device);
     e->prof_now = e->prof_on;
+    e->cur_slices = 1;
     CHECK(ensure_packed(e, st));
     CHECK(timestep_rows(e, (const long long*)t, batch, st));
     const int rows = cfg ? 2 * batch : batch;
@@ -996,6 +1028,7 @@ struct LoopPlan {
 // writes them for the next one (mst_sample_loop decides; see DEpiEmbedOut::xt_next)
 static int enqueue_step(mst_engine* e, const LoopPlan& p, int joff, int nsj, bool frames_ready = false, bool frames_next = false) {
     const mst_loop_args* a = p.a;
+    e->cur_slices = nsj;
     for (int sl = 0; sl < nsj; sl++) {
         const int per = (a->batch + nsj - 1) / nsj;          // clips per slice (last one may be short)
         const int c0 = sl * per;
@@ -1075,7 +1108,7 @@ extern "C" int mst_sample_loop(mst_engine* e, const mst_schedule* s, const mst_l
     // the CUs the other leaves idle in its prologues, tails and launch gaps (per-launch time is per-CU bound and
     // flat in the block count at this size).  CFG batches are sliced the same way (cond + uncond twins stay together).
     LoopPlan p{s, a, loop_slices_for(e, a->batch, a->cfg, a->frames), (size_t)e->cfg.feats * a->frames, (size_t)a->batch * e->cfg.feats * a->frames,
-               {st, e->aux_stream[0], e->aux_stream[1], e->aux_stream[2]}};
+               {st, e->aux_stream[0], e->aux_stream[1], e->aux_stream[2], e->aux_stream[3], e->aux_stream[4], e->aux_stream[5], e->aux_stream[6]}};
     // per-call arguments -> device (pinned staging slot; the slot's previous upload has long completed when it comes round again)
     {
         const int slot = e->ld_next;
@@ -1097,7 +1130,7 @@ extern "C" int mst_sample_loop(mst_engine* e, const mst_schedule* s, const mst_l
     std::vector<long long> key = {a->batch, a->frames, a->cfg, a->sampler, a->noise_mode, a->mask_noise, a->clip_denoised,
                                   a->inpainting_mask_dev != nullptr, a->inpainted_motion_dev != nullptr, a->xstart_dump_dev != nullptr,
                                   a->scale_dev != nullptr, p.nsl, U, (long long)(size_t)s->tab, s->n, e->small_m, e->fuse_tail,
-                                  e->fuse_qkv_attn, e->ln128_min_m};
+                                  e->fuse_qkv_attn, e->ln128_min_m, e->precise, e->tail_ntb};      // every switch run_trunk / loop_slices_for branch on
     const bool use_graph = e->graph_on && !e->prof_on && e->dbg_stage < 0 && nrun >= 2 * U;
     bool forked = false;
     auto steps = [&]() -> int {
@@ -1203,7 +1236,7 @@ extern "C" int mst_step_epilogue(const mst_schedule* s, const float* model_out, 
 
 extern "C" int mst_step_backward(const mst_schedule* s, const float* g_sample, const float* g_pred, const float* mask,
                                  int32_t has_blend, const int64_t* t, int32_t batch, int64_t per_clip, int32_t sampler, float eta,
-                                 float* d_model_out, void* stream) {
+                                 const float* pred_clipped, float* d_model_out, void* stream) {
     if (!s || !t || !d_model_out || batch < 1 || per_clip < 1 || (!g_sample && !g_pred) || (has_blend && !mask))
         return fail("mst_step_backward: bad arguments");
     ON_DEVICE(s->device);
@@ -1211,10 +1244,10 @@ extern "C" int mst_step_backward(const mst_schedule* s, const float* g_sample, c
     if (gx > 2048) gx = 2048;
     if (sampler == MST_SAMPLER_DDPM)
         hipLaunchKernelGGL(k_step_backward<0>, dim3(gx, batch), dim3(256), 0, (hipStream_t)stream, s->tab, s->n, eta, g_sample, g_pred, mask,
-                           has_blend, (const long long*)t, (long long)per_clip, d_model_out);
+                           has_blend, (const long long*)t, (long long)per_clip, pred_clipped, d_model_out);
     else if (sampler == MST_SAMPLER_DDIM)
         hipLaunchKernelGGL(k_step_backward<1>, dim3(gx, batch), dim3(256), 0, (hipStream_t)stream, s->tab, s->n, eta, g_sample, g_pred, mask,
-                           has_blend, (const long long*)t, (long long)per_clip, d_model_out);
+                           has_blend, (const long long*)t, (long long)per_clip, pred_clipped, d_model_out);
     else
         return fail("mst_step_backward: bad sampler %d", sampler);
     HIPCHECK(hipGetLastError());
@@ -1861,7 +1894,8 @@ extern "C" int mst_recover_from_ric(const float* sample, const float* mean, cons
 extern "C" int mst_set_precise(mst_engine* e, int32_t on) {
     if (!e) return fail("mst_set_precise: null engine");
     e->precise = on != 0;
-    return 0;
+    // 2 = switched on, but weights uploaded so far lack their lo halves: the caller uploads them again (DenoiserEngine.set_precise does)
+    return (e->precise && !e->lo_missing.empty()) ? 2 : 0;
 }
 
 // ------------------------------------------------------------------------------------------ debug ABI

@@ -89,6 +89,17 @@ __global__ __launch_bounds__(256) void k_pack_tail(const f16* __restrict__ w_out
 }
 
 __device__ __forceinline__ void tail_fence() { asm volatile("" ::: "memory"); }
+// add_half() is INLINE ASM (v_fma_mix_f32), and hipcc's hazard recognizer does not look inside inline asm: where it reads a register an
+// MFMA has just written, nothing inserts the wait states the hardware needs between an XDL write and a VALU read of the same VGPR (it
+// is not interlocked).  hipcc also moves MFMAs -- register-only instructions -- across asm barriers, so round 3's kernel was right only
+// by the distance the scheduler happened to leave (found in round 4: the 48-token instantiation interleaved pass 1's last MFMAs with the
+// lo-residual adds and came out 7 % wrong).  tail_acc_settle(): no instruction crosses, and every MFMA issued in front of it has written
+// its result behind it (v_mfma_f32_16x16x32_f16 -> VALU read: 8 wait states by hipcc's own count; 10 here).
+__device__ __forceinline__ void tail_acc_settle() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 9" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
 __device__ __forceinline__ void tail_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }   // LDS only: the stream stays in flight
 
 // GELU(x) = x Phi(x), Phi by linear interpolation in the LDS table (TailCfg::OFF_TAB): 7 VALU ops + one 8-byte LDS read per value
@@ -106,6 +117,11 @@ __device__ __forceinline__ void tail_glds1(unsigned voff, unsigned long long sba
                  : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
 }
 
+// NTB = 16-token blocks per tile (tile = 16 NTB tokens): 4 for launches that fill the chip or share it with other clip slices, 3 / 2 for
+// a lone launch of fewer tokens.  A tile streams all 2.5 MB of the layer through its CU's L1 (64 B / clk: 41 k cycles) whatever its
+// height; at 64 tokens its MFMA work is another 41 k cycles on every SIMD.  csrc/probes/tail_clock.hip, 4 334 tokens alone on the
+// chip: 64-token tiles (68 workgroups) 37.5 us per launch, 48-token (91) 32.6 us, 32-token (136) 30.4 us.
+template <int NTB>
 __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att, const f16* __restrict__ wt,
                                                     const float* __restrict__ b_out, const float* __restrict__ g1, const float* __restrict__ be1,
                                                     const float* __restrict__ b1, const float* __restrict__ b2,
@@ -117,7 +133,8 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t16 = lane & 15, q4 = lane >> 4;                       // accumulator map: token 16 tb + t16, features .. + 4 q4 + i
-    const int tok0 = blockIdx.x * C::BT;
+    constexpr int BT = 16 * NTB, RPW = 2 * NTB;                      // tile rows; rows per wave in the row-wise stages (DMA, LayerNorm2)
+    const int tok0 = blockIdx.x * BT;
     const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     TAIL_MARK(0)
 
@@ -140,18 +157,18 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
     // residual rows of the tile -> [OFF_X1, +64 KB) in the att / x1 image layout; wave w fills rows [8 w, 8 w + 8)
     auto stage_rows = [&](const f16* src) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int r = 8 * wave + j;
+        for (int j = 0; j < RPW; j++) {
+            const int r = RPW * wave + j;
             int tok = tok0 + r;
             if (tok >= M) tok = M - 1;                                // last tile: clamp (rows beyond M are never stored)
             const unsigned voff = (unsigned)tok * (unsigned)(MST_D * 2) + (unsigned)((lane ^ (r & 15)) << 4);
             tail_glds1(voff, (unsigned long long)src, __builtin_amdgcn_readfirstlane(smem_base + C::OFF_X1 + r * 1024));
         }
     };
-    constexpr int ROW_OPS = 8;
+    constexpr int ROW_OPS = RPW;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int r = 8 * wave + j;
+    for (int j = 0; j < RPW; j++) {
+        const int r = RPW * wave + j;
         int tok = tok0 + r;
         if (tok >= M) tok = M - 1;
         const unsigned voff = (unsigned)tok * (unsigned)(MST_D * 2) + (unsigned)((lane ^ (r & 15)) << 4);
@@ -184,18 +201,18 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
 
     // token fragments of k-step k32 from an image with ROWB-byte rows: lane -> token 16 tb + t16, chunk (4 k32 + q4) ^ t16
     const unsigned xlane1k = (unsigned)t16 * 1024u, xlane512 = (unsigned)t16 * 512u, xswz = (unsigned)((q4 ^ t16) << 4);
-    auto xread = [&](const char* img, auto rowb, int k32, f16x8 (&x)[4]) {
+    auto xread = [&](const char* img, auto rowb, int k32, f16x8 (&x)[NTB]) {
         constexpr int ROWB = decltype(rowb)::value;
         const char* p = img + (ROWB == 1024 ? xlane1k : xlane512) + (((unsigned)k32 << 6) ^ xswz);
 #pragma unroll
-        for (int tb = 0; tb < 4; tb++) x[tb] = *reinterpret_cast<const f16x8*>(p + tb * 16 * ROWB);
+        for (int tb = 0; tb < NTB; tb++) x[tb] = *reinterpret_cast<const f16x8*>(p + tb * 16 * ROWB);
     };
     using RB1K = std::integral_constant<int, 1024>;
     using RB512 = std::integral_constant<int, 512>;
 
-    f32x4 acc[2][2][4];                     // [feature half nh][16-row block rb][16-token block tb]
-    f32x4 acch[2][4];                       // FFN1 chunk: [rb][tb]
-    f16x8 xs[2][4];                         // token fragments, double-buffered by k-step parity
+    f32x4 acc[2][2][NTB];                   // [feature half nh][16-row block rb][16-token block tb]
+    f32x4 acch[2][NTB];                     // FFN1 chunk: [rb][tb]
+    f16x8 xs[2][NTB];                       // token fragments, double-buffered by k-step parity
 
     // One unrolled pass = D fragments (`more`: another pass of the same phase follows).  RA fragments per k-step (4: out-proj / FFN2, both feature halves; 2: FFN1), each against the
     // step's four token fragments.  LOAD = false: the stream's last pass (nothing left to request; the waits count down).
@@ -222,11 +239,11 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
                     if constexpr (RA == 4) {
                         constexpr int nh = (J >> 1) & 1, rb = J & 1;
 #pragma unroll
-                        for (int tb = 0; tb < 4; tb++) acc[nh][rb][tb] = mfma16(wf, xs[(J / RA) & 1][tb], acc[nh][rb][tb]);
+                        for (int tb = 0; tb < NTB; tb++) acc[nh][rb][tb] = mfma16(wf, xs[(J / RA) & 1][tb], acc[nh][rb][tb]);
                     } else {
                         constexpr int rb = J & 1;
 #pragma unroll
-                        for (int tb = 0; tb < 4; tb++) acch[rb][tb] = mfma16(wf, xs[(J / RA) & 1][tb], acch[rb][tb]);
+                        for (int tb = 0; tb < NTB; tb++) acch[rb][tb] = mfma16(wf, xs[(J / RA) & 1][tb], acch[rb][tb]);
                     }
                     if constexpr (LOAD) tail_wload<(J & 3) * 1024>(q[J], w_voff, (unsigned long long)(wnext + (J >> 2) * 4096));
                 };
@@ -257,7 +274,7 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
 #pragma unroll
         for (int rb = 0; rb < 2; rb++)
 #pragma unroll
-            for (int tb = 0; tb < 4; tb++) acc[nh][rb][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int tb = 0; tb < NTB; tb++) acc[nh][rb][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D + 1) : "memory");       // this wave's att rows have landed (behind them: 1 .. 3 table pieces and the D fragments)
     tail_barrier();                                                    // ... and everybody's
     TAIL_MARK(1)
@@ -272,6 +289,7 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
         pass(img, RB1K(), RA4(), std::integral_constant<int, 1 + 2 * ROW_OPS>(), 0, true, [](int) {});
         pass(img, RB1K(), RA4(), LD1(), D / 4, true, [](int) {});
         // the lo rows are older than the fragments requested by pass 0, which pass 1 has consumed: landed
+        tail_acc_settle();                                             // the adds below are inline asm reading MFMA results
         tail_barrier();
         {
             const char* stg = smem + C::OFF_X1;
@@ -280,7 +298,7 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
 #pragma unroll
                 for (int rb = 0; rb < 2; rb++)
 #pragma unroll
-                    for (int tb = 0; tb < 4; tb++) {
+                    for (int tb = 0; tb < NTB; tb++) {
                         const uint2 l = *reinterpret_cast<const uint2*>(stg + slot1k(nh, rb, tb));
                         f32x4& a = acc[nh][rb][tb];
                         a = f32x4{add_half<0>(l.x, a[0]), add_half<1>(l.x, a[1]), add_half<0>(l.y, a[2]), add_half<1>(l.y, a[3])};
@@ -303,14 +321,14 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
     {
         char* x1img = smem + C::OFF_X1;
         float2* exch = reinterpret_cast<float2*>(smem + C::OFF_ATT);   // [wave][token]: a 16-lane group writes / reads 128 contiguous bytes (no bank conflict)
-        float mw[4], m2[4];
+        float mw[NTB], m2[NTB];
 #pragma unroll
         for (int nh = 0; nh < 2; nh++)
 #pragma unroll
             for (int rb = 0; rb < 2; rb++) {
                 const f32x4 bo = *reinterpret_cast<const f32x4*>(b_out + 256 * nh + 32 * wave + 16 * rb + 4 * q4);
 #pragma unroll
-                for (int tb = 0; tb < 4; tb++) {
+                for (int tb = 0; tb < NTB; tb++) {
                     const uint2 h = *reinterpret_cast<const uint2*>(x1img + slot1k(nh, rb, tb));
                     const f32x4 a = acc[nh][rb][tb] + bo;
                     acc[nh][rb][tb] = f32x4{add_half<0>(h.x, a[0]), add_half<1>(h.x, a[1]), add_half<0>(h.y, a[2]), add_half<1>(h.y, a[3])};
@@ -321,12 +339,12 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
             return v + __shfl_xor(v, 32);
         };
 #pragma unroll
-        for (int tb = 0; tb < 4; tb++) {
+        for (int tb = 0; tb < NTB; tb++) {
             f32x4 t = (acc[0][0][tb] + acc[0][1][tb]) + (acc[1][0][tb] + acc[1][1][tb]);
             mw[tb] = quad_sum((t[0] + t[1]) + (t[2] + t[3])) * (1.0f / 64.0f);
         }
 #pragma unroll
-        for (int tb = 0; tb < 4; tb++) {
+        for (int tb = 0; tb < NTB; tb++) {
             f32x4 sq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int nh = 0; nh < 2; nh++)
@@ -340,9 +358,9 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
         }
         tail_barrier();
         TAIL_MARK(6)
-        float mean[4], rstd[4];
+        float mean[NTB], rstd[NTB];
 #pragma unroll
-        for (int tb = 0; tb < 4; tb++) {
+        for (int tb = 0; tb < NTB; tb++) {
             const float2* e = exch + 16 * tb + t16;
             const float2 e0 = e[0], e1 = e[64], e2 = e[128], e3 = e[192], e4 = e[256], e5 = e[320], e6 = e[384], e7 = e[448];   // (mean_w, M2_w) of waves 0 .. 7
             const float mu = (((e0.x + e1.x) + (e2.x + e3.x)) + ((e4.x + e5.x) + (e6.x + e7.x))) * 0.125f;
@@ -359,7 +377,7 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
                 const int f = 256 * nh + 32 * wave + 16 * rb + 4 * q4;
                 const f32x4 g = *reinterpret_cast<const f32x4*>(g1 + f), be = *reinterpret_cast<const f32x4*>(be1 + f);
 #pragma unroll
-                for (int tb = 0; tb < 4; tb++) {
+                for (int tb = 0; tb < NTB; tb++) {
                     const f32x4 y = (acc[nh][rb][tb] - mean[tb]) * (g * rstd[tb]) + be;
                     acc[nh][rb][tb] = y;
                     *reinterpret_cast<uint2*>(x1img + slot1k(nh, rb, tb)) = pack4_f16(y[0], y[1], y[2], y[3]);
@@ -389,7 +407,7 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
             for (int rb = 0; rb < 2; rb++) {
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(bb + 16 * rb);
 #pragma unroll
-                for (int tb = 0; tb < 4; tb++) acch[rb][tb] = bv;
+                for (int tb = 0; tb < NTB; tb++) acch[rb][tb] = bv;
             }
             xread(x1img, RB1K(), 0, xs[0]);
 #pragma unroll 1
@@ -414,14 +432,15 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
             while (__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile unsigned*>(arrived + hc)) < 8u) __builtin_amdgcn_s_sleep(1);
             tail_fence();
         };
-        static_assert(C::F2_FRAG / 4 == 8, "FFN2 of a chunk = eight k-steps: one GELU group (rb, tb) per k-step");
+        static_assert(C::F2_FRAG / 4 == 8 && 2 * NTB <= 8, "FFN2 of a chunk = eight k-steps: at most one GELU group (rb, tb) per k-step");
+        constexpr int NG = 2 * NTB;                                    // GELU groups per chunk: g -> (rb, tb) = (g / NTB, g % NTB)
         constexpr int NP2 = C::F2_FRAG / D, ST2 = D / 4;               // FFN2 passes per chunk, k-steps per pass
         ffn1(0);
         TAIL_MARK(12)
 #pragma unroll
         for (int rb = 0; rb < 2; rb++)
 #pragma unroll
-            for (int tb = 0; tb < 4; tb++) gelu_group(0, rb, tb);
+            for (int tb = 0; tb < NTB; tb++) gelu_group(0, rb, tb);
         announce(0);
         TAIL_MARK(13)
 #pragma unroll 1
@@ -434,7 +453,7 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
             xread(himg, RB512(), 0, xs[0]);
 #pragma unroll
             for (int ps = 0; ps < NP2; ps++)
-                pass(himg, RB512(), RA4(), LD1(), ps * ST2, ps + 1 < NP2, [&](int s) { const int g = ps * ST2 + s; gelu_group(hc + 1, g >> 2, g & 3); });
+                pass(himg, RB512(), RA4(), LD1(), ps * ST2, ps + 1 < NP2, [&](int s) { const int g = ps * ST2 + s; if (g < NG) gelu_group(hc + 1, g / NTB, g % NTB); });
             announce(hc + 1);
             TAIL_MARK(16 + 3 * hc)
         }
@@ -455,7 +474,7 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
     // =========================================================================================== LayerNorm2 -> the stream
     {
 #pragma unroll
-        for (int tb = 0; tb < 4; tb++) {
+        for (int tb = 0; tb < NTB; tb++) {
             char* trow = smem + (16 * tb + t16) * C::LN_LD;
 #pragma unroll
             for (int nh = 0; nh < 2; nh++)
@@ -468,26 +487,26 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
         const f32x4 ba = *reinterpret_cast<const f32x4*>(b2 + fa), bb = *reinterpret_cast<const f32x4*>(b2 + fb);
         const f32x4 ga = *reinterpret_cast<const f32x4*>(g2 + fa), gb = *reinterpret_cast<const f32x4*>(g2 + fb);
         const f32x4 ea = *reinterpret_cast<const f32x4*>(be2 + fa), eb = *reinterpret_cast<const f32x4*>(be2 + fb);
-        f32x4 xa[8], xb[8];
-        float mean[8], rstd[8];
+        f32x4 xa[RPW], xb[RPW];
+        float mean[RPW], rstd[RPW];
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const char* srow = smem + (8 * wave + r) * C::LN_LD;
+        for (int r = 0; r < RPW; r++) {
+            const char* srow = smem + (RPW * wave + r) * C::LN_LD;
             xa[r] = *reinterpret_cast<const f32x4*>(srow + fa * 4) + ba;
             xb[r] = *reinterpret_cast<const f32x4*>(srow + fb * 4) + bb;
             const f32x4 t = xa[r] + xb[r];
             mean[r] = wave_sum((t[0] + t[1]) + (t[2] + t[3])) * (1.0f / MST_D);
         }
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
+        for (int r = 0; r < RPW; r++) {
             xa[r] -= mean[r];
             xb[r] -= mean[r];
             const f32x4 sq = xa[r] * xa[r] + xb[r] * xb[r];
             rstd[r] = ln_rstd(wave_sum((sq[0] + sq[1]) + (sq[2] + sq[3])));
         }
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const int tok = tok0 + 8 * wave + r;
+        for (int r = 0; r < RPW; r++) {
+            const int tok = tok0 + RPW * wave + r;
             if (tok < M) {
                 const size_t off = (size_t)tok * MST_D;
                 uint2 h, l;

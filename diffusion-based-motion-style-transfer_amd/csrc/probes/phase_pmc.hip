@@ -37,7 +37,7 @@ int main() {
     CK(hipMemcpy(v, ones.data(), 4096 * 4, hipMemcpyHostToDevice));
     auto ka = k_qkv_attention2<13>;
     CK(hipFuncSetAttribute((const void*)ka, hipFuncAttributeMaxDynamicSharedMemorySize, QA2Tile<13>::SMEM));
-    CK(hipFuncSetAttribute((const void*)k_layer_tail, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
+    CK(hipFuncSetAttribute((const void*)k_layer_tail<4>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
     // attention: stop at 1 (projection done), 2 (images written), 3 (scores + softmax), 4 = end; each twice (the first dispatch of a value warms up)
     const int a_stops[] = {1, 1, 2, 2, 3, 3, 4, 4};
     for (int st : a_stops) {
@@ -49,7 +49,7 @@ int main() {
     const int t_stops[] = {1, 1, 2, 2, 3, 3, 12, 12, 13, 13, 4, 4, 5, 5};
     for (int st : t_stops) {
         CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stop), &st, sizeof(int)));
-        hipLaunchKernelGGL(k_layer_tail, dim3((M + C::BT - 1) / C::BT), dim3(512), C::SMEM, 0, att, wt, v, v, v, v, v, v, v, hx, hl, v, M);
+        hipLaunchKernelGGL(k_layer_tail<4>, dim3((M + C::BT - 1) / C::BT), dim3(512), C::SMEM, 0, att, wt, v, v, v, v, v, v, v, hx, hl, v, M);
         CK(hipDeviceSynchronize());
     }
     printf("done: 8 attention dispatches (stops 1 1 2 2 3 3 4 4), 14 tail dispatches (stops 1 1 2 2 3 3 12 12 13 13 4 4 5 5)\n");

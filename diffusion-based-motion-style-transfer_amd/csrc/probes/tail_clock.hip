@@ -2,7 +2,7 @@
 // every wave stamps s_memtime (shader clock) / s_memrealtime (100 MHz) at the phase boundaries (mst_tail.h, TAIL_MARK).  The
 // waves of a workgroup run decoupled between barriers, so a boundary's time is the LAST wave's stamp.  Diagnostic build only:
 // the product library is compiled without MST_PROBE_BUILD and contains no stamp.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tail_clock.hip -o bin/tail_clock && bin/tail_clock [batch=64]
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DTAIL_NTB=3] tail_clock.hip -o bin/tail_clock && bin/tail_clock [batch=64 [tokens]]
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
@@ -15,9 +15,13 @@ __device__ unsigned long long g_tail_stamp[1024][8][48];
 #endif
 #include TAIL_HEADER
 using namespace mst;
+#ifndef TAIL_NTB
+#define TAIL_NTB 4           // -DTAIL_NTB=3 / 2: 48- / 32-token tiles
+#endif
+#define KTAIL k_layer_tail<TAIL_NTB>
 
 int main(int argc, char** argv) {
-    const int B = argc > 1 ? atoi(argv[1]) : 64, M = B * 197;
+    const int B = argc > 1 ? atoi(argv[1]) : 64, M = argc > 2 ? atoi(argv[2]) : B * 197;   // [batch] or [_ tokens]
     using C = TailCfg;
     const size_t nx = (size_t)(M + 64) * MST_D, nw = C::LAYER_BYTES / 2;
     f16 *att, *wt, *hx, *hl; float* v;
@@ -31,14 +35,14 @@ int main(int argc, char** argv) {
     hipMemcpy(wt, h.data(), nw * 2, hipMemcpyHostToDevice);
     std::vector<float> ones(4096, 1.0f);
     hipMemcpy(v, ones.data(), 4096 * 4, hipMemcpyHostToDevice);
-    if (hipFuncSetAttribute((const void*)k_layer_tail, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM) != hipSuccess) { printf("LDS attribute failed\n"); return 1; }
-    const int grid = (M + C::BT - 1) / C::BT;
+    if (hipFuncSetAttribute((const void*)KTAIL, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM) != hipSuccess) { printf("LDS attribute failed\n"); return 1; }
+    const int grid = (M + 16 * TAIL_NTB - 1) / (16 * TAIL_NTB);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; rep++) {
         const int iters = rep == 0 ? 100 : 20000;
         hipEventRecord(e0);
         for (int i = 0; i < iters; i++)
-            hipLaunchKernelGGL(k_layer_tail, dim3(grid), dim3(512), C::SMEM, 0, att, wt, v, v, v, v, v, v, v, hx, hl, v, M);
+            hipLaunchKernelGGL(KTAIL, dim3(grid), dim3(512), C::SMEM, 0, att, wt, v, v, v, v, v, v, v, hx, hl, v, M);
         hipEventRecord(e1);
         if (hipEventSynchronize(e1) != hipSuccess) { printf("kernel failed: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
         float ms; hipEventElapsedTime(&ms, e0, e1);

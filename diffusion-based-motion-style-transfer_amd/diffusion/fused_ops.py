@@ -24,18 +24,17 @@ def _cuda_f32(t, what):
 class FusedStepFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model_out, x, t, noise, mask, motion, schedule, sampler, eta, mask_noise, clip_denoised):
-        if clip_denoised and model_out.requires_grad:
-            raise NotImplementedError("clip_denoised is not differentiated (no caller of the *_with_grad samplers clips)")
         sample, pred = schedule.step(model_out.detach(), x, t, noise, sampler, eta, mask=mask, motion=motion,
                                      mask_noise=mask_noise, clip_denoised=clip_denoised)
         ctx.schedule, ctx.sampler, ctx.eta = schedule, int(sampler), float(eta)
         ctx.has_blend = mask is not None and motion is not None
-        ctx.save_for_backward(t, mask if ctx.has_blend else None)
+        # clip_denoised (the reference signature's default): x0-hat = clamp(blend, -1, 1); its gradient mask is read off the output
+        ctx.save_for_backward(t, mask if ctx.has_blend else None, pred if clip_denoised else None)
         return sample, pred
 
     @staticmethod
     def backward(ctx, g_sample, g_pred):
-        t, mask = ctx.saved_tensors
+        t, mask, pred_clipped = ctx.saved_tensors
         ref = g_pred if g_pred is not None else g_sample
         gs = None if g_sample is None else _cuda_f32(g_sample.contiguous(), "g_sample")
         gp = None if g_pred is None else _cuda_f32(g_pred.contiguous(), "g_pred")
@@ -44,7 +43,7 @@ class FusedStepFn(torch.autograd.Function):
         tt = t.to(device=d.device, dtype=torch.int64).contiguous()
         mk = None if mask is None else mask.to(device=d.device, dtype=torch.float32).contiguous()
         N.check(N.lib().mst_step_backward(ctx.schedule.handle, N.ptr(gs), N.ptr(gp), N.ptr(mk), int(ctx.has_blend), N.ptr(tt), B,
-                                          d.numel() // B, ctx.sampler, ctx.eta, N.ptr(d), N.stream_ptr(d.device)))
+                                          d.numel() // B, ctx.sampler, ctx.eta, N.ptr(pred_clipped), N.ptr(d), N.stream_ptr(d.device)))
         return (d,) + (None,) * 10
 
 

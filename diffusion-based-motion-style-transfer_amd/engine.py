@@ -122,6 +122,8 @@ class DenoiserEngine:
 
     # ------------------------------------------------------------------------------ weights
     def load_tensor(self, name, tensor):
+        self._sources = getattr(self, "_sources", {})
+        self._sources[name] = tensor                       # the caller's tensor (not the device temporary): set_precise re-uploads from it
         t = _f32c(tensor, self.device, name)
         shape = (C.c_int64 * t.dim())(*t.shape)
         N.check(N.lib().mst_load_weight(self.handle, name.encode(), N.ptr(t), shape, t.dim(), N.stream_ptr(self.device)))
@@ -333,7 +335,13 @@ class DenoiserEngine:
     def set_precise(self, on=True):
         """Every layer GEMM of the sampling path multiplies its activation as an f16 hi + lo pair (~22 bits): for checkpoints
         whose outlier statistics put plain f16 operands above the 1e-3 bar; about half the default throughput at 64 clips."""
-        N.check(N.lib().mst_set_precise(self.handle, int(bool(on))))
+        rc = N.lib().mst_set_precise(self.handle, int(bool(on)))
+        if rc == 2:                                        # weights went up without their lo halves: upload again, now with them
+            for name, tensor in list(getattr(self, "_sources", {}).items()):
+                self.load_tensor(name, tensor)
+            torch.cuda.current_stream(self.device).synchronize()
+            rc = 0
+        N.check(rc)
 
     def debug_stop_after(self, layer=-1, stage=-1):
         N.check(N.lib().mst_debug_stop_after(self.handle, layer, stage))

@@ -66,7 +66,11 @@ void mst_engine_destroy(mst_engine* e);
  *   sequence_pos_encoder.pe [pe_len,512]                    (PositionalEncoding :387-404)
  * For StyleDiffusion the caller passes its own `seqTransEncoder.*` tensors and the frozen prior's
  * (`motion_enc.mdm_model.*`) projections, which is exactly what StyleDiffusion.forward (:602-625)
- * reads.  Replaces: nn.Module.load_state_dict / .to(device) for this path. */
+ * reads.  Replaces: nn.Module.load_state_dict / .to(device) for this path.
+ * Stream contract: the f16 copies are written on `stream`.  The fused kernels' pre-packed copies (fragment streams of W_in and of
+ * W_out | W1 | W2) are produced lazily on the stream of the FIRST mst_forward / mst_sample_loop after an upload (for a loop: the
+ * engine's loop stream, which is ordered behind the caller's stream); a caller that uploads on one stream and samples on another
+ * orders the two itself, exactly as for the plain copies. */
 int mst_load_weight(mst_engine* e, const char* name, const float* src_dev,
                     const int64_t* shape, int32_t ndim, void* stream);
 /* 0 when every tensor of the list above has been loaded. */
@@ -187,10 +191,11 @@ int mst_step_epilogue(const mst_schedule* s, const float* model_out_dev, const f
  * :179-239; the fine-tune objective keeps every x0-hat in the autograd graph, gaussian_diffusion.py:1364-1378):
  *     d_model_out = (g_pred + g_sample * d sample / d pred) * (1 - mask)
  * g_sample / g_pred: upstream gradients of the two outputs, either may be NULL (= zero).  has_blend: the forward blended
- * with (mask, motion).  clip_denoised is not differentiated (no caller on this path clips: SURVEY section 9). */
+ * with (mask, motion).  pred_clipped_dev: NULL, or -- when the forward ran with clip_denoised (the reference signature's default,
+ * gaussian_diffusion.py:389-395) -- its x0-hat output: the clamp's gradient mask (zero where the prediction saturated at +-1). */
 int mst_step_backward(const mst_schedule* s, const float* g_sample_dev, const float* g_pred_dev, const float* mask_dev,
                       int32_t has_blend, const int64_t* t_dev, int32_t batch, int64_t per_clip, int32_t sampler, float eta,
-                      float* d_model_out_dev, void* stream);
+                      const float* pred_clipped_dev, float* d_model_out_dev, void* stream);
 
 /* K13 of SURVEY section 2.1 -- the reductions of the fine-tune objective, one launch each way:
  * mst_masked_l2: `masked_l2` (gaussian_diffusion.py:223-235) of a, b [n][feats][1][frames] with a frame mask
@@ -323,7 +328,10 @@ int mst_profile_read(mst_engine* e, const char** names, float* total_ms, int32_t
  * layer GEMM of the sampling path (mst_forward, mst_sample_loop) multiplies its activation operand as hi + lo -- f16(x) and
  * f16(x - hi), ~22 significant bits -- instead of f16(x): for checkpoints whose statistics (LayerNorm-gain outlier channels, large
  * FFN / attention weights) put plain f16 operands above the 1e-3 relative-L2 bar.  Takes the small-tile kernels at any batch size
- * (about half the throughput of the default path at 64 clips); default off, also MST_PRECISE=1. */
+ * (about half the throughput of the default path at 64 clips); default off, also MST_PRECISE=1.
+ * The weights' lo halves are written by mst_load_weight only while precise mode is on (a fine-tune iteration re-uploads 96 tensors and
+ * never reads them).  Returns 0, or 2 when it was switched on over weights uploaded without them: upload those again (mst_forward /
+ * mst_sample_loop fail until then). */
 int mst_set_precise(mst_engine* e, int32_t on);
 
 /* Debug / test hooks (no reference counterpart): stop the encoder stack after (layer, stage) --

@@ -25,8 +25,11 @@ def _extract(arr, t, shape):
     return torch.from_numpy(np.asarray(arr)).to(dev())[t].float().view(-1, 1, 1, 1).expand(shape)
 
 
+@pytest.mark.parametrize("clip", [False, True], ids=["noclip", "clip_denoised"])
 @pytest.mark.parametrize("ddim,eta", [(False, 0.0), (True, 0.0), (True, 0.5)])
-def test_fused_step_node_matches_torch_autograd(ddim, eta):
+def test_fused_step_node_matches_torch_autograd(ddim, eta, clip):
+    """clip=True is the reference signature's default (inpainting_gaussian_diffusion.py:66-77: clip_denoised=True): x0-hat is
+    clamped to [-1, 1] behind the blend (gaussian_diffusion.py:389-395) and the clamp's gradient mask applies."""
     from mst_amd.diffusion.fused_ops import FusedStepFn
     from mst_amd.engine import SAMPLER_DDIM, SAMPLER_DDPM
     from mst_amd.diffusion.inpainting_gaussian_diffusion import InpaintingGaussianDiffusion
@@ -47,6 +50,8 @@ def test_fused_step_node_matches_torch_autograd(ddim, eta):
     # reference formulas with torch ops (what the fused node replaces)
     o = out0.clone().requires_grad_(True)
     pred = o * (1 - mask) + motion * mask
+    if clip:
+        pred = pred.clamp(-1, 1)                    # standard-normal test values: about a third of them saturate
     nz = noise * (1 - mask)
     nonzero = (t != 0).float().view(-1, 1, 1, 1)
     if not ddim:
@@ -60,7 +65,7 @@ def test_fused_step_node_matches_torch_autograd(ddim, eta):
     ((sample * ws).sum() + (pred * wp).sum()).backward()
     # fused node
     o2 = out0.clone().requires_grad_(True)
-    s2, p2 = FusedStepFn.apply(o2, x, t, noise, mask, motion, d._schedule(dev()), SAMPLER_DDIM if ddim else SAMPLER_DDPM, eta, True, False)
+    s2, p2 = FusedStepFn.apply(o2, x, t, noise, mask, motion, d._schedule(dev()), SAMPLER_DDIM if ddim else SAMPLER_DDPM, eta, True, clip)
     ((s2 * ws).sum() + (p2 * wp).sum()).backward()
     assert rel_l2(s2.detach().cpu().numpy(), sample.detach().cpu().numpy()) < 2e-5
     assert torch.equal(p2.detach(), pred.detach())

@@ -12,7 +12,11 @@ for d in sys.argv[1:]:
             for key, fam in FAMILIES:
                 if key in r["Kernel_Name"]:
                     acc[fam][r["Counter_Name"]].append(float(r["Counter_Value"]))
-out = {"method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 1 --denoise-steps 12` "
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import mst_amd  # noqa: E402,F401
+from mst_amd import _native  # noqa: E402
+out = {"source_hash": _native.built_hash(), "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 1 --denoise-steps 12` "
                  "with MST_STREAMS=1 (64-clip launches); KiB -> bytes; FETCH_SIZE x2 (gfx950 correction)", "kernels": {}}
 for fam, cs in acc.items():
     fetch = 2 * 1024 * sum(cs["FETCH_SIZE"]) / max(len(cs["FETCH_SIZE"]), 1)
