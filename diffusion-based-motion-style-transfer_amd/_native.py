@@ -90,7 +90,10 @@ SIGNATURES = {
 
 # The one compile recipe.  No -D but the source hash is ever passed: the kernels' tunables are constants in the sources, and the
 # diagnostic hooks (phase stamps) exist only in the probes under csrc/probes/, which define MST_PROBE_BUILD themselves.
-HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC")
+HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+               # no SLP packing: hipcc turns pairs of scalar f32 ops into v_pk_fma_f32 / v_pk_mul_f32 + v_mov shuffles, which buy nothing
+               # on CDNA4 (a packed op issues at the rate of its two scalar ones) and cost the shuffles: +0.4 % clips/s, same-box A/B
+               "-fno-slp-vectorize")
 
 
 def source_files():

@@ -151,8 +151,11 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
                                               uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
 #pragma unroll
     for (int i = 0; i < 10; i++) {
-        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of v_mul_hi_u32 + v_mul_lo_u32: the same bits, half the
+        // quarter-rate multiplies (the generator is ~2/3 of the noise draw's issue cycles)
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;

@@ -19,6 +19,12 @@
 #include "mst_elem.h"
 #include "mst_gemm_dma.h"
 #include "mst_tail.h"
+#ifdef EMB_PROBE            // diagnostic build only (tools/r4_embed_stamps.sh): wave 0..7 of every workgroup stamp the 100 MHz clock at the phase marks
+__device__ unsigned long long g_emb_stamp[512][8][8];
+#define EMB_MARK(i) if ((threadIdx.x & 63) == 0 && blockIdx.x < 512) g_emb_stamp[blockIdx.x][threadIdx.x >> 6][i] = __builtin_amdgcn_s_memrealtime();
+extern "C" int mst_probe_read(void* dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_emb_stamp), sizeof(g_emb_stamp)) == hipSuccess ? 0 : 1; }
+#endif
+#include "mst_embed.h"
 
 using namespace mst;
 
@@ -160,6 +166,9 @@ struct mst_engine {
     f16 *w_pose_in_lo = nullptr, *w_pose_out_lo = nullptr;      // lo halves (precise mode)
     f16 *w_pose_inT = nullptr, *w_pose_outT = nullptr;   // [fout_pad][512] and [512][kin_pad]: the projections' dgrad operands
     float *b_pose_in = nullptr, *b_pose_out = nullptr;
+    f16 *w_pose_in_pk = nullptr, *w_pose_out_pk = nullptr;      // the two projections as per-wave fragment streams (mst_embed.h, k_pack_wave_blocks)
+    bool pose_in_dirty = true, pose_out_dirty = true;          // ... older than w_pose_in / w_pose_out: repacked by ensure_packed()
+    int embed_fast = 1;                   // K3 / K9 as the latency kernels of mst_embed.h; MST_EMBED_FAST=0: the ring GEMMs of rounds 1-3
     float *w_t0 = nullptr, *b_t0 = nullptr, *w_t2 = nullptr, *b_t2 = nullptr, *w_text = nullptr, *b_text = nullptr;
     float* pe = nullptr;
     // workspace
@@ -304,6 +313,8 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     CHECK(dmalloc(&e->w_pose_in_lo, (size_t)MST_D * e->kin_pad));
     CHECK(dmalloc(&e->w_pose_out_lo, (size_t)e->fout_pad * MST_D));
     CHECK(dmalloc(&e->b_pose_in, MST_D));
+    CHECK(dmalloc(&e->w_pose_in_pk, (size_t)8 * 16 * 4 * 512));
+    CHECK(dmalloc(&e->w_pose_out_pk, (size_t)8 * 16 * 4 * 512));
     CHECK(dmalloc(&e->w_pose_out, (size_t)e->fout_pad * MST_D));
     CHECK(dmalloc(&e->b_pose_out, e->fout_pad));
     CHECK(dmalloc(&e->w_pose_inT, (size_t)e->fout_pad * MST_D));
@@ -351,6 +362,7 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     if (const char* v = getenv("MST_FUSE_QKV_ATTN")) e->fuse_qkv_attn = atoi(v);
     if (const char* v = getenv("MST_FUSE_TAIL")) e->fuse_tail = atoi(v) != 0;
     if (const char* v = getenv("MST_FUSE_FRAMES")) e->fuse_frames = atoi(v) != 0;
+    if (const char* v = getenv("MST_EMBED_FAST")) e->embed_fast = atoi(v) != 0;
     if (const char* v = getenv("MST_TAIL_NTB")) { int n = atoi(v); e->tail_ntb = (n >= 2 && n <= 4) ? n : 0; }
     if (const char* v = getenv("MST_WGRAD_STREAM")) e->wgrad_stream_on = atoi(v) != 0;
     if (const char* v = getenv("MST_SMALL_M")) e->small_m = atoi(v);
@@ -387,7 +399,7 @@ extern "C" void mst_engine_destroy(mst_engine* e) {
         for (int i = 0; i < 2; i++) if (t.ev_side[i]) (void)hipEventDestroy(t.ev_side[i]);
         for (void* q : p) (void)hipFree(q);
     }
-    void* p[] = {e->w_pose_in_lo, e->w_pose_out_lo, e->w_pose_in, e->b_pose_in, e->w_pose_out, e->b_pose_out, e->w_pose_inT, e->w_pose_outT, e->w_t0, e->b_t0, e->w_t2, e->b_t2,
+    void* p[] = {e->w_pose_in_pk, e->w_pose_out_pk, e->w_pose_in_lo, e->w_pose_out_lo, e->w_pose_in, e->b_pose_in, e->w_pose_out, e->b_pose_out, e->w_pose_inT, e->w_pose_outT, e->w_t0, e->b_t0, e->w_t2, e->b_t2,
                  e->w_text, e->b_text, e->pe, e->hl, e->hx, e->qkv, e->att, e->hid, e->xt, e->xt_lo, e->gelu_tab, e->temb_hid, e->temb, e->textproj, e->zacc};
     for (void* q : p) (void)hipFree(q);
     for (int i = 0; i < mst_engine::MAX_SLICES - 1; i++) {
@@ -470,7 +482,7 @@ extern "C" int mst_load_weight(mst_engine* e, const char* name, const float* src
     } else if (n == "input_process.poseEmbedding.weight") {
         if (!shape_is(shape, ndim, MST_D, F)) return fail("mst_load_weight: %s: bad shape", name);
         rc = put_matrix(src, MST_D, F, e->w_pose_in, MST_D, e->kin_pad, st, e->precise ? e->w_pose_in_lo : nullptr);
-        if (!rc) { if (e->precise) e->lo_missing.erase(n); else e->lo_missing.insert(n); }
+        if (!rc) { if (e->precise) e->lo_missing.erase(n); else e->lo_missing.insert(n); e->pose_in_dirty = true; }
         if (!rc) {      // [512][F] -> [F (padded to fout_pad)][512]
             hipLaunchKernelGGL(k_convert_transpose, dim3((F + 31) / 32, (MST_D + 31) / 32), dim3(256), 0, st, src, MST_D, F, e->w_pose_inT, MST_D);
             HIPCHECK(hipGetLastError());
@@ -481,7 +493,7 @@ extern "C" int mst_load_weight(mst_engine* e, const char* name, const float* src
     } else if (n == "output_process.poseFinal.weight") {
         if (!shape_is(shape, ndim, F, MST_D)) return fail("mst_load_weight: %s: bad shape", name);
         rc = put_matrix(src, F, MST_D, e->w_pose_out, e->fout_pad, MST_D, st, e->precise ? e->w_pose_out_lo : nullptr);
-        if (!rc) { if (e->precise) e->lo_missing.erase(n); else e->lo_missing.insert(n); }
+        if (!rc) { if (e->precise) e->lo_missing.erase(n); else e->lo_missing.insert(n); e->pose_out_dirty = true; }
         if (!rc) {      // [F][512] -> [512][F (padded to kin_pad)]
             hipLaunchKernelGGL(k_convert_transpose, dim3((MST_D + 31) / 32, (F + 31) / 32), dim3(256), 0, st, src, F, MST_D, e->w_pose_outT, e->kin_pad);
             HIPCHECK(hipGetLastError());
@@ -736,7 +748,18 @@ static WS ws_slice(const mst_engine* e, int r0, int T) {
 
 // Packed weight copies of the two fused kernels, refreshed where stale: on the stream the sampling launch is about to use (the caller
 // orders that stream behind its weight uploads, as for the plain matrices).
+static int embed_out_nbw(const mst_engine* e) { return (e->cfg.feats + 127) / 128; }     // 16-feature blocks per wave of k_embed_out
 static int ensure_packed(mst_engine* e, hipStream_t st) {
+    if (e->pose_in_dirty) {
+        hipLaunchKernelGGL(k_pack_wave_blocks, dim3(256), dim3(256), 0, st, e->w_pose_in, e->kin_pad, MST_D, e->kin_pad / 32, 4, e->w_pose_in_pk);
+        HIPCHECK(hipGetLastError());
+        e->pose_in_dirty = false;
+    }
+    if (e->pose_out_dirty) {
+        hipLaunchKernelGGL(k_pack_wave_blocks, dim3(256), dim3(256), 0, st, e->w_pose_out, MST_D, e->fout_pad, MST_D / 32, embed_out_nbw(e), e->w_pose_out_pk);
+        HIPCHECK(hipGetLastError());
+        e->pose_out_dirty = false;
+    }
     for (int l = 0; l < e->cfg.num_layers; l++) {
         LayerW& w = e->L[l];
         if (w.qkv_dirty) {
@@ -786,6 +809,23 @@ static int launch_tail(const mst_engine* e, const LayerW& w, const WS& ws, int M
 // K1-K3: conditioning token + pose embedding of the frames -> token stream rows (ws.hx / ws.hl)
 struct LoopRef { const LoopDev* ld = nullptr; int joff = 0; unsigned long long eo = 0; bool frames_ready = false; };   // frames_ready: the previous step's epilogue already wrote ws.xt   // loop mode of a step's kernels (see LoopDev)
 
+template <int KS>
+static int launch_embed_in_n(mst_engine* e, const WS& ws, int tot, const DEpiEmbedIn& epi, hipStream_t st) {
+    CHECK(ensure_dyn_lds((const void*)k_embed_in<KS>, EmbCfg::SMEM));
+    hipLaunchKernelGGL(k_embed_in<KS>, dim3((tot + EmbCfg::BT - 1) / EmbCfg::BT), dim3(512), EmbCfg::SMEM, st, ws.xt, ws.xt_lo, e->kin_pad,
+                       e->w_pose_in_pk, epi);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+static int launch_embed_in(mst_engine* e, const WS& ws, int tot, const DEpiEmbedIn& epi, hipStream_t st) {
+    switch (e->kin_pad / 32) {
+#define EI(K_) case K_: return launch_embed_in_n<K_>(e, ws, tot, epi, st);
+        EI(3) EI(4) EI(5) EI(6) EI(7) EI(8) EI(9) EI(10) EI(11) EI(12) EI(13) EI(14) EI(15) EI(16)
+#undef EI
+    }
+    return fail("pose embedding: %d input columns unsupported", e->kin_pad);
+}
+
 static int assemble_stream(mst_engine* e, const WS& ws, const float* x, int clips_x, int rows, int T, int temb_uniform_row, int temb_mod,
                            hipStream_t st, int tp_uncond, LoopRef lr = LoopRef()) {
     const int S = T + 1;
@@ -804,6 +844,7 @@ static int assemble_stream(mst_engine* e, const WS& ws, const float* x, int clip
         epi.ct.temb = e->temb; epi.ct.textproj = ws.textproj; epi.ct.ld = lr.ld;
         epi.ct.uniform_row = temb_uniform_row; epi.ct.temb_mod = temb_mod; epi.ct.joff = lr.joff; epi.ct.rows = rows;
         epi.ct.tp_half = rows > clips_x ? clips_x : 0; epi.ct.tp_uncond = rows > clips_x ? tp_uncond : 0;
+        if (e->embed_fast && !e->precise) return launch_embed_in(e, ws, tot, epi, st);
         // x_t as hi + lo (RowsDirect::Xlo): both halves of a k-slab beside ONE copy of the weight slab
         CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1, 32, 2>(dim3((tot + 63) / 64, 1), RowsDirect{ws.xt, e->kin_pad, ws.xt_lo, e->precise ? e->w_pose_in_lo : nullptr},
                                                           e->w_pose_in, e->kin_pad, e->kin_pad, epi, st)));
@@ -950,10 +991,32 @@ static int launch_out_nx(mst_engine* e, const WS& ws, int cfg, int batch, int T,
     return cfg ? launch_out<MODE, BF, MT, NT, 2>(e, ws, batch, T, out, sa, st, wo, bo, tok_off, frames_next, hi_lo)
                : launch_out<MODE, BF, MT, NT, 1>(e, ws, batch, T, out, sa, st, wo, bo, tok_off, frames_next, hi_lo);
 }
+template <int MODE, int NBW, int NX>
+static int launch_embed_out_n(mst_engine* e, const RowsFrames& xs, const DEpiEmbedOut<MODE>& epi, int tiles, hipStream_t st) {
+    CHECK(ensure_dyn_lds((const void*)k_embed_out<NBW, MODE, NX>, EmbCfg::SMEM));
+    hipLaunchKernelGGL((k_embed_out<NBW, MODE, NX>), dim3(tiles), dim3(512), EmbCfg::SMEM, st, xs, e->w_pose_out_pk, epi);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+template <int MODE>
+static int launch_embed_out(mst_engine* e, const WS& ws, int cfg, int batch, int T, float* out, const StepArgs& sa, hipStream_t st,
+                            int tok_off, bool frames_next) {
+    const int S = T + tok_off, tiles = (batch * T + EmbCfg::BT - 1) / EmbCfg::BT;
+    RowsFrames xs{ws.hx, MST_D, T, S, batch * T, EmbCfg::BT, (size_t)batch * S, tok_off, ws.hl, nullptr};
+    DEpiEmbedOut<MODE> epi{e->b_pose_out, e->cfg.feats, T, batch * T, out, sa};
+    if (frames_next) { epi.xt_next = ws.xt; epi.kpad = e->kin_pad; epi.xt_next_lo = ws.xt_lo; }
+    const int nbw = embed_out_nbw(e);
+#define EO(N_) case N_: return cfg ? launch_embed_out_n<MODE, N_, 2>(e, xs, epi, tiles, st) : launch_embed_out_n<MODE, N_, 1>(e, xs, epi, tiles, st);
+    switch (nbw) { EO(1) EO(2) EO(3) case 4: return launch_embed_out_n<MODE, 4, 1>(e, xs, epi, tiles, st); }
+#undef EO
+    return fail("output projection: %d features unsupported", e->cfg.feats);
+}
 template <int MODE>
 static int launch_out_nt(mst_engine* e, const WS& ws, int cfg, int batch, int T, float* out, const StepArgs& sa, hipStream_t st,
                          const f16* wo = nullptr, const float* bo = nullptr, int tok_off = 1, bool frames_next = false, bool hi_lo = false) {
     ProfScope ps(e, FAM_EMBED_OUT, st);
+    if (e->embed_fast && !e->precise && hi_lo && !wo && !bo && !(cfg && embed_out_nbw(e) == 4))      // (385+ features under CFG: its two accumulator sets spill)
+        return launch_embed_out<MODE>(e, ws, cfg, batch, T, out, sa, st, tok_off, frames_next);
     const int rows_out = e->cfg.feats;                   // (also for the pose embedding's backward, which runs this kernel with W_in^T)
     if (rows_out <= 256) return launch_out_nx<MODE, 256, 2, 1>(e, ws, cfg, batch, T, out, sa, st, wo, bo, tok_off, frames_next, hi_lo);
     if (rows_out <= 384) return launch_out_nx<MODE, 384, 1, 3>(e, ws, cfg, batch, T, out, sa, st, wo, bo, tok_off, frames_next, hi_lo);

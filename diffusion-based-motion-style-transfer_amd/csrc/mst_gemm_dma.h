@@ -495,23 +495,38 @@ struct DEpiEmbedIn {
                 }
         }
         __syncthreads();
+        finish<BT>(tok0, smem);
+    }
+    // everything behind the accumulator -> LDS rows hop (smem: BT rows of LD = 2064 bytes, fp32): + bias + positional row -> the stream's
+    // hi / lo rows, whole-row stores; conditioning tokens.  Shared by the ring GEMM above and k_embed_in (mst_embed.h).
+    template <int BT>
+    __device__ __forceinline__ void finish(int tok0, char* smem) const {
+        constexpr int LD = MST_D * 4 + 16;
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int fa = lane * 4, fb = 256 + lane * 4;
         const f32x4 ba = *reinterpret_cast<const f32x4*>(bias + fa), bb = *reinterpret_cast<const f32x4*>(bias + fb);
         constexpr int RPW = BT / 8;
+        // the positional rows of all RPW rows first (one memory latency, not RPW in series), then the rows themselves
+        f32x4 pa[RPW], pb[RPW];
+#pragma unroll
+        for (int r = 0; r < RPW; r++) {
+            int tok = tok0 + wave * RPW + r;
+            if (tok >= total) tok = total - 1;
+            const float* perow = pe + (size_t)(tok % T + tok_off) * MST_D;
+            pa[r] = *reinterpret_cast<const f32x4*>(perow + fa);
+            pb[r] = *reinterpret_cast<const f32x4*>(perow + fb);
+        }
 #pragma unroll
         for (int r = 0; r < RPW; r++) {
             const int row = wave * RPW + r, tok = tok0 + row;
             if (tok >= total) continue;
             const int clip = tok / T, t = tok - clip * T;
-            const float* perow = pe + (size_t)(t + tok_off) * MST_D;
             f32x4 xa = *reinterpret_cast<const f32x4*>(smem + row * LD + fa * 4);
             f32x4 xb = *reinterpret_cast<const f32x4*>(smem + row * LD + fb * 4);
-            const f32x4 pa = *reinterpret_cast<const f32x4*>(perow + fa), pb = *reinterpret_cast<const f32x4*>(perow + fb);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                xa[i] = xa[i] + ba[i] + pa[i];
-                xb[i] = xb[i] + bb[i] + pb[i];
+                xa[i] = xa[i] + ba[i] + pa[r][i];
+                xb[i] = xb[i] + bb[i] + pb[r][i];
             }
             size_t off = ((size_t)clip * S + tok_off + t) * MST_D;
             uint2 ha, la, hb, lb;
@@ -595,6 +610,14 @@ struct DEpiEmbedOut {
                 }
         }
         __syncthreads();
+        finish<BT>(sa, tok0, f0, smem);
+    }
+    // everything behind the accumulator -> [feature][frame] tile hop (smem: F rows of BT + 4 floats): the diffusion update with float4
+    // accesses along the frames, the next step's f16 frame rows.  Shared by the ring GEMM above and k_embed_out (mst_embed.h).
+    template <int BT>
+    __device__ __forceinline__ void finish(const StepArgs& sa, int tok0, int f0, char* smem) const {
+        constexpr int LDT = BT + 4;
+        float* tile = reinterpret_cast<float*>(smem);
         StepCoef sc;
         if (MODE != 0) sc = step_coef(sa.tab, sa.nsteps, sa.t, sa.eta);
         const bool blend = sa.mask != nullptr && sa.motion != nullptr, use_mask = sa.mask != nullptr;
@@ -696,9 +719,16 @@ struct DEpiEmbedOut {
                 }
             }
         }
-        if (MODE != 0 && xt_next && vec) {
-            // second pass over the tile, now holding x_{t-1}: lanes walk the frames of one 8-feature group (conflict-free LDS
-            // reads), each writing 16 bytes of its frame's row; columns [F, kpad) are the zero padding of the GEMM's K
+        if (MODE != 0 && vec) frames_next<BT>(tok0, f0, smem);
+    }
+    // second pass over the tile, now holding x_{t-1}: the NEXT step's f16 frame rows (hi + lo), [frame][kpad]
+    template <int BT>
+    __device__ __forceinline__ void frames_next(int tok0, int f0, char* smem) const {
+        constexpr int LDT = BT + 4;
+        const float* tile = reinterpret_cast<const float*>(smem);
+        if (MODE != 0 && xt_next) {
+            // lanes walk the frames of one 8-feature group (conflict-free LDS reads), each writing 16 bytes of its frame's row;
+            // columns [F, kpad) are the zero padding of the GEMM's K
             __syncthreads();
             const int groups = kpad / 8;
             for (int it = threadIdx.x; it < BT * groups; it += 512) {
