@@ -749,7 +749,9 @@ static WS ws_slice(const mst_engine* e, int r0, int T) {
 // Packed weight copies of the two fused kernels, refreshed where stale: on the stream the sampling launch is about to use (the caller
 // orders that stream behind its weight uploads, as for the plain matrices).
 static int embed_out_nbw(const mst_engine* e) { return (e->cfg.feats + 127) / 128; }     // 16-feature blocks per wave of k_embed_out
-static int ensure_packed(mst_engine* e, hipStream_t st) {
+// (layers = false: the training node's model calls -- they run the two projections' fast kernels but read the layers' plain matrices,
+// and every fine-tune iteration re-uploads those: their packed copies are made only when a sampling launch follows)
+static int ensure_packed(mst_engine* e, hipStream_t st, bool layers = true) {
     if (e->pose_in_dirty) {
         hipLaunchKernelGGL(k_pack_wave_blocks, dim3(256), dim3(256), 0, st, e->w_pose_in, e->kin_pad, MST_D, e->kin_pad / 32, 4, e->w_pose_in_pk);
         HIPCHECK(hipGetLastError());
@@ -760,6 +762,7 @@ static int ensure_packed(mst_engine* e, hipStream_t st) {
         HIPCHECK(hipGetLastError());
         e->pose_out_dirty = false;
     }
+    if (!layers) return 0;
     for (int l = 0; l < e->cfg.num_layers; l++) {
         LayerW& w = e->L[l];
         if (w.qkv_dirty) {
@@ -1740,6 +1743,7 @@ extern "C" int mst_train_model_forward(mst_engine* e, const float* x, const int6
     Tape t;
     tape_layout((char*)tape, nl, tape_rows(M), &t);
     e->prof_now = 0;
+    CHECK(ensure_packed(e, st, false));
     CHECK(timestep_rows(e, (const long long*)t_idx, batch, st));
     WS ws = ws_slice(e, 0, frames);
     ws.hx = t.sh[0];                                      // the token stream is assembled straight into tape slot 0

@@ -415,7 +415,9 @@ class GaussianDiffusion:
             from tqdm.auto import tqdm
             indices = tqdm(indices)
         for i in indices:
-            t = th.tensor([i] * shape[0], device=device)
+            # (the reference's th.tensor([i] * B, device=...) at gaussian_diffusion.py:780 is a blocking host-to-device copy: it would
+            # drain the GPU once per chained step of the fine-tune objective; a device-side fill gives the same tensor)
+            t = th.full((shape[0],), int(i), device=device, dtype=th.long)
             with th.no_grad():
                 if with_grad:
                     out = (self.ddim_sample_with_grad(model, img, t, clip_denoised=clip_denoised, model_kwargs=model_kwargs, eta=eta,

@@ -66,17 +66,20 @@ class SpacedDiffusion(GaussianDiffusion):
     def _wrap_model(self, model):
         if isinstance(model, _WrappedModel):
             return model
-        return _WrappedModel(model, self.timestep_map, self.rescale_timesteps, self.original_num_steps)
+        # one device copy of the map per (device, dtype) for the life of the diffusion object: the wrapper is rebuilt on every call,
+        # and an upload per call is a blocking host-to-device copy (it drains the GPU once per chained step of the fine-tune objective)
+        maps = self.__dict__.setdefault("_device_maps", {})
+        return _WrappedModel(model, self.timestep_map, self.rescale_timesteps, self.original_num_steps, maps)
 
     def _scale_timesteps(self, t):
         return t    # scaling is the wrapped model's job
 
 
 class _WrappedModel:
-    def __init__(self, model, timestep_map, rescale_timesteps, original_num_steps):
+    def __init__(self, model, timestep_map, rescale_timesteps, original_num_steps, maps=None):
         self.model, self.timestep_map = model, timestep_map
         self.rescale_timesteps, self.original_num_steps = rescale_timesteps, original_num_steps
-        self._maps = {}
+        self._maps = {} if maps is None else maps
 
     def __call__(self, x, ts, **kwargs):
         key = (ts.device, ts.dtype)
