@@ -63,7 +63,7 @@ SIGNATURES = {
     "mst_train_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_uint64,
                                      C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
     "mst_train_model_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float,
-                                          C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                          C.c_uint64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "mst_train_model_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float,
                                            C.c_uint64, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
     "mst_motion_encoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,

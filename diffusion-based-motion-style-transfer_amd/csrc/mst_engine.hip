@@ -1374,10 +1374,25 @@ static size_t tape_layout(char* base, int nl, size_t Mp, Tape* t) {
     return off;
 }
 
-static Drop make_drop(uint64_t seed, int layer, int site, float p) {
+// elem_off: the site's element counter starts there (drop_mul hashes idx * phi + key, so an offset is a shifted key): a forward pass that
+// writes clips [clip0, ..) of a LARGER tape draws exactly the masks a backward pass over the whole tape regenerates
+// the rows of clips [clip0, ..) inside a tape laid out for more clips (every slot is [rows][width], clip-major)
+static void tape_shift(Tape& t, int nl, size_t row0) {
+    for (int l = 0; l <= nl; l++) { t.sh[l] += row0 * MST_D; t.sl[l] += row0 * MST_D; }
+    for (int l = 0; l < nl; l++) {
+        TapeL& a = t.L[l];
+        a.qkv += row0 * 3 * MST_D; a.att += row0 * MST_D;
+        a.z1h += row0 * MST_D; a.z1l += row0 * MST_D; a.x1h += row0 * MST_D; a.x1l += row0 * MST_D;
+        a.pre += row0 * MST_FF; a.hid += row0 * MST_FF;
+        a.z2h += row0 * MST_D; a.z2l += row0 * MST_D;
+        a.lse += row0 * MST_H;
+    }
+}
+
+static Drop make_drop(uint64_t seed, int layer, int site, float p, uint32_t elem_off = 0) {
     Drop d{0u, 0u, 1.0f};
     if (p <= 0.f) return d;
-    d.key = mix32((uint32_t)seed ^ mix32((uint32_t)(seed >> 32) + 0x9E3779B9u * (uint32_t)(layer * 4 + site + 1)));
+    d.key = mix32((uint32_t)seed ^ mix32((uint32_t)(seed >> 32) + 0x9E3779B9u * (uint32_t)(layer * 4 + site + 1))) + elem_off * 0x9E3779B9u;
     const double t = (double)p * 4294967296.0;
     d.thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
     d.inv = 1.0f / (1.0f - p);
@@ -1443,8 +1458,10 @@ static int launch_attn_bwd(const f16* qkv, const f16* att, const f16* datt, f16*
 // with nn.TransformerEncoderLayer semantics (post-norm, erf GELU, dropout p at the four sites of the layer).
 // the eight layers from tape slot 0 to slot num_layers
 static int train_stack_forward(mst_engine* e, const Tape& t, int rows, int S, float p_drop, uint64_t seed, const uint8_t* key_keep,
-                               hipStream_t st) {
+                               hipStream_t st, int clip0 = 0) {
     const int M = rows * S, nl = e->cfg.num_layers;
+    // dropout counters of the four sites start at clip `clip0` of the tape (attention probabilities, 512-wide rows, hidden rows)
+    const uint32_t o0 = (uint32_t)clip0 * MST_H * S * S, o1 = (uint32_t)clip0 * S * MST_D, o2 = (uint32_t)clip0 * S * MST_FF;
     e->prof_now = 0;
     const bool small = e->small_m > 0 && M <= e->small_m;
     for (int l = 0; small && l < nl; l++) {              // few token rows: 64 x 128 tiles, row-wise LayerNorm, query-split attention
@@ -1454,23 +1471,23 @@ static int train_stack_forward(mst_engine* e, const Tape& t, int rows, int S, fl
             DEpiBiasF16<false> epi{w.b_in, a.qkv, 3 * MST_D, M};
             CHECK(launch_small(M, 3 * MST_D, RowsDirect{t.sh[l], MST_D}, w.w_in, MST_D, MST_D, epi, st));
         }
-        CHECK(launch_attn_train(a.qkv, a.att, S, rows, make_drop(seed, l, 0, p_drop), key_keep, 1, a.lse, st));
+        CHECK(launch_attn_train(a.qkv, a.att, S, rows, make_drop(seed, l, 0, p_drop, o0), key_keep, 1, a.lse, st));
         {
             DEpiPlainF32 epi{e->zacc, MST_D, M};
             CHECK(launch_small(M, MST_D, RowsDirect{a.att, MST_D}, w.w_out, MST_D, MST_D, epi, st));
             hipLaunchKernelGGL(k_ln_rows_train, dim3((M + 3) / 4), dim3(256), 0, st, e->zacc, w.b_out, w.g1, w.be1, t.sh[l], t.sl[l],
-                               a.z1h, a.z1l, a.x1h, a.x1l, M, make_drop(seed, l, 1, p_drop));
+                               a.z1h, a.z1l, a.x1h, a.x1l, M, make_drop(seed, l, 1, p_drop, o1));
             HIPCHECK(hipGetLastError());
         }
         {
-            DEpiRowOp<OpFfn1Train> epi{w.b1, M, OpFfn1Train{a.pre, a.hid, MST_FF, make_drop(seed, l, 2, p_drop)}};
+            DEpiRowOp<OpFfn1Train> epi{w.b1, M, OpFfn1Train{a.pre, a.hid, MST_FF, make_drop(seed, l, 2, p_drop, o2)}};
             CHECK(launch_small(M, MST_FF, RowsDirect{a.x1h, MST_D}, w.w1, MST_D, MST_D, epi, st));
         }
         {
             DEpiPlainF32 epi{e->zacc, MST_D, M};
             CHECK(launch_small(M, MST_D, RowsDirect{a.hid, MST_FF}, w.w2, MST_FF, MST_FF, epi, st));
             hipLaunchKernelGGL(k_ln_rows_train, dim3((M + 3) / 4), dim3(256), 0, st, e->zacc, w.b2, w.g2, w.be2, a.x1h, a.x1l,
-                               a.z2h, a.z2l, t.sh[l + 1], t.sl[l + 1], M, make_drop(seed, l, 3, p_drop));
+                               a.z2h, a.z2l, t.sh[l + 1], t.sl[l + 1], M, make_drop(seed, l, 3, p_drop, o1));
             HIPCHECK(hipGetLastError());
         }
     }
@@ -1481,17 +1498,17 @@ static int train_stack_forward(mst_engine* e, const Tape& t, int rows, int S, fl
             DEpiBiasF16<false> epi{w.b_in, a.qkv, 3 * MST_D, M};
             CHECK((launch_wide(M, 3 * MST_D / 256, RowsDirect{t.sh[l], MST_D}, w.w_in, MST_D, MST_D, epi, st)));
         }
-        CHECK(launch_attn_train(a.qkv, a.att, S, rows, make_drop(seed, l, 0, p_drop), key_keep, 0, a.lse, st));
+        CHECK(launch_attn_train(a.qkv, a.att, S, rows, make_drop(seed, l, 0, p_drop, o0), key_keep, 0, a.lse, st));
         {
-            DEpiResidLNTrain epi{w.b_out, w.g1, w.be1, t.sh[l], t.sl[l], a.z1h, a.z1l, a.x1h, a.x1l, M, make_drop(seed, l, 1, p_drop)};
+            DEpiResidLNTrain epi{w.b_out, w.g1, w.be1, t.sh[l], t.sl[l], a.z1h, a.z1l, a.x1h, a.x1l, M, make_drop(seed, l, 1, p_drop, o1)};
             CHECK((launch_gemm_dma<64, 512, 2, 2, LN_NS, 1, LN_BK>(dim3((M + 63) / 64, 1), RowsDirect{a.att, MST_D}, w.w_out, MST_D, MST_D, epi, st)));
         }
         {
-            DEpiRowOp<OpFfn1Train> epi{w.b1, M, OpFfn1Train{a.pre, a.hid, MST_FF, make_drop(seed, l, 2, p_drop)}};
+            DEpiRowOp<OpFfn1Train> epi{w.b1, M, OpFfn1Train{a.pre, a.hid, MST_FF, make_drop(seed, l, 2, p_drop, o2)}};
             CHECK((launch_wide(M, MST_FF / 256, RowsDirect{a.x1h, MST_D}, w.w1, MST_D, MST_D, epi, st)));
         }
         {
-            DEpiResidLNTrain epi{w.b2, w.g2, w.be2, a.x1h, a.x1l, a.z2h, a.z2l, t.sh[l + 1], t.sl[l + 1], M, make_drop(seed, l, 3, p_drop)};
+            DEpiResidLNTrain epi{w.b2, w.g2, w.be2, a.x1h, a.x1l, a.z2h, a.z2l, t.sh[l + 1], t.sl[l + 1], M, make_drop(seed, l, 3, p_drop, o1)};
             CHECK((launch_gemm_dma<64, 512, 2, 2, LN_NS, 1, LN_BK>(dim3((M + 63) / 64, 1), RowsDirect{a.hid, MST_FF}, w.w2, MST_FF, MST_FF, epi, st)));
         }
     }
@@ -1728,20 +1745,24 @@ extern "C" int mst_train_wait_layer_grads(mst_engine* e, int32_t layer, void* st
 // ---- the whole denoiser inside the native graph: conditioning token, pose embedding, positional-encoding dropout, the
 // trainable stack, output projection (StyleDiffusion.forward / MDM.forward, mdm_forstyledataset.py:602-625 / :315-364, in
 // train mode).  Text conditioning as for mst_forward: mst_set_text(batch, cfg = 0) first.
-static Drop pe_drop(uint64_t seed, float p) { return make_drop(seed, 32, 0, p); }       // site of its own, beyond any layer
+static Drop pe_drop(uint64_t seed, float p, uint32_t elem_off = 0) { return make_drop(seed, 32, 0, p, elem_off); }       // site of its own, beyond any layer
 
 extern "C" int mst_train_model_forward(mst_engine* e, const float* x, const int64_t* t_idx, int32_t batch, int32_t frames,
-                                       float p_drop, float p_pe, uint64_t seed, void* tape, float* out, void* stream) {
+                                       float p_drop, float p_pe, uint64_t seed, void* tape, float* out, int32_t clip0, int32_t tape_clips,
+                                       void* stream) {
     CHECK(check_ready(e, batch, frames, 0));
     const int S = frames + 1;
-    CHECK(train_check(e, batch, S, p_drop));
+    if (tape_clips <= 0) { tape_clips = batch; clip0 = 0; }
+    if (clip0 < 0 || clip0 + batch > tape_clips) return fail("mst_train_model_forward: clips %d..%d outside a tape of %d", clip0, clip0 + batch, tape_clips);
+    CHECK(train_check(e, tape_clips, S, p_drop));
     if (!(p_pe >= 0.f && p_pe < 1.f)) return fail("mst_train_model_forward: positional-encoding dropout %g outside [0, 1)", (double)p_pe);
     if (!x || !t_idx || !tape || !out) return fail("mst_train_model_forward: null argument");
     hipStream_t st = (hipStream_t)stream;
     ON_DEVICE(e->cfg.device);
     const int M = batch * S, nl = e->cfg.num_layers;
     Tape t;
-    tape_layout((char*)tape, nl, tape_rows(M), &t);
+    tape_layout((char*)tape, nl, tape_rows(tape_clips * S), &t);
+    tape_shift(t, nl, (size_t)clip0 * S);
     e->prof_now = 0;
     CHECK(ensure_packed(e, st, false));
     CHECK(timestep_rows(e, (const long long*)t_idx, batch, st));
@@ -1750,10 +1771,11 @@ extern "C" int mst_train_model_forward(mst_engine* e, const float* x, const int6
     ws.hl = t.sl[0];
     CHECK(assemble_stream(e, ws, x, batch, batch, frames, -1, batch, st, batch));
     if (p_pe > 0.f) {
-        hipLaunchKernelGGL(k_dropout_stream, dim3(1024), dim3(256), 0, st, t.sh[0], t.sl[0], (size_t)M * MST_D, pe_drop(seed, p_pe));
+        hipLaunchKernelGGL(k_dropout_stream, dim3(1024), dim3(256), 0, st, t.sh[0], t.sl[0], (size_t)M * MST_D,
+                           pe_drop(seed, p_pe, (uint32_t)clip0 * S * MST_D));
         HIPCHECK(hipGetLastError());
     }
-    CHECK(train_stack_forward(e, t, batch, S, p_drop, seed, nullptr, st));
+    CHECK(train_stack_forward(e, t, batch, S, p_drop, seed, nullptr, st, clip0));
     ws.hx = t.sh[nl];
     ws.hl = t.sl[nl];
     StepArgs sa{};

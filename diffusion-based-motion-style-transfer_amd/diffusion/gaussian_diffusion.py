@@ -411,6 +411,14 @@ class GaussianDiffusion:
             yield from self._engine_loop(sampler, denoiser, cfg, img, indices, clip_denoised, model_kwargs, const_noise, eta,
                                          progress, chunked, want_xstart)
             return
+        if with_grad:
+            # the steps' inputs are cut from each other's graphs (x.detach() in *_with_grad): native model calls on a single clip share
+            # one activation tape and ONE backward pass (model/native_stack.ChainedCalls); anything else is untouched by the context
+            from ..model.native_stack import ChainedCalls
+            with ChainedCalls(len(indices)):
+                yield from self._grad_steps(ddim, model, img, indices, shape, device, progress, clip_denoised, model_kwargs, eta,
+                                            const_noise, pred_xstart_in_graph)
+            return
         if progress:
             from tqdm.auto import tqdm
             indices = tqdm(indices)
@@ -429,6 +437,22 @@ class GaussianDiffusion:
                                             model_kwargs=model_kwargs, eta=eta) if ddim else
                            self.p_sample(model, img, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn,
                                          model_kwargs=model_kwargs, const_noise=const_noise))
+                yield out
+                img = out["sample"]
+
+    def _grad_steps(self, ddim, model, img, indices, shape, device, progress, clip_denoised, model_kwargs, eta, const_noise,
+                    pred_xstart_in_graph):
+        """The *_with_grad loop (reference gaussian_diffusion.py:775-794 with cond_fn_with_grad): every step's x0-hat stays in the graph."""
+        if progress:
+            from tqdm.auto import tqdm
+            indices = tqdm(indices)
+        for i in indices:
+            t = th.full((shape[0],), int(i), device=device, dtype=th.long)
+            with th.no_grad():
+                out = (self.ddim_sample_with_grad(model, img, t, clip_denoised=clip_denoised, model_kwargs=model_kwargs, eta=eta,
+                                                  pred_xstart_in_graph=pred_xstart_in_graph) if ddim else
+                       self.p_sample_with_grad(model, img, t, clip_denoised=clip_denoised, model_kwargs=model_kwargs,
+                                               const_noise=const_noise, pred_xstart_in_graph=pred_xstart_in_graph))
                 yield out
                 img = out["sample"]
 

@@ -165,12 +165,13 @@ class DenoiserEngine:
         return out
 
     # ------------------------------------------------------------------------------ training
-    def train_tape(self, rows, S):
-        """Uninitialised activation tape for one train_forward of `rows` clips x S tokens (caller-owned)."""
+    def train_tape(self, rows, S, zero=False):
+        """Activation tape for one train_forward of `rows` clips x S tokens (caller-owned); uninitialised unless `zero` (a tape
+        whose clips are written by several calls: a clip nobody wrote must differentiate to zeros, not to garbage)."""
         n = N.lib().mst_train_tape_bytes(self.handle, rows, S)
         if n <= 0:
             raise RuntimeError("mst_train_tape_bytes failed")
-        return torch.empty(n, dtype=torch.uint8, device=self.device)
+        return (torch.zeros if zero else torch.empty)(n, dtype=torch.uint8, device=self.device)
 
     def _key_keep(self, keep, rows, S):
         if keep is None:
@@ -213,16 +214,19 @@ class DenoiserEngine:
                                            N.ptr(kk), N.ptr(d_in), arr, N.stream_ptr(self.device)))
         return d_in
 
-    def train_model_forward(self, x, t, p_drop, p_pe, seed):
-        """Whole denoiser in train mode: x [B, F, 1, T], t int64 [B] -> (model output [B, F, 1, T], tape).  set_text first."""
+    def train_model_forward(self, x, t, p_drop, p_pe, seed, tape=None, clip0=0, tape_clips=0):
+        """Whole denoiser in train mode: x [B, F, 1, T], t int64 [B] -> (model output [B, F, 1, T], tape).  set_text first.
+        tape / clip0 / tape_clips: write clips [clip0, clip0 + B) of a tape made by train_tape(tape_clips, T + 1) (calls whose
+        inputs are cut from each other's graphs share one tape and ONE backward pass over all tape_clips clips)."""
         x = _f32c(x, self.device, "x")
         B, F, one, T = x.shape
         assert F * one == self.feats, (F, one, self.feats)
         t = t.to(device=self.device, dtype=torch.int64).contiguous()
-        tape = self.train_tape(B, T + 1)
+        if tape is None:
+            tape, clip0, tape_clips = self.train_tape(B, T + 1), 0, 0
         out = torch.empty_like(x)
         N.check(N.lib().mst_train_model_forward(self.handle, N.ptr(x), N.ptr(t), B, T, float(p_drop), float(p_pe), int(seed),
-                                                N.ptr(tape), N.ptr(out), N.stream_ptr(self.device)))
+                                                N.ptr(tape), N.ptr(out), int(clip0), int(tape_clips), N.stream_ptr(self.device)))
         return out, tape
 
     def train_model_backward(self, tape, d_out, p_drop, p_pe, seed, grads, need_input_grad=True):

@@ -152,6 +152,67 @@ def _node_done(ctx, had_param_grads):
         ready(ctx.eng)
 
 
+def _CHAIN_ON():
+    import os
+    return os.environ.get("MST_CHAIN", "1") != "0"      # MST_CHAIN=0: every model call differentiates alone (A/B, tests)
+
+
+class ChainedCalls:
+    """n single-clip model calls whose inputs are cut from each other's graphs -- the chained x0-hat steps of the fine-tune objective
+    (reference gaussian_diffusion.py:1364-1378 / inpainting_gaussian_diffusion.py:93, :206: `x = x.detach()`).  Their forward passes
+    are sequential (a step's input is the previous step's sample), their backward passes are independent: they write the clips of ONE
+    activation tape (mst_train_model_forward's clip0 / tape_clips) and are differentiated by ONE native backward pass over the n
+    clips, instead of n passes of ~160 launches each on a single clip's 197 token rows (6 x 0.94 ms of the fine-tune iteration).
+    The pass runs when the last of the n nodes has received its gradient, or at the end of the autograd pass with zeros for nodes
+    that received none."""
+    current = None
+
+    def __init__(self, n):
+        self.n, self.k, self.reported, self.done = int(n), 0, 0, False
+        self.tape = self.seed = self.dbuf = self.ctx0 = None
+        self.key = None
+
+    def __enter__(self):
+        self.prev, ChainedCalls.current = ChainedCalls.current, self
+        return self
+
+    def __exit__(self, *exc):
+        ChainedCalls.current = self.prev
+        return False
+
+    def accepts(self, key):
+        """Same engine, shape and dropout rates as the chain's first call, and a free slot."""
+        return not self.done and self.k < self.n and (self.key is None or self.key == key)
+
+    def report(self, ctx, k, grad_out):
+        if self.done:
+            raise RuntimeError("backward through a chained native training node a second time (its tape is released by the first)")
+        if self.dbuf is None:
+            self.dbuf = torch.zeros((self.n,) + tuple(grad_out.shape[1:]), dtype=torch.float32, device=grad_out.device)
+            self.ctx0 = ctx
+            Variable._execution_engine.queue_callback(self.finish)      # nodes that never receive a gradient: zeros
+        self.dbuf[k:k + 1].copy_(grad_out)
+        self.reported += 1
+        if self.reported == self.k:
+            self.finish()
+
+    def finish(self):
+        if self.done or self.dbuf is None:
+            return
+        self.done = True
+        ctx = self.ctx0
+        tape, self.tape = self.tape, None
+        try:
+            views = _sink_views(ctx, True, self.dbuf.device)
+            ctx.eng.train_model_backward(tape, self.dbuf, ctx.p_drop, ctx.p_pe, self.seed, views, need_input_grad=False)
+            _node_done(ctx, True)
+        except BaseException:
+            _abort_sink(ctx)
+            raise
+        finally:
+            self.dbuf = None
+
+
 class DenoiserTrainFn(torch.autograd.Function):
     """The WHOLE denoiser call as one node: conditioning token, pose embedding, positional-encoding dropout, the trainable
     stack and the output projection (mst_train_model_forward / _backward).  Used when the module conditions on text (every
@@ -160,17 +221,32 @@ class DenoiserTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, host, p_drop, p_pe, timesteps, text_emb, *params):
         B, F, one, T = x.shape
-        eng = host.mst_engine(B, T)
+        chain = ChainedCalls.current if _CHAIN_ON() else None
+        eng = host.mst_engine(max(B, chain.n) if chain is not None else B, T)
         eng.set_text(text_emb.detach())
         seed = _draw_seed(max(p_drop, p_pe))
+        ctx.eng, ctx.p_drop, ctx.p_pe, ctx.host, ctx.params, ctx.chain = eng, p_drop, p_pe, host, params, None
+        key = (id(eng), B, F, T, float(p_drop), float(p_pe))
+        if (chain is not None and B == 1 and not ctx.needs_input_grad[0] and any(ctx.needs_input_grad[6:]) and chain.accepts(key)):
+            if chain.k == 0:
+                chain.key, chain.seed, chain.tape = key, seed, eng.train_tape(chain.n, T + 1, zero=True)
+                _sink_of(host, params).open_nodes += 1          # the chain is ONE native backward call
+            out, _ = eng.train_model_forward(x.detach(), timesteps, p_drop, p_pe, chain.seed, tape=chain.tape, clip0=chain.k,
+                                             tape_clips=chain.n)
+            ctx.chain, ctx.slot, ctx.tape, ctx.seed = chain, chain.k, None, chain.seed
+            chain.k += 1
+            return out
         out, tape = eng.train_model_forward(x.detach(), timesteps, p_drop, p_pe, seed)
-        ctx.eng, ctx.tape, ctx.p_drop, ctx.p_pe, ctx.seed, ctx.host, ctx.params = eng, tape, p_drop, p_pe, seed, host, params
+        ctx.tape, ctx.seed = tape, seed
         if any(ctx.needs_input_grad[6:]):
             _sink_of(host, params).open_nodes += 1
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
+        if ctx.chain is not None:         # one slot of a shared tape: differentiated with the chain's other calls in one pass
+            ctx.chain.report(ctx, ctx.slot, grad_out)
+            return (None,) * (6 + len(ctx.params))
         need_in = ctx.needs_input_grad[0]
         tape = _take_tape(ctx)            # raises on a second backward BEFORE the sink is touched
         try:

@@ -249,10 +249,15 @@ int mst_train_backward(mst_engine* e, const void* tape_dev, const float* d_out_d
  * mst_set_text as for mst_forward), pose embedding + positional rows, PositionalEncoding's dropout p_pe (:404) on the
  * assembled sequence, the trainable stack (p_drop), output projection.  Backward returns dL/dx and accumulates the 96
  * stack gradients (the projections, the timestep MLP and the text projection are frozen in every shipped script).
- * x, out, d_out, d_x: float32 [batch][feats][1][frames]; t_idx: int64 [batch] original-process timesteps. */
+ * x, out, d_out, d_x: float32 [batch][feats][1][frames]; t_idx: int64 [batch] original-process timesteps.
+ * clip0 / tape_clips (tape_clips <= 0: the tape is this call's own): the call writes clips [clip0, clip0 + batch) of a tape laid out
+ * for tape_clips clips, and draws the dropout masks those clips have in a pass over the WHOLE tape with the same seed.  For model calls
+ * whose inputs are cut from each other's graphs -- the chained x0-hat steps of the fine-tune objective (gaussian_diffusion.py:1364-1378:
+ * `x.detach()` between steps) -- so that ONE mst_train_model_backward over tape_clips clips differentiates all of them (their forward
+ * passes are sequential, their backward passes independent). */
 int mst_train_model_forward(mst_engine* e, const float* x_dev, const int64_t* t_idx_dev, int32_t batch,
                             int32_t frames, float p_drop, float p_pe, uint64_t seed, void* tape_dev,
-                            float* out_dev, void* stream);
+                            float* out_dev, int32_t clip0, int32_t tape_clips, void* stream);
 int mst_train_model_backward(mst_engine* e, const void* tape_dev, const float* d_out_dev, int32_t batch,
                              int32_t frames, float p_drop, float p_pe, uint64_t seed, float* d_x_dev,
                              float* const* grads_host_array, void* stream);

@@ -428,3 +428,49 @@ def test_failed_backward_does_not_poison_the_gradient_sink():
     assert set(again) == set(fresh) and len(fresh) >= 96
     for n in fresh:
         assert rel_l2(again[n].cpu().numpy(), fresh[n].cpu().numpy()) < 1e-6, n
+
+
+def _cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(_dev())
+
+
+def test_chained_calls_share_one_backward_pass(monkeypatch):
+    """The fine-tune objective's chained x0-hat steps (reference gaussian_diffusion.py:1364-1378: inputs cut with x.detach()) write the
+    clips of ONE tape and are differentiated in ONE native pass (native_stack.ChainedCalls, mst_train_model_forward's clip0 /
+    tape_clips).  (i) engine level, dropout 0.1: the pass over the shared tape == the sum of passes over each clip alone in a tape of
+    the same layout (the same masks: the dropout counters are offset by the clip); (ii) through autograd, dropout 0: all 96 gradients
+    with the chain == without it (MST_CHAIN=0)."""
+    from mst_amd.engine import DenoiserEngine
+    F, T, n = 181, 76, 3
+    eng = DenoiserEngine(F, T, 4, device=_dev())
+    w = syn.denoiser_state(SEED, F)
+    eng.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, pe=torch.from_numpy(syn.positional_table(5000, 512)))
+    eng.set_text(_cu(syn.normal(SEED, "ch/txt", (1, 512))))
+    xs = [_cu(syn.normal(SEED, f"ch/x{k}", (1, F, 1, T))) for k in range(n)]
+    ts = [torch.tensor([t], device=_dev()) for t in (950, 500, 50)]
+    dout = _cu(syn.normal(SEED, "ch/dout", (n, F, 1, T)))
+    shapes = [tuple(torch.from_numpy(w[f"seqTransEncoder.layers.{l}.{k}"]).shape) for l in range(8) for k in LAYER_TENSORS]
+    zeros = lambda: [torch.zeros(s, device=_dev()) for s in shapes]
+    seed, p = 123456789, 0.1
+    # one pass over the shared tape
+    tape = eng.train_tape(n, T + 1, zero=True)
+    outs = [eng.train_model_forward(xs[k], ts[k], p, p, seed, tape=tape, clip0=k, tape_clips=n)[0] for k in range(n)]
+    g_all = zeros()
+    eng.train_model_backward(tape, dout, p, p, seed, g_all, need_input_grad=False)
+    # each clip alone in a tape of the same layout, the other clips' gradient zero
+    g_sum = zeros()
+    for k in range(n):
+        tk = eng.train_tape(n, T + 1, zero=True)
+        o, _ = eng.train_model_forward(xs[k], ts[k], p, p, seed, tape=tk, clip0=k, tape_clips=n)
+        assert torch.equal(o, outs[k])
+        dk = torch.zeros_like(dout)
+        dk[k] = dout[k]
+        eng.train_model_backward(tk, dk, p, p, seed, g_sum, need_input_grad=False)
+    worst = max(rel_l2(a.cpu().numpy(), b.cpu().numpy()) for a, b in zip(g_all, g_sum))
+    print("chained backward vs per-clip passes, worst tensor", worst)
+    assert worst < 2e-3                    # (f16 wgrad operands scaled by ONE power of two for the pass vs one per clip)
+    # a clip of the shared tape == the same call with a tape of its own when dropout is off
+    o_own, _ = eng.train_model_forward(xs[1], ts[1], 0.0, 0.0, 0)
+    t0 = eng.train_tape(n, T + 1, zero=True)
+    o_slot, _ = eng.train_model_forward(xs[1], ts[1], 0.0, 0.0, 0, tape=t0, clip0=1, tape_clips=n)
+    assert torch.equal(o_own, o_slot)
