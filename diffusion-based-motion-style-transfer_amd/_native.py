@@ -38,6 +38,7 @@ SIGNATURES = {
     "mst_engine_create": (C.c_int, [C.POINTER(MstConfig), C.POINTER(C.c_void_p)]),
     "mst_engine_destroy": (None, [C.c_void_p]),
     "mst_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_void_p]),
+    "mst_load_layers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
     "mst_weights_complete": (C.c_int, [C.c_void_p]),
     "mst_schedule_create": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
     "mst_schedule_destroy": (None, [C.c_void_p]),

@@ -19,6 +19,42 @@ __global__ void k_convert_pad(const float* __restrict__ src, int N, int K, f16* 
     }
 }
 
+// The 12 tensors of up to 8 encoder layers in ONE launch (a fine-tune iteration re-uploads all 96 after every optimizer step: 16
+// launches per layer one by one, 1.8 ms of launch chain per iteration).  grid = (2048 matrix tiles + 1 vector block, layers).
+// A matrix block converts one 32 x 32 fp32 tile to the f16 [out][in] copy (the GEMMs' NT operand) and the [in][out] copy (the dgrad
+// operand) -- the same roundings as k_convert_pad / k_convert_transpose; the vector block copies the 8 fp32 vectors.
+struct UpLayer { const float* src[12]; f16* w[4]; f16* wT[4]; float* v[8]; };
+struct UpArgs { UpLayer L[8]; };
+__global__ __launch_bounds__(256) void k_upload_layers(UpArgs a) {
+    __shared__ float tile[32][33];
+    const UpLayer& L = a.L[blockIdx.y];
+    int b = blockIdx.x;
+    if (b == 2048) {                                    // vectors: in_proj_bias 1536, out_proj.bias 512, linear1.bias 1024, linear2.bias 512, 4 x 512 LayerNorm
+        const int vs[8] = {1, 3, 5, 7, 8, 9, 10, 11}, vn[8] = {3 * MST_D, MST_D, MST_FF, MST_D, MST_D, MST_D, MST_D, MST_D};
+        for (int j = 0; j < 8; j++)
+            for (int i = threadIdx.x; i < vn[j]; i += 256) L.v[j][i] = L.src[vs[j]][i];
+        return;
+    }
+    // matrix m: 0 in_proj [1536][512], 1 out_proj [512][512], 2 linear1 [1024][512], 3 linear2 [512][1024]; tiles 768 | 256 | 512 | 512
+    int m, N, K;
+    if (b < 768) { m = 0; N = 3 * MST_D; K = MST_D; }
+    else if (b < 1024) { m = 1; b -= 768; N = MST_D; K = MST_D; }
+    else if (b < 1536) { m = 2; b -= 1024; N = MST_FF; K = MST_D; }
+    else { m = 3; b -= 1536; N = MST_D; K = MST_FF; }
+    const int ktiles = K / 32, n0 = (b / ktiles) * 32, k0 = (b % ktiles) * 32;
+    const float* src = L.src[2 * m];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int j = ty; j < 32; j += 8) {
+        const float v = src[(size_t)(n0 + j) * K + k0 + tx];
+        tile[j][tx] = v;
+        L.w[m][(size_t)(n0 + j) * K + k0 + tx] = (f16)v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = ty; j < 32; j += 8) L.wT[m][(size_t)(k0 + j) * N + n0 + tx] = (f16)tile[tx][j];
+}
+
 __global__ void k_copy_pad_f32(const float* __restrict__ src, int n, float* __restrict__ dst, int npad) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < npad) dst[i] = i < n ? src[i] : 0.f;

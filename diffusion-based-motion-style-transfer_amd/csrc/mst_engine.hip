@@ -191,9 +191,10 @@ struct mst_engine {
     int fuse_frames = 1;                  // sampling loop: a step's epilogue writes the next step's f16 frame rows; MST_FUSE_FRAMES=0 runs k_frames_f16 every step
     int precise = 0;                      // mst_set_precise / MST_PRECISE=1: every layer GEMM of the sampling path multiplies its activation as hi + lo (the small-tile
                                           // kernels at any size, ~2x their MFMA work): for checkpoints whose outlier channels put f16 operands above the 1e-3 bar
-    int small_m = 3200;                   // launches of at most this many token rows take the small-tile path (MST_SMALL_M, 0 = never);
-                                          // tools/small_m_ab2.sh, one launch, us per step small / large tiles: 8 clips 444 / 569, 11: 519 / 571,
-                                          // 14: 560 / 572, 16: 566 / 571, 20: 641 / 575, 24: 718 / 577 (the large-tile step is flat: hand-over at 16 clips)
+    int small_m = 1900;                   // launches of at most this many token rows take the small-tile path (MST_SMALL_M, 0 = never).
+                                          // Round 4, with 32-token tiles in the fused tail of a lone launch (tools/r4_batch_sweep.sh, clips/s of a
+                                          // 200-step loop, small / large tiles): 4 clips 46.2 / 41.0, 8: 85.6 / 83.2, 12: 105.8 / 125.1, 16: 139.2 / 167.5
+                                          // -- hand-over between 9 and 10 clips (it was 16 clips = 3200 rows with 64-token tiles only)
     float* zacc = nullptr;                // fp32 GEMM result feeding k_ln_rows on that path
     int ln128_min_m = 1 << 30;            // MST_LN128_M=n: launches of >= n token rows use 128-token LayerNorm tiles (half the weight
                                           // re-streaming).  Off by default: wins 16-21 % in gemm_bench, nothing in the pipeline (CFG 39.7 vs
@@ -524,6 +525,50 @@ extern "C" int mst_load_weight(mst_engine* e, const char* name, const float* src
     bool seen = false;
     for (auto& s : e->loaded) seen |= (s == n);
     if (!seen) e->loaded.push_back(n);
+    return 0;
+}
+
+// All 12 tensors of every encoder layer in one launch per 8 layers (k_upload_layers): what a fine-tune iteration does after every
+// optimizer step.  srcs: num_layers x 12 device pointers in the order of mst_load_weight's layer list (in_proj_weight, in_proj_bias,
+// out_proj.weight, out_proj.bias, linear1.weight, linear1.bias, linear2.weight, linear2.bias, norm1.weight, norm1.bias, norm2.weight,
+// norm2.bias).  Same results as 12 x num_layers mst_load_weight calls (precise mode: use those -- this entry writes no lo halves).
+extern "C" int mst_load_layers(mst_engine* e, const float* const* srcs, void* stream) {
+    if (!e || !srcs) return fail("mst_load_layers: null argument");
+    if (e->precise) return fail("mst_load_layers: precise mode needs the weights' lo halves: upload with mst_load_weight");
+    static_assert(MST_D == 512 && MST_FF == 1024, "k_upload_layers' tile map");
+    static const char* kNames[12] = {"self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_attn.out_proj.weight", "self_attn.out_proj.bias",
+                                     "linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias", "norm1.weight", "norm1.bias",
+                                     "norm2.weight", "norm2.bias"};
+    hipStream_t st = (hipStream_t)stream;
+    ON_DEVICE(e->cfg.device);
+    const int nl = e->cfg.num_layers;
+    for (int i = 0; i < 12 * nl; i++) if (!srcs[i]) return fail("mst_load_layers: null tensor %d", i);
+    for (int l0 = 0; l0 < nl; l0 += 8) {
+        UpArgs a{};
+        const int n = nl - l0 < 8 ? nl - l0 : 8;
+        for (int j = 0; j < n; j++) {
+            LayerW& w = e->L[l0 + j];
+            UpLayer& u = a.L[j];
+            for (int k = 0; k < 12; k++) u.src[k] = srcs[(l0 + j) * 12 + k];
+            u.w[0] = w.w_in; u.w[1] = w.w_out; u.w[2] = w.w1; u.w[3] = w.w2;
+            u.wT[0] = w.w_inT; u.wT[1] = w.w_outT; u.wT[2] = w.w1T; u.wT[3] = w.w2T;
+            u.v[0] = w.b_in; u.v[1] = w.b_out; u.v[2] = w.b1; u.v[3] = w.b2; u.v[4] = w.g1; u.v[5] = w.be1; u.v[6] = w.g2; u.v[7] = w.be2;
+        }
+        hipLaunchKernelGGL(k_upload_layers, dim3(2049, n), dim3(256), 0, st, a);
+        HIPCHECK(hipGetLastError());
+    }
+    for (int l = 0; l < nl; l++) {
+        e->L[l].qkv_dirty = e->L[l].tail_dirty = true;
+        for (int k = 0; k < 12; k++) {
+            char name[160];
+            snprintf(name, sizeof(name), "seqTransEncoder.layers.%d.%s", l, kNames[k]);
+            std::string n(name);
+            if ((k & 1) == 0 && k < 8) e->lo_missing.insert(n);
+            bool seen = false;
+            for (auto& s2 : e->loaded) seen |= (s2 == n);
+            if (!seen) e->loaded.push_back(n);
+        }
+    }
     return 0;
 }
 

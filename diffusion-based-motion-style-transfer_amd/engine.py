@@ -113,6 +113,8 @@ class DenoiserEngine:
         h = C.c_void_p()
         N.check(N.lib().mst_engine_create(C.byref(self.cfg), C.byref(h)))
         self.handle = h
+        import os
+        self._precise_on = os.environ.get("MST_PRECISE", "0") not in ("", "0")
 
     def __del__(self):
         h = getattr(self, "handle", None)
@@ -127,6 +129,18 @@ class DenoiserEngine:
         t = _f32c(tensor, self.device, name)
         shape = (C.c_int64 * t.dim())(*t.shape)
         N.check(N.lib().mst_load_weight(self.handle, name.encode(), N.ptr(t), shape, t.dim(), N.stream_ptr(self.device)))
+
+    def load_layers(self, tensors):
+        """All layer tensors (num_layers x LAYER_TENSORS order) in one launch per 8 layers: float32, contiguous, on this device."""
+        assert len(tensors) == 12 * self.num_layers
+        for t in tensors:
+            if not (t.is_cuda and t.device == self.device and t.dtype == torch.float32 and t.is_contiguous()):
+                raise ValueError("load_layers wants float32 contiguous tensors on the engine's device")
+        arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+        N.check(N.lib().mst_load_layers(self.handle, arr, N.stream_ptr(self.device)))
+        self._sources = getattr(self, "_sources", {})
+        for i, t in enumerate(tensors):
+            self._sources[f"seqTransEncoder.layers.{i // 12}.{LAYER_TENSORS[i % 12]}"] = t
 
     def load_state_dict(self, sd, layer_prefix="seqTransEncoder.layers.", prior_prefix="motion_enc.mdm_model.",
                         pe=None):
@@ -339,6 +353,7 @@ class DenoiserEngine:
     def set_precise(self, on=True):
         """Every layer GEMM of the sampling path multiplies its activation as an f16 hi + lo pair (~22 bits): for checkpoints
         whose outlier statistics put plain f16 operands above the 1e-3 bar; about half the default throughput at 64 clips."""
+        self._precise_on = bool(on)
         rc = N.lib().mst_set_precise(self.handle, int(bool(on)))
         if rc == 2:                                        # weights went up without their lo halves: upload again, now with them
             for name, tensor in list(getattr(self, "_sources", {}).items()):

@@ -73,6 +73,11 @@ void mst_engine_destroy(mst_engine* e);
  * orders the two itself, exactly as for the plain copies. */
 int mst_load_weight(mst_engine* e, const char* name, const float* src_dev,
                     const int64_t* shape, int32_t ndim, void* stream);
+/* The 12 tensors of EVERY encoder layer in one call (one launch per 8 layers): srcs_host_array = num_layers x 12 device pointers, per
+ * layer in the order in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias, linear1.weight, linear1.bias, linear2.weight,
+ * linear2.bias, norm1.weight, norm1.bias, norm2.weight, norm2.bias.  Same result as the 12 x num_layers mst_load_weight calls; what
+ * a fine-tune iteration does after every optimizer step (train/training_loop.py:297-303 updates all 96).  Not in precise mode. */
+int mst_load_layers(mst_engine* e, const float* const* srcs_host_array, void* stream);
 /* 0 when every tensor of the list above has been loaded. */
 int mst_weights_complete(const mst_engine* e);
 

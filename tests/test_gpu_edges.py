@@ -139,8 +139,8 @@ def test_odd_batch_across_the_two_slices_equals_single_slice():
     from oracle import schedule
     F, T, B = 181, 76, 17
     eng, w, pe = make(F, T, B)
-    # 17 clips x 77 tokens take the small-tile path: sliced (8-clip minimum); 64 clips = 4928 rows are past the hand-over (3200 rows:
-    # the large-tile step is flat in the batch and the shorter one from 16 full-length clips on) and fit the chip at once: one slice,
+    # 17 clips x 77 tokens take the small-tile path: sliced (8-clip minimum); 64 clips = 4928 rows are past the hand-over (1900 rows:
+    # the large-tile step wins from 10 full-length clips on) and fit the chip at once: one slice,
     # as does their CFG batch (9856 rows, 154 large tiles)
     assert eng.loop_slices(B) == 2 and eng.loop_slices(8) == 1 and eng.loop_slices(64) == 1 and eng.loop_slices(64, cfg=True) == 1
     shape = (B, F, 1, T)
@@ -241,7 +241,7 @@ def test_cfg_loop_in_slices_equals_clipwise_runs():
     """CFG with the batch split over concurrent slices: every clip must come out as when run alone."""
     from mst_amd.engine import Schedule, SAMPLER_DDPM
     from oracle import schedule
-    F, T, B = 181, 76, 13
+    F, T, B = 181, 76, 12                          # 24 rows x 77 tokens = 1848: the small-tile path (hand-over at 1900 rows), three slices of 8 rows
     eng, w, pe = make(F, T, 2 * B)
     assert eng.loop_slices(B, cfg=True) == 3
     shape = (B, F, 1, T)
@@ -256,11 +256,11 @@ def test_cfg_loop_in_slices_equals_clipwise_runs():
     eng.set_text(txt, cfg=True)
     whole = eng.sample_loop(sch, x0.clone(), 3, 0, SAMPLER_DDPM, cfg=True, scale=scale, mask=mask, motion=motion, noise=nz)
     parts = []
-    for i in (0, 6, 12):
+    for i in (0, 6, 11):
         eng.set_text(txt[i:i + 1], cfg=True)
         parts.append(eng.sample_loop(sch, x0[i:i + 1].clone(), 3, 0, SAMPLER_DDPM, cfg=True, scale=scale[i:i + 1],
                                      mask=mask[i:i + 1], motion=motion[i:i + 1], noise=nz[:, i:i + 1].contiguous()))
-    assert rel_l2(torch.cat(parts).cpu().numpy(), whole[[0, 6, 12]].cpu().numpy()) < 1e-6
+    assert rel_l2(torch.cat(parts).cpu().numpy(), whole[[0, 6, 11]].cpu().numpy()) < 1e-6
 
 
 def test_graph_replayed_loop_equals_host_enqueued_loop(monkeypatch):
@@ -303,3 +303,33 @@ def test_graph_replayed_loop_equals_host_enqueued_loop(monkeypatch):
         eng.set_text(txt, cfg=True)
         res.append(eng.sample_loop(sch, x0.clone(), NS - 1, 0, SAMPLER_DDPM, cfg=True, scale=scale, mask=mask, motion=motion, seed=9))
     assert torch.equal(res[0], res[1])
+
+
+def test_fused_layer_upload_equals_tensor_by_tensor_upload():
+    """mst_load_layers (all 96 layer tensors in one launch: what a fine-tune iteration does after the optimizer step) against 96
+    mst_load_weight calls: the sampling forward (packed fragment streams) and the training node (plain [out][in] and [in][out]
+    copies) give bit-identical results."""
+    from mst_amd.engine import LAYER_TENSORS
+    F, T, B = 181, 76, 2
+    eng_a, w, pe = make(F, T, B)
+    eng_b, _, _ = make(F, T, B)
+    w2 = {k: (v * 1.25 + 0.01).astype(np.float32) if k.startswith("seqTransEncoder.layers.") else v for k, v in w.items()}
+    layer_names = [f"seqTransEncoder.layers.{i}.{k}" for i in range(8) for k in LAYER_TENSORS]
+    for k in layer_names:
+        eng_a.load_tensor(k, torch.from_numpy(w2[k]))
+    eng_b.load_layers([cu(w2[k]) for k in layer_names])
+    x = cu(syn.normal(SEED, "up/x", (B, F, 1, T)))
+    t = torch.tensor([10, 900], device=dev())
+    txt = cu(syn.normal(SEED, "up/txt", (B, 512)))
+    eng_a.set_text(txt)
+    eng_b.set_text(txt)
+    assert torch.equal(eng_a.forward(x, t), eng_b.forward(x, t))
+    oa, ta = eng_a.train_model_forward(x, t, 0.1, 0.1, 4242)
+    ob, tb = eng_b.train_model_forward(x, t, 0.1, 0.1, 4242)
+    assert torch.equal(oa, ob)
+    d = cu(syn.normal(SEED, "up/d", (B, F, 1, T)))
+    ga = [torch.zeros(torch.from_numpy(w2[k]).shape, device=dev()) for k in layer_names]
+    gb = [torch.zeros_like(g) for g in ga]
+    dxa = eng_a.train_model_backward(ta, d, 0.1, 0.1, 4242, ga)
+    dxb = eng_b.train_model_backward(tb, d, 0.1, 0.1, 4242, gb)
+    assert torch.equal(dxa, dxb) and all(torch.equal(p, q) for p, q in zip(ga, gb))
