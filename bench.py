@@ -50,9 +50,9 @@ SYMBOL = {
     "qkv_attention_fused": "k_qkv_attention2<13>",
     "ffn1_gelu_gemm": "k_gemm_dma<128,256,2,2,3,1,RowsDirect,DEpiBiasF16<true>,32>",
     "layer_tail_fused": "k_layer_tail",
-    # (as rocprofv3 prints them at 263 features: 384-row output tile, split hi + lo activation operand XS = 2; NX = 2 under CFG)
-    "embed_out_step": "k_gemm_dma<64,384,1,3,4,1,RowsFrames,DEpiEmbedOut<1>,32,2>",
-    "embed_in": "k_gemm_dma<64,512,2,2,4,1,RowsDirect,DEpiEmbedIn,32,2> (writes the conditioning tokens too; + k_frames_f16 on the first step of a loop, later steps get their f16 frame rows from the previous step's epilogue)",
+    # (as rocprofv3 prints them at 263 features: 3 blocks of 16 output features per wave, ancestral step, no CFG; kpad 288 = 9 k-steps)
+    "embed_out_step": "k_embed_out<3,1,1>",
+    "embed_in": "k_embed_in<9> (writes the conditioning tokens too; + k_frames_f16 on the first step of a loop, later steps get their f16 frame rows from the previous step's epilogue)",
     "cond_token": "k_cond_token",
     "qkv_gemm": "k_gemm_dma<...,DEpiBiasF16<false>>",
     "attention": "k_attention<7>",

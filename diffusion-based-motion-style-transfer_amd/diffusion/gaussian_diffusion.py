@@ -423,7 +423,7 @@ class GaussianDiffusion:
             from tqdm.auto import tqdm
             indices = tqdm(indices)
         for i in indices:
-            # (the reference's th.tensor([i] * B, device=...) at gaussian_diffusion.py:780 is a blocking host-to-device copy: it would
+            # (the reference's th.tensor([i] * B, device=...) at gaussian_diffusion.py:775 / :1063 is a blocking host-to-device copy: it would
             # drain the GPU once per chained step of the fine-tune objective; a device-side fill gives the same tensor)
             t = th.full((shape[0],), int(i), device=device, dtype=th.long)
             with th.no_grad():

@@ -159,7 +159,7 @@ def _CHAIN_ON():
 
 class ChainedCalls:
     """n single-clip model calls whose inputs are cut from each other's graphs -- the chained x0-hat steps of the fine-tune objective
-    (reference gaussian_diffusion.py:1364-1378 / inpainting_gaussian_diffusion.py:93, :206: `x = x.detach()`).  Their forward passes
+    (reference gaussian_diffusion.py:1364-1378 / inpainting_gaussian_diffusion.py:96, :197: `x = x.detach()`).  Their forward passes
     are sequential (a step's input is the previous step's sample), their backward passes are independent: they write the clips of ONE
     activation tape (mst_train_model_forward's clip0 / tape_clips) and are differentiated by ONE native backward pass over the n
     clips, instead of n passes of ~160 launches each on a single clip's 197 token rows (6 x 0.94 ms of the fine-tune iteration).
