@@ -205,8 +205,15 @@ struct OutItems {
 // NBW: 16-feature blocks per wave (F <= 128 NBW); NX = 2: classifier-free guidance (cond and uncond rows, blended in the accumulators).
 // LDS: hi image [0, 64 K) | lo image [64 K, 128 K): frame row r = 1 KB, 16-B chunk c at c ^ (r & 15) (conflict-free ds_read_b128 of the
 // 16x16x32 B operand, as the layer tail's att image); the epilogue's [feature][frame] tile overlays them.
-template <int NBW, int MODE, int NX>
-__global__ __launch_bounds__(512) void k_embed_out(RowsFrames xs, const f16* __restrict__ wpk, DEpiEmbedOut<MODE> epi) {
+// KSN > 0: the NEXT step's pose embedding in the same launch (the sampling loop's steps j and j + 1 meet in this tile: x_{t-1} is on chip,
+// the 64 frames are the same rows of the token stream).  The updated clip goes from the [feature][frame] tile into two f16 images
+// [frame][kpad] (hi, lo) BEHIND the tile, a second streamed GEMM (KSN k-steps, wave w owns output blocks w, w + 8, w + 16, w + 24) multiplies
+// them with W_in, and DEpiEmbedIn::finish writes the stream rows and the conditioning tokens of step j + 1: one launch, one boundary
+// and the 16 MB round trip of the f16 frame rows less per step.
+template <int NBW, int MODE, int NX, int KSN = 0>
+__global__ __launch_bounds__(512) void k_embed_out(RowsFrames xs, const f16* __restrict__ wpk, DEpiEmbedOut<MODE> epi,
+                                                   const f16* __restrict__ wpk_in = nullptr, DEpiEmbedIn epi_in = DEpiEmbedIn{}) {
+    static_assert(KSN == 0 || (NX == 1 && MODE != 0 && NBW <= 3), "the fused next-step embedding is for plain sampling steps");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using C = EmbCfg;
     constexpr int KS = MST_D / 32, NFR = KS * NBW, D = 8;               // (8 fragments in flight: the registers go to the staged epilogue)
@@ -321,9 +328,72 @@ __global__ __launch_bounds__(512) void k_embed_out(RowsFrames xs, const f16* __r
             }
             items.apply(epi, sa, tile);
             EMB_MARK(5)
-            epi.template frames_next<C::BT>(tok0, 0, smem);
-            EMB_MARK(6)
-            return;
+            if constexpr (KSN == 0) {
+                epi.template frames_next<C::BT>(tok0, 0, smem);
+                EMB_MARK(6)
+                return;
+            } else {
+                // ---- step j + 1's pose embedding.  (The host sends only frame counts that are multiples of 4 here: `staged` holds.)
+                constexpr int RS = KSN * 64 + 16, IMG = C::BT * RS, NFR2 = KSN * 4, D2 = NFR2 < 16 ? NFR2 / 4 * 4 : 16;
+                const int off_img = (epi.F * LDT * 4 + 15) & ~15;      // behind the tile's F feature rows (the host checked that both images fit)
+                __syncthreads();                                       // the tile holds all of x_{t-1}
+                char* img = smem + off_img;
+                for (int it = tid; it < C::BT * KSN * 4; it += 512) {  // (frame, 8 features) items: conflict-free tile reads, 16-byte image writes
+                    const int tl = it % C::BT, fg = it / C::BT;
+                    f16x8 v, vl;
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const int f = 8 * fg + q;
+                        const float xv = f < epi.F ? tile[f * LDT + tl] : 0.f;      // columns [F, kpad): the zero padding of the GEMM's K
+                        v[q] = (f16)xv;
+                        vl[q] = (f16)(xv - (float)v[q]);
+                    }
+                    *reinterpret_cast<f16x8*>(img + tl * RS + fg * 16) = v;
+                    *reinterpret_cast<f16x8*>(img + IMG + tl * RS + fg * 16) = vl;
+                }
+                __syncthreads();
+                f32x4 acc2[4][4];
+#pragma unroll
+                for (int bi = 0; bi < 4; bi++)
+#pragma unroll
+                    for (int tb = 0; tb < 4; tb++) acc2[bi][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                f16x8 yh[2][4], yl[2][4];
+                auto yread = [&](int k32, int p) {
+                    const char* src = img + (unsigned)t16 * RS + (unsigned)k32 * 64u + (unsigned)q4 * 16u;
+#pragma unroll
+                    for (int tb = 0; tb < 4; tb++) {
+                        yh[p][tb] = *reinterpret_cast<const f16x8*>(src + tb * 16 * RS);
+                        yl[p][tb] = *reinterpret_cast<const f16x8*>(src + IMG + tb * 16 * RS);
+                    }
+                };
+                yread(0, 0);
+                emb_stream<NFR2, D2>(reinterpret_cast<const char*>(wpk_in) + (size_t)wave * NFR2 * 1024, w_voff,
+                    [&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        if constexpr (j % 4 == 0 && j / 4 + 1 < KSN) yread(j / 4 + 1, (j / 4 + 1) & 1);
+                    },
+                    [&](auto jc, f16x8 wf) {
+                        constexpr int j = decltype(jc)::value;
+                        constexpr int k32 = j / 4, bi = j % 4;
+#pragma unroll
+                        for (int tb = 0; tb < 4; tb++) {
+                            acc2[bi][tb] = mfma16(wf, yh[k32 & 1][tb], acc2[bi][tb]);
+                            acc2[bi][tb] = mfma16(wf, yl[k32 & 1][tb], acc2[bi][tb]);
+                        }
+                    });
+                __syncthreads();                                       // tile and images are dead: the fp32 rows overlay them
+                constexpr int LD = MST_D * 4 + 16;
+#pragma unroll
+                for (int tb = 0; tb < 4; tb++) {
+                    char* trow = smem + (16 * tb + t16) * LD;
+#pragma unroll
+                    for (int bi = 0; bi < 4; bi++) *reinterpret_cast<f32x4*>(trow + (16 * (wave + 8 * bi) + 4 * q4) * 4) = acc2[bi][tb];
+                }
+                __syncthreads();
+                epi_in.template finish<C::BT>(tok0, smem);
+                EMB_MARK(6)
+                return;
+            }
         }
     }
     epi.template finish<C::BT>(sa, tok0, 0, smem);

@@ -168,6 +168,7 @@ struct mst_engine {
     float *b_pose_in = nullptr, *b_pose_out = nullptr;
     f16 *w_pose_in_pk = nullptr, *w_pose_out_pk = nullptr;      // the two projections as per-wave fragment streams (mst_embed.h, k_pack_wave_blocks)
     bool pose_in_dirty = true, pose_out_dirty = true;          // ... older than w_pose_in / w_pose_out: repacked by ensure_packed()
+    int fuse_embed = 1;                   // a sampling step's output projection also embeds the next step (MST_FUSE_EMBED=0: two launches)
     int embed_fast = 1;                   // K3 / K9 as the latency kernels of mst_embed.h; MST_EMBED_FAST=0: the ring GEMMs of rounds 1-3
     float *w_t0 = nullptr, *b_t0 = nullptr, *w_t2 = nullptr, *b_t2 = nullptr, *w_text = nullptr, *b_text = nullptr;
     float* pe = nullptr;
@@ -364,6 +365,7 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     if (const char* v = getenv("MST_FUSE_TAIL")) e->fuse_tail = atoi(v) != 0;
     if (const char* v = getenv("MST_FUSE_FRAMES")) e->fuse_frames = atoi(v) != 0;
     if (const char* v = getenv("MST_EMBED_FAST")) e->embed_fast = atoi(v) != 0;
+    if (const char* v = getenv("MST_FUSE_EMBED")) e->fuse_embed = atoi(v) != 0;
     if (const char* v = getenv("MST_TAIL_NTB")) { int n = atoi(v); e->tail_ntb = (n >= 2 && n <= 4) ? n : 0; }
     if (const char* v = getenv("MST_WGRAD_STREAM")) e->wgrad_stream_on = atoi(v) != 0;
     if (const char* v = getenv("MST_SMALL_M")) e->small_m = atoi(v);
@@ -855,7 +857,7 @@ static int launch_tail(const mst_engine* e, const LayerW& w, const WS& ws, int M
 
 // K3 .. K8: token stream through the encoder stack.  rows = clips through the transformer.
 // K1-K3: conditioning token + pose embedding of the frames -> token stream rows (ws.hx / ws.hl)
-struct LoopRef { const LoopDev* ld = nullptr; int joff = 0; unsigned long long eo = 0; bool frames_ready = false; };   // frames_ready: the previous step's epilogue already wrote ws.xt   // loop mode of a step's kernels (see LoopDev)
+struct LoopRef { const LoopDev* ld = nullptr; int joff = 0; unsigned long long eo = 0; bool frames_ready = false; bool stream_ready = false; };   // stream_ready: the previous step's k_embed_out already embedded this step (token stream and conditioning tokens are in ws.hx / ws.hl)   // frames_ready: the previous step's epilogue already wrote ws.xt   // loop mode of a step's kernels (see LoopDev)
 
 template <int KS>
 static int launch_embed_in_n(mst_engine* e, const WS& ws, int tot, const DEpiEmbedIn& epi, hipStream_t st) {
@@ -874,9 +876,22 @@ static int launch_embed_in(mst_engine* e, const WS& ws, int tot, const DEpiEmbed
     return fail("pose embedding: %d input columns unsupported", e->kin_pad);
 }
 
+// the pose embedding's epilogue of a model call / loop step: positional rows, stream rows, conditioning tokens
+static DEpiEmbedIn embed_in_epi(const mst_engine* e, const WS& ws, int clips_x, int rows, int T, int temb_uniform_row, int temb_mod, int tp_uncond,
+                                const LoopDev* ld, int joff) {
+    const int S = T + 1, tot = clips_x * T;
+    DEpiEmbedIn epi{e->b_pose_in, e->pe, ws.hx, ws.hl, T, S, tot, rows > clips_x ? (size_t)clips_x * S * MST_D : 0};
+    epi.ct.temb = e->temb; epi.ct.textproj = ws.textproj; epi.ct.ld = ld;
+    epi.ct.uniform_row = temb_uniform_row; epi.ct.temb_mod = temb_mod; epi.ct.joff = joff; epi.ct.rows = rows;
+    epi.ct.tp_half = rows > clips_x ? clips_x : 0; epi.ct.tp_uncond = rows > clips_x ? tp_uncond : 0;
+    return epi;
+}
+
 static int assemble_stream(mst_engine* e, const WS& ws, const float* x, int clips_x, int rows, int T, int temb_uniform_row, int temb_mod,
                            hipStream_t st, int tp_uncond, LoopRef lr = LoopRef()) {
+    if (lr.stream_ready) return 0;
     const int S = T + 1;
+    (void)S;
     // (the conditioning token of every clip -- timestep embedding + text projection + positional row 0, formerly a launch of its
     // own, k_cond_token -- is written by the pose-embedding GEMM's epilogue: CondTok in mst_gemm_dma.h)
     {
@@ -888,10 +903,7 @@ static int assemble_stream(mst_engine* e, const WS& ws, const float* x, int clip
             hipLaunchKernelGGL(k_frames_f16, dim3((T + 31) / 32, e->kin_pad / 32, clips_x), dim3(256), 0, st, x, F, T, e->kin_pad, ws.xt, (const float*)nullptr, lr.ld, lr.eo, ws.xt_lo);
             HIPCHECK(hipGetLastError());
         }
-        DEpiEmbedIn epi{e->b_pose_in, e->pe, ws.hx, ws.hl, T, S, tot, rows > clips_x ? (size_t)clips_x * S * MST_D : 0};
-        epi.ct.temb = e->temb; epi.ct.textproj = ws.textproj; epi.ct.ld = lr.ld;
-        epi.ct.uniform_row = temb_uniform_row; epi.ct.temb_mod = temb_mod; epi.ct.joff = lr.joff; epi.ct.rows = rows;
-        epi.ct.tp_half = rows > clips_x ? clips_x : 0; epi.ct.tp_uncond = rows > clips_x ? tp_uncond : 0;
+        const DEpiEmbedIn epi = embed_in_epi(e, ws, clips_x, rows, T, temb_uniform_row, temb_mod, tp_uncond, lr.ld, lr.joff);
         if (e->embed_fast && !e->precise) return launch_embed_in(e, ws, tot, epi, st);
         // x_t as hi + lo (RowsDirect::Xlo): both halves of a k-slab beside ONE copy of the weight slab
         CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1, 32, 2>(dim3((tot + 63) / 64, 1), RowsDirect{ws.xt, e->kin_pad, ws.xt_lo, e->precise ? e->w_pose_in_lo : nullptr},
@@ -1046,14 +1058,41 @@ static int launch_embed_out_n(mst_engine* e, const RowsFrames& xs, const DEpiEmb
     HIPCHECK(hipGetLastError());
     return 0;
 }
+// Can a sampling step's output projection also embed the NEXT step (k_embed_out<.., KSN>)?  The shapes the reference's datasets have
+// (150 / 181 / 190 / 263 features: 5 / 6 / 6 / 9 k-steps), and the tile plus the two frame images must fit the LDS.
+static bool embed_next_fits(const mst_engine* e, int T) {
+    const int ks = e->kin_pad / 32, nbw = (e->cfg.feats + 127) / 128, F = e->cfg.feats;
+    if (!e->embed_fast || e->precise || (T & 3)) return false;
+    if (!((ks == 5 && nbw == 2) || (ks == 6 && nbw == 2) || (ks == 9 && nbw == 3))) return false;
+    return (size_t)F * (EmbCfg::BT + 4) * 4 + 16 + 2 * (size_t)EmbCfg::BT * (ks * 64 + 16) <= (size_t)EmbCfg::SMEM;
+}
+template <int MODE, int NBW, int KSN>
+static int launch_embed_step_n(mst_engine* e, const RowsFrames& xs, const DEpiEmbedOut<MODE>& epi, const DEpiEmbedIn& next, int tiles, hipStream_t st) {
+    CHECK(ensure_dyn_lds((const void*)k_embed_out<NBW, MODE, 1, KSN>, EmbCfg::SMEM));
+    hipLaunchKernelGGL((k_embed_out<NBW, MODE, 1, KSN>), dim3(tiles), dim3(512), EmbCfg::SMEM, st, xs, e->w_pose_out_pk, epi, e->w_pose_in_pk, next);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
 template <int MODE>
 static int launch_embed_out(mst_engine* e, const WS& ws, int cfg, int batch, int T, float* out, const StepArgs& sa, hipStream_t st,
-                            int tok_off, bool frames_next) {
+                            int tok_off, bool frames_next, const DEpiEmbedIn* next = nullptr) {
     const int S = T + tok_off, tiles = (batch * T + EmbCfg::BT - 1) / EmbCfg::BT;
     RowsFrames xs{ws.hx, MST_D, T, S, batch * T, EmbCfg::BT, (size_t)batch * S, tok_off, ws.hl, nullptr};
     DEpiEmbedOut<MODE> epi{e->b_pose_out, e->cfg.feats, T, batch * T, out, sa};
     if (frames_next) { epi.xt_next = ws.xt; epi.kpad = e->kin_pad; epi.xt_next_lo = ws.xt_lo; }
     const int nbw = embed_out_nbw(e);
+    if constexpr (MODE != 0) {
+        if (next) {                                         // (mst_sample_loop asked embed_next_fits first)
+            if (cfg || tok_off != 1) return fail("output projection: the fused next-step embedding is for plain sampling steps");
+            epi.xt_next = ws.xt; epi.kpad = e->kin_pad;     // (marks the tile as reusable: OutItems::apply writes x_{t-1} back into it)
+            switch (e->kin_pad / 32) {
+                case 5: return launch_embed_step_n<MODE, 2, 5>(e, xs, epi, *next, tiles, st);
+                case 6: return launch_embed_step_n<MODE, 2, 6>(e, xs, epi, *next, tiles, st);
+                case 9: return launch_embed_step_n<MODE, 3, 9>(e, xs, epi, *next, tiles, st);
+            }
+            return fail("output projection: no fused instantiation for %d input columns", e->kin_pad);
+        }
+    }
 #define EO(N_) case N_: return cfg ? launch_embed_out_n<MODE, N_, 2>(e, xs, epi, tiles, st) : launch_embed_out_n<MODE, N_, 1>(e, xs, epi, tiles, st);
     switch (nbw) { EO(1) EO(2) EO(3) case 4: return launch_embed_out_n<MODE, 4, 1>(e, xs, epi, tiles, st); }
 #undef EO
@@ -1061,10 +1100,12 @@ static int launch_embed_out(mst_engine* e, const WS& ws, int cfg, int batch, int
 }
 template <int MODE>
 static int launch_out_nt(mst_engine* e, const WS& ws, int cfg, int batch, int T, float* out, const StepArgs& sa, hipStream_t st,
-                         const f16* wo = nullptr, const float* bo = nullptr, int tok_off = 1, bool frames_next = false, bool hi_lo = false) {
+                         const f16* wo = nullptr, const float* bo = nullptr, int tok_off = 1, bool frames_next = false, bool hi_lo = false,
+                         const DEpiEmbedIn* next = nullptr) {
     ProfScope ps(e, FAM_EMBED_OUT, st);
     if (e->embed_fast && !e->precise && hi_lo && !wo && !bo && !(cfg && embed_out_nbw(e) == 4))      // (385+ features under CFG: its two accumulator sets spill)
-        return launch_embed_out<MODE>(e, ws, cfg, batch, T, out, sa, st, tok_off, frames_next);
+        return launch_embed_out<MODE>(e, ws, cfg, batch, T, out, sa, st, tok_off, frames_next, next);
+    if (next) return fail("output projection: the fused next-step embedding needs the fast embed kernels");
     const int rows_out = e->cfg.feats;                   // (also for the pose embedding's backward, which runs this kernel with W_in^T)
     if (rows_out <= 256) return launch_out_nx<MODE, 256, 2, 1>(e, ws, cfg, batch, T, out, sa, st, wo, bo, tok_off, frames_next, hi_lo);
     if (rows_out <= 384) return launch_out_nx<MODE, 384, 1, 3>(e, ws, cfg, batch, T, out, sa, st, wo, bo, tok_off, frames_next, hi_lo);
@@ -1137,7 +1178,9 @@ struct LoopPlan {
 };
 // frames_ready / frames_next: the step's frame rows (ws.xt) were written by the previous step's epilogue / this step's epilogue
 // writes them for the next one (mst_sample_loop decides; see DEpiEmbedOut::xt_next)
-static int enqueue_step(mst_engine* e, const LoopPlan& p, int joff, int nsj, bool frames_ready = false, bool frames_next = false) {
+// stream_ready / embed_next: the previous step's output projection embedded this step / this step's embeds the next (k_embed_out<.., KSN>)
+static int enqueue_step(mst_engine* e, const LoopPlan& p, int joff, int nsj, bool frames_ready = false, bool frames_next = false,
+                        bool stream_ready = false, bool embed_next = false) {
     const mst_loop_args* a = p.a;
     e->cur_slices = nsj;
     for (int sl = 0; sl < nsj; sl++) {
@@ -1151,8 +1194,10 @@ static int enqueue_step(mst_engine* e, const LoopPlan& p, int joff, int nsj, boo
         WS ws = ws_slice(e, a->cfg ? 2 * c0 : c0, a->frames);
         ws.textproj = e->textproj + (size_t)c0 * MST_D;
         hipStream_t ss = p.streams[sl];
-        LoopRef lr{e->ld_dev, joff, eo, frames_ready};
+        LoopRef lr{e->ld_dev, joff, eo, frames_ready, stream_ready};
         CHECK(run_trunk(e, ws, nullptr, nb, a->cfg ? 2 * nb : nb, a->frames, 0, 0, ss, a->batch, lr));
+        const DEpiEmbedIn next_epi = embed_in_epi(e, ws, nb, nb, a->frames, 0, 0, a->batch, e->ld_dev, joff + 1);
+        const DEpiEmbedIn* next = embed_next ? &next_epi : nullptr;
         StepArgs sa{};
         sa.tab = p.s->tab;
         sa.nsteps = p.s->n;
@@ -1172,8 +1217,8 @@ static int enqueue_step(mst_engine* e, const LoopPlan& p, int joff, int nsj, boo
         sa.eo = eo;
         sa.step_stride = p.clip_elems;
         sa.rowflag = (a->inpainting_mask_dev && a->inpainted_motion_dev) ? e->rowflag + (size_t)c0 * e->cfg.feats : nullptr;
-        if (a->sampler == MST_SAMPLER_DDPM) CHECK(launch_out_nt<1>(e, ws, a->cfg, nb, a->frames, nullptr, sa, ss, nullptr, nullptr, 1, frames_next, true));
-        else CHECK(launch_out_nt<2>(e, ws, a->cfg, nb, a->frames, nullptr, sa, ss, nullptr, nullptr, 1, frames_next, true));
+        if (a->sampler == MST_SAMPLER_DDPM) CHECK(launch_out_nt<1>(e, ws, a->cfg, nb, a->frames, nullptr, sa, ss, nullptr, nullptr, 1, frames_next, true, next));
+        else CHECK(launch_out_nt<2>(e, ws, a->cfg, nb, a->frames, nullptr, sa, ss, nullptr, nullptr, 1, frames_next, true, next));
     }
     return 0;
 }
@@ -1241,7 +1286,7 @@ extern "C" int mst_sample_loop(mst_engine* e, const mst_schedule* s, const mst_l
     std::vector<long long> key = {a->batch, a->frames, a->cfg, a->sampler, a->noise_mode, a->mask_noise, a->clip_denoised,
                                   a->inpainting_mask_dev != nullptr, a->inpainted_motion_dev != nullptr, a->xstart_dump_dev != nullptr,
                                   a->scale_dev != nullptr, p.nsl, U, (long long)(size_t)s->tab, s->n, e->small_m, e->fuse_tail,
-                                  e->fuse_qkv_attn, e->ln128_min_m, e->precise, e->tail_ntb};      // every switch run_trunk / loop_slices_for branch on
+                                  e->fuse_qkv_attn, e->ln128_min_m, e->precise, e->tail_ntb, e->embed_fast};      // every switch run_trunk / loop_slices_for branch on
     const bool use_graph = e->graph_on && !e->prof_on && e->dbg_stage < 0 && nrun >= 2 * U;
     bool forked = false;
     auto steps = [&]() -> int {
@@ -1288,6 +1333,11 @@ extern "C" int mst_sample_loop(mst_engine* e, const mst_schedule* s, const mst_l
         // step runs as one slice), not for frame counts the epilogue walks element-wise, not in captured graphs (their first
         // step would have to differ from call to call).
         const bool chain = e->fuse_frames && !a->cfg && (a->frames & 3) == 0 && e->dbg_stage < 0;
+        // ... and where the shapes allow, step j's output projection embeds step j + 1 in the same launch (MST_FUSE_EMBED=0: frame rows
+        // only).  Instrumented steps and their neighbours keep the two kernels apart, so that the event-timed families stay what they say.
+        const bool fuse_embed = chain && e->fuse_embed && embed_next_fits(e, a->frames);
+        auto instrumented = [&](int jj) { return e->prof_on && (jj % e->prof_period == 0); };
+        bool stream_ready = false;
         for (; j < nrun; j++) {
             e->prof_now = e->prof_on && (j % e->prof_period == 0);
             // instrumented steps run as ONE full-batch slice so the HIP-event durations are those of isolated
@@ -1295,7 +1345,9 @@ extern "C" int mst_sample_loop(mst_engine* e, const mst_schedule* s, const mst_l
             const int nsj = e->prof_now ? 1 : p.nsl;
             if (nsj > 1 && !forked) { CHECK(fork_slices(e, p)); forked = true; }
             else if (nsj == 1 && forked) { CHECK(join_slices(e, p)); forked = false; }
-            CHECK(enqueue_step(e, p, j, nsj, chain && j > 0, chain && j + 1 < nrun));
+            const bool embed_next = fuse_embed && j + 1 < nrun && !instrumented(j) && !instrumented(j + 1);
+            CHECK(enqueue_step(e, p, j, nsj, chain && j > 0 && !stream_ready, chain && j + 1 < nrun && !embed_next, stream_ready, embed_next));
+            stream_ready = embed_next;
         }
         return 0;
     };
