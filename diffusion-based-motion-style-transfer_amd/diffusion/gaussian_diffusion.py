@@ -402,22 +402,25 @@ class GaussianDiffusion:
                                  pred_xstart_in_graph, stop_timesteps, eta=0.0, chunked=False, want_xstart=True):
         if randomize_class:
             raise NotImplementedError("randomize_class is an image-diffusion leftover, unused by this model family")
-        device, img, indices = self._loop_setup(model, shape, noise, device, skip_timesteps, init_image, stop_timesteps, model_kwargs)
         with_grad = cond_fn_with_grad or pred_xstart_in_graph
+        if with_grad:
+            # the steps' inputs are cut from each other's graphs (x.detach() in *_with_grad): native model calls on a single clip share
+            # one activation tape and ONE backward pass, and may run on a side stream (model/native_stack.ChainedCalls) -- the loop's
+            # set-up (x_T, q_sample of the init image) included, so that it is ordered with them; anything else is untouched
+            from ..model.native_stack import ChainedCalls
+            n = self.num_timesteps - skip_timesteps - (stop_timesteps if stop_timesteps is not None else 0)
+            with ChainedCalls(n, start_event=self.__dict__.get("_chain_start_event")):
+                device, img, indices = self._loop_setup(model, shape, noise, device, skip_timesteps, init_image, stop_timesteps, model_kwargs)
+                yield from self._grad_steps(ddim, model, img, indices, shape, device, progress, clip_denoised, model_kwargs, eta,
+                                            const_noise, pred_xstart_in_graph)
+            return
+        device, img, indices = self._loop_setup(model, shape, noise, device, skip_timesteps, init_image, stop_timesteps, model_kwargs)
         denoiser, cfg, _ = _unwrap(model)
         sampler = _eng.SAMPLER_DDIM if ddim else _eng.SAMPLER_DDPM
-        if (denoiser is not None and not with_grad and cond_fn is None and denoised_fn is None and not denoiser.training
+        if (denoiser is not None and cond_fn is None and denoised_fn is None and not denoiser.training
                 and self.model_mean_type == ModelMeanType.START_X):
             yield from self._engine_loop(sampler, denoiser, cfg, img, indices, clip_denoised, model_kwargs, const_noise, eta,
                                          progress, chunked, want_xstart)
-            return
-        if with_grad:
-            # the steps' inputs are cut from each other's graphs (x.detach() in *_with_grad): native model calls on a single clip share
-            # one activation tape and ONE backward pass (model/native_stack.ChainedCalls); anything else is untouched by the context
-            from ..model.native_stack import ChainedCalls
-            with ChainedCalls(len(indices)):
-                yield from self._grad_steps(ddim, model, img, indices, shape, device, progress, clip_denoised, model_kwargs, eta,
-                                            const_noise, pred_xstart_in_graph)
             return
         if progress:
             from tqdm.auto import tqdm
@@ -520,6 +523,12 @@ class GaussianDiffusion:
         if noise is None:
             noise = th.randn_like(x_content_start)       # drawn, unused afterwards (reference :1330)
         noise_t2m = th.rand_like(x_start)
+        # everything the chained x0-hat steps read (content clip, masks, the parameters) is ready HERE: their forward calls may run on
+        # a side stream beside the text-to-motion call and the motion encoder below (model/native_stack.ChainedCalls)
+        chain_start = None
+        if x_start.is_cuda:
+            chain_start = th.cuda.Event()
+            chain_start.record()
         x_t = self.q_sample(x_start, t, noise=noise_t2m, model_kwargs=model_t2m_kwargs)
         model_output = model(x_t, self._scale_timesteps(t), **model_t2m_kwargs)
         if semantic_guidance:
@@ -528,9 +537,13 @@ class GaussianDiffusion:
             sample_fn, skip_steps = self.ddim_sample_loop, int(skip_steps / 1000 * 20)
         else:
             sample_fn = self.p_sample_loop
-        sample = sample_fn(model, x_content_start.shape, clip_denoised=False, model_kwargs=model_kwargs,
-                           skip_timesteps=skip_steps, init_image=x_content_start, progress=True, dump_steps=None, noise=None,
-                           const_noise=False, cond_fn_with_grad=True, pred_xstart_in_graph=True, dump_all_xstart=True)
+        self.__dict__["_chain_start_event"] = chain_start
+        try:
+            sample = sample_fn(model, x_content_start.shape, clip_denoised=False, model_kwargs=model_kwargs,
+                               skip_timesteps=skip_steps, init_image=x_content_start, progress=True, dump_steps=None, noise=None,
+                               const_noise=False, cond_fn_with_grad=True, pred_xstart_in_graph=True, dump_all_xstart=True)
+        finally:
+            self.__dict__["_chain_start_event"] = None
         num_step = len(sample)
         sample = th.cat(sample, dim=0)
         if self.loss_type not in (LossType.MSE, LossType.RESCALED_MSE):

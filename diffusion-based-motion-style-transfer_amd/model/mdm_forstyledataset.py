@@ -108,19 +108,22 @@ class _EngineHost:
     """Mixin: lazily built native engines for a module that owns (or borrows) an MDM-shaped
     parameter set.  `_engine_sources()` -> (layer_prefix, prior_prefix, parameters to watch)."""
 
-    def mst_engine(self, rows, frames):
+    def mst_engine(self, rows, frames, slot=None):
+        """slot: None = the module's engine; a name = a SECOND engine instance with its own workspace and weight copies (the chained
+        single-clip calls of the fine-tune objective run on a side stream beside the 64-clip call: native_stack.ChainedCalls)."""
         dev = next(self.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("the native denoiser runs on the GPU only; call .to('cuda') (there is no CPU fallback)")
         cache = self.__dict__.setdefault("_mst_engines", {})
-        ent = cache.get(dev)
+        key = dev if slot is None else (dev, slot)
+        ent = cache.get(key)
         if ent is None or ent["rows"] < rows or ent["frames"] < frames:
             rows_cap = max(rows, ent["rows"] if ent else 0)
             frames_cap = max(frames, ent["frames"] if ent else 0)
             eng = _eng.DenoiserEngine(self.input_feats, frames_cap, rows_cap, num_layers=self.num_layers, device=dev,
                                       latent_dim=self.latent_dim, num_heads=self.num_heads, ff_size=self.ff_size,
                                       clip_dim=self.clip_dim)
-            ent = cache[dev] = {"eng": eng, "rows": rows_cap, "frames": frames_cap, "version": None}
+            ent = cache[key] = {"eng": eng, "rows": rows_cap, "frames": frames_cap, "version": None}
         src = self.__dict__.get("_mst_sources")          # (layer prefix, prior prefix, parameters to watch): built once;
         if src is None:                                  # Parameter objects survive .to() / load_state_dict / optimizer steps
             src = self.__dict__["_mst_sources"] = self._engine_sources()

@@ -157,6 +157,11 @@ def _CHAIN_ON():
     return os.environ.get("MST_CHAIN", "1") != "0"      # MST_CHAIN=0: every model call differentiates alone (A/B, tests)
 
 
+def _CHAIN_STREAM_ON():
+    import os
+    return os.environ.get("MST_CHAIN_STREAM", "1") != "0"      # MST_CHAIN_STREAM=0: the chain's forward calls stay on the caller's stream
+
+
 class ChainedCalls:
     """n single-clip model calls whose inputs are cut from each other's graphs -- the chained x0-hat steps of the fine-tune objective
     (reference gaussian_diffusion.py:1364-1378 / inpainting_gaussian_diffusion.py:96, :197: `x = x.detach()`).  Their forward passes
@@ -166,18 +171,40 @@ class ChainedCalls:
     The pass runs when the last of the n nodes has received its gradient, or at the end of the autograd pass with zeros for nodes
     that received none."""
     current = None
+    _side = {}
 
-    def __init__(self, n):
+    def __init__(self, n, start_event=None):
+        """start_event: a CUDA event recorded (on the caller's stream) where everything the chain reads was ready -- the chain's forward
+        calls then run on a SIDE stream behind that event, on a second engine instance, beside whatever the caller's stream has been
+        given since (the fine-tune objective: the 64-clip text-to-motion call and the frozen motion encoder, neither of which the
+        chain depends on; six launch-bound single-clip calls use a few CUs each).  The caller's stream waits for the side stream when
+        the block ends; the chain's ONE backward pass runs on the caller's stream (parameter gradients are accumulated in place: the
+        passes of one iteration stay ordered on one stream)."""
         self.n, self.k, self.reported, self.done = int(n), 0, 0, False
         self.tape = self.seed = self.dbuf = self.ctx0 = None
         self.key = None
+        self.start_event = start_event if _CHAIN_STREAM_ON() else None
+        self.main = self.side = self._sctx = None
 
     def __enter__(self):
         self.prev, ChainedCalls.current = ChainedCalls.current, self
+        if self.start_event is not None and torch.cuda.is_available():
+            dev = torch.cuda.current_device()
+            self.main = torch.cuda.current_stream(dev)
+            self.side = ChainedCalls._side.get(dev)
+            if self.side is None:
+                self.side = ChainedCalls._side[dev] = torch.cuda.Stream(dev)
+            self.side.wait_event(self.start_event)
+            self._sctx = torch.cuda.stream(self.side)
+            self._sctx.__enter__()
         return self
 
     def __exit__(self, *exc):
         ChainedCalls.current = self.prev
+        if self._sctx is not None:
+            self._sctx.__exit__(*exc)
+            self._sctx = None
+            self.main.wait_stream(self.side)               # what follows on the caller's stream reads the chain's outputs
         return False
 
     def accepts(self, key):
@@ -204,7 +231,16 @@ class ChainedCalls:
         tape, self.tape = self.tape, None
         try:
             views = _sink_views(ctx, True, self.dbuf.device)
-            ctx.eng.train_model_backward(tape, self.dbuf, ctx.p_drop, ctx.p_pe, self.seed, views, need_input_grad=False)
+            if self.main is not None:
+                # autograd runs this node on the side stream (its forward's); the pass itself belongs on the caller's stream, behind
+                # the gradients the side stream has just copied in and in line with the iteration's other backward passes
+                self.main.wait_stream(torch.cuda.current_stream(self.dbuf.device))
+                with torch.cuda.stream(self.main):
+                    ctx.eng.train_model_backward(tape, self.dbuf, ctx.p_drop, ctx.p_pe, self.seed, views, need_input_grad=False)
+                self.dbuf.record_stream(self.main)
+                tape.record_stream(self.main)
+            else:
+                ctx.eng.train_model_backward(tape, self.dbuf, ctx.p_drop, ctx.p_pe, self.seed, views, need_input_grad=False)
             _node_done(ctx, True)
         except BaseException:
             _abort_sink(ctx)
@@ -222,12 +258,15 @@ class DenoiserTrainFn(torch.autograd.Function):
     def forward(ctx, x, host, p_drop, p_pe, timesteps, text_emb, *params):
         B, F, one, T = x.shape
         chain = ChainedCalls.current if _CHAIN_ON() else None
-        eng = host.mst_engine(max(B, chain.n) if chain is not None else B, T)
+        if chain is not None and not (B == 1 and not ctx.needs_input_grad[0] and any(ctx.needs_input_grad[6:])):
+            chain = None
+        # (a chain on a side stream works on an engine instance of its own: workspace, text projection and weight copies)
+        eng = host.mst_engine(max(B, chain.n), T, slot="chain" if chain.side is not None else None) if chain is not None else host.mst_engine(B, T)
         eng.set_text(text_emb.detach())
         seed = _draw_seed(max(p_drop, p_pe))
         ctx.eng, ctx.p_drop, ctx.p_pe, ctx.host, ctx.params, ctx.chain = eng, p_drop, p_pe, host, params, None
         key = (id(eng), B, F, T, float(p_drop), float(p_pe))
-        if (chain is not None and B == 1 and not ctx.needs_input_grad[0] and any(ctx.needs_input_grad[6:]) and chain.accepts(key)):
+        if chain is not None and chain.accepts(key):
             if chain.k == 0:
                 chain.key, chain.seed, chain.tape = key, seed, eng.train_tape(chain.n, T + 1, zero=True)
                 _sink_of(host, params).open_nodes += 1          # the chain is ONE native backward call
