@@ -3,15 +3,24 @@
 /opt/skills/guides/MI355X_MICROARCH.md: both counters are in KiB; FETCH_SIZE under-counts wide coalesced reads 2x on gfx950."""
 import collections, csv, glob, json, sys
 
+# (kernel-name fragment, family): first match wins.  The fused step kernel (k_embed_out<.., KSN> with KSN != 0: output projection of step j +
+# pose embedding of step j + 1) is a family of its own; "embed_out_step" / "embed_in" are the two stand-alone kernels the bench's event-timed families are.
 FAMILIES = (("k_qkv_attention", "qkv_attention_fused"), ("k_layer_tail", "layer_tail_fused"), ("DEpiResidLNE", "ln_gemm"), ("DEpiBiasF16ILb1E", "ffn1_gelu_gemm"),
-            ("DEpiEmbedInE", "embed_in"), ("DEpiEmbedOut", "embed_out_step"))
+            ("k_embed_in", "embed_in"), ("k_embed_out", "embed_out_step"), ("DEpiEmbedInE", "embed_in"), ("DEpiEmbedOut", "embed_out_step"))
+def family_of(name):
+    for key, fam in FAMILIES:
+        if key in name:
+            if key == "k_embed_out" and "ELi0EEEv" not in name:
+                return "embed_step_fused"
+            return fam
+    return None
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sys.argv[1:]:
     for f in glob.glob(d + "/*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            for key, fam in FAMILIES:
-                if key in r["Kernel_Name"]:
-                    acc[fam][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            fam = family_of(r["Kernel_Name"])
+            if fam:
+                acc[fam][r["Counter_Name"]].append(float(r["Counter_Value"]))
 import os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import mst_amd  # noqa: E402,F401

@@ -5,7 +5,9 @@ rows = []
 for f in glob.glob(sys.argv[1] + "/*/*kernel_trace.csv"):
     rows += list(csv.DictReader(open(f)))
 def short(n):
-    for k, v in (("k_layer_tail", "tail"), ("k_qkv_attention", "attn"), ("DEpiEmbedIn", "embed_in"), ("DEpiEmbedOut", "embed_out"), ("k_frames_f16", "frames")):
+    if "k_embed_out" in n:
+        return "embed_out" if "ELi0EEEv" in n else "embed_step"        # embed_step: the output projection that also embeds the next step
+    for k, v in (("k_layer_tail", "tail"), ("k_qkv_attention", "attn"), ("k_embed_in", "embed_in"), ("DEpiEmbedIn", "embed_in"), ("DEpiEmbedOut", "embed_out"), ("k_frames_f16", "frames")):
         if k in n:
             return v
     return "other"
@@ -20,7 +22,7 @@ for q, ks in sorted(by_q.items()):
     for (s0, e0, n0, g0), (s1, e1, n1, g1) in zip(ks, ks[1:]):
         dur[(n0, g0)].append((e0 - s0) * 1e-3)
         gap[(n0, n1)].append((s1 - e0) * 1e-3)
-    steps = max(1, sum(1 for k in ks if k[2] == "embed_out"))
+    steps = max(1, sum(1 for k in ks if k[2] in ("embed_out", "embed_step")))
     print(f"queue {q}: {len(ks)} kernels, {steps} steps, span {(ks[-1][1] - ks[0][0]) * 1e-3 / steps:.1f} us per step")
     tot_d = sum(sum(v) for v in dur.values()) / steps; tot_g = sum(sum(v) for v in gap.values()) / steps
     print(f"   per step: kernel durations {tot_d:.1f} us, gaps {tot_g:.1f} us")
