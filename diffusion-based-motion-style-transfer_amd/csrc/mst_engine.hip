@@ -25,6 +25,7 @@ __device__ unsigned long long g_emb_stamp[512][8][8];
 extern "C" int mst_probe_read(void* dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_emb_stamp), sizeof(g_emb_stamp)) == hipSuccess ? 0 : 1; }
 #endif
 #include "mst_embed.h"
+#include "mst_small.h"
 
 using namespace mst;
 
@@ -130,6 +131,8 @@ struct LayerW {
     f16 *w_in_lo = nullptr, *w_out_lo = nullptr, *w1_lo = nullptr, *w2_lo = nullptr;   // f16(w - f16(w)): the weights' lo halves (precise mode)
     bool tail_dirty = true, qkv_dirty = true;   // wtail / wqkv are older than w_out | w1 | w2 / w_in: repacked by ensure_packed() before the next sampling launch
     f16* wqkv = nullptr;            // W_in as the fused QKV+attention kernel's per-(head, wave) fragment streams (mst_attn.h, k_pack_qkv)
+    f16 *wsm_in = nullptr, *wsm_out = nullptr, *wsm_1 = nullptr, *wsm_2 = nullptr;   // the four matrices as [16-row block][k-step] fragments: the small-launch GEMMs (mst_small.h)
+    bool small_dirty = true;        // ... older than the plain matrices: repacked by the first small launch that follows an upload
 };
 
 // engine-owned scratch of the backward pass, allocated on the first training call
@@ -168,6 +171,7 @@ struct mst_engine {
     float *b_pose_in = nullptr, *b_pose_out = nullptr;
     f16 *w_pose_in_pk = nullptr, *w_pose_out_pk = nullptr;      // the two projections as per-wave fragment streams (mst_embed.h, k_pack_wave_blocks)
     bool pose_in_dirty = true, pose_out_dirty = true;          // ... older than w_pose_in / w_pose_out: repacked by ensure_packed()
+    int small_fast = 1;                   // small launches: the layer GEMMs as the kernels of mst_small.h (MST_SMALL_FAST=0: the slab ring)
     int fuse_embed = 1;                   // a sampling step's output projection also embeds the next step (MST_FUSE_EMBED=0: two launches)
     int embed_fast = 1;                   // K3 / K9 as the latency kernels of mst_embed.h; MST_EMBED_FAST=0: the ring GEMMs of rounds 1-3
     float *w_t0 = nullptr, *b_t0 = nullptr, *w_t2 = nullptr, *b_t2 = nullptr, *w_text = nullptr, *b_text = nullptr;
@@ -306,6 +310,10 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
         CHECK(dmalloc(&w.w2T, (size_t)MST_D * MST_FF));
         CHECK(dmalloc(&w.wtail, TailCfg::LAYER_BYTES / 2));
         CHECK(dmalloc(&w.wqkv, (size_t)3 * MST_D * MST_D));
+        CHECK(dmalloc(&w.wsm_in, (size_t)3 * MST_D * MST_D));
+        CHECK(dmalloc(&w.wsm_out, (size_t)MST_D * MST_D));
+        CHECK(dmalloc(&w.wsm_1, (size_t)MST_FF * MST_D));
+        CHECK(dmalloc(&w.wsm_2, (size_t)MST_D * MST_FF));
         CHECK(dmalloc(&w.w_in_lo, (size_t)3 * MST_D * MST_D));
         CHECK(dmalloc(&w.w_out_lo, (size_t)MST_D * MST_D));
         CHECK(dmalloc(&w.w1_lo, (size_t)MST_FF * MST_D));
@@ -366,6 +374,7 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     if (const char* v = getenv("MST_FUSE_FRAMES")) e->fuse_frames = atoi(v) != 0;
     if (const char* v = getenv("MST_EMBED_FAST")) e->embed_fast = atoi(v) != 0;
     if (const char* v = getenv("MST_FUSE_EMBED")) e->fuse_embed = atoi(v) != 0;
+    if (const char* v = getenv("MST_SMALL_FAST")) e->small_fast = atoi(v) != 0;
     if (const char* v = getenv("MST_TAIL_NTB")) { int n = atoi(v); e->tail_ntb = (n >= 2 && n <= 4) ? n : 0; }
     if (const char* v = getenv("MST_WGRAD_STREAM")) e->wgrad_stream_on = atoi(v) != 0;
     if (const char* v = getenv("MST_SMALL_M")) e->small_m = atoi(v);
@@ -390,7 +399,7 @@ extern "C" void mst_engine_destroy(mst_engine* e) {
     for (int l = 0; l < e->cfg.num_layers; l++) {
         LayerW& w = e->L[l];
         void* p[] = {w.w_in, w.w_out, w.w1, w.w2, w.b_in, w.b_out, w.b1, w.b2, w.g1, w.be1, w.g2, w.be2,
-                     w.w_inT, w.w_outT, w.w1T, w.w2T, w.wtail, w.wqkv, w.w_in_lo, w.w_out_lo, w.w1_lo, w.w2_lo};
+                     w.w_inT, w.w_outT, w.w1T, w.w2T, w.wtail, w.wqkv, w.w_in_lo, w.w_out_lo, w.w1_lo, w.w2_lo, w.wsm_in, w.wsm_out, w.wsm_1, w.wsm_2};
         for (void* q : p) (void)hipFree(q);
     }
     {
@@ -481,6 +490,7 @@ extern "C" int mst_load_weight(mst_engine* e, const char* name, const float* src
         // follows (ensure_packed): a fine-tune iteration re-uploads all 96 tensors and its training node reads the plain matrices.
         if (rc == 0 && r == "self_attn.in_proj_weight") w.qkv_dirty = true;
         if (rc == 0 && repack) w.tail_dirty = true;
+        if (rc == 0 && is_gemm_w) w.small_dirty = true;
         if (rc == 0 && is_gemm_w) { if (e->precise) e->lo_missing.erase(n); else e->lo_missing.insert(n); }
     } else if (n == "input_process.poseEmbedding.weight") {
         if (!shape_is(shape, ndim, MST_D, F)) return fail("mst_load_weight: %s: bad shape", name);
@@ -560,7 +570,7 @@ extern "C" int mst_load_layers(mst_engine* e, const float* const* srcs, void* st
         HIPCHECK(hipGetLastError());
     }
     for (int l = 0; l < nl; l++) {
-        e->L[l].qkv_dirty = e->L[l].tail_dirty = true;
+        e->L[l].qkv_dirty = e->L[l].tail_dirty = e->L[l].small_dirty = true;
         for (int k = 0; k < 12; k++) {
             char name[160];
             snprintf(name, sizeof(name), "seqTransEncoder.layers.%d.%s", l, kNames[k]);
@@ -679,6 +689,15 @@ static int launch_small(int M, int N, const SRC& xs, const f16* W, int ldw, int 
     return launch_gemm_dma<64, 128, 1, 1, 3, 1, 64>(dim3((M + 63) / 64, N / 128), xs, W, ldw, K, epi, st, 0);
 }
 
+// The small-launch GEMMs of mst_small.h: 64 x 128 tiles, the token tile resident in LDS, the weights streamed as fragments.
+template <int KS, int MODE>
+static int launch_rows_gemm(int M, int N, const f16* X, const f16* wpk, const float* bias, void* out, int ldo, hipStream_t st) {
+    constexpr int smem = 64 * (KS / 16) * 1024;
+    CHECK(ensure_dyn_lds((const void*)k_rows_gemm<KS, MODE>, smem));
+    hipLaunchKernelGGL((k_rows_gemm<KS, MODE>), dim3((M + 63) / 64, N / 128), dim3(512), smem, st, X, wpk, bias, out, ldo, M);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
 template <int NKT>
 static int launch_attn_n(const f16* qkv, f16* out, int S, int rows, hipStream_t st, int qsplit, f16* out_lo) {
     auto kern = k_attention<NKT>;
@@ -798,6 +817,19 @@ static WS ws_slice(const mst_engine* e, int r0, int T) {
 static int embed_out_nbw(const mst_engine* e) { return (e->cfg.feats + 127) / 128; }     // 16-feature blocks per wave of k_embed_out
 // (layers = false: the training node's model calls -- they run the two projections' fast kernels but read the layers' plain matrices,
 // and every fine-tune iteration re-uploads those: their packed copies are made only when a sampling launch follows)
+// (on the stream every slice of a loop forks from: mst_sample_loop packs before the fork, so no slice reads fragments another stream is still writing)
+static int ensure_small_packed(mst_engine* e, int l, hipStream_t st) {
+    LayerW& w = e->L[l];
+    if (!w.small_dirty) return 0;
+    hipLaunchKernelGGL(k_pack_blocks, dim3(192), dim3(256), 0, st, w.w_in, MST_D, 3 * MST_D, MST_D, w.wsm_in);
+    hipLaunchKernelGGL(k_pack_blocks, dim3(64), dim3(256), 0, st, w.w_out, MST_D, MST_D, MST_D, w.wsm_out);
+    hipLaunchKernelGGL(k_pack_blocks, dim3(128), dim3(256), 0, st, w.w1, MST_D, MST_FF, MST_D, w.wsm_1);
+    hipLaunchKernelGGL(k_pack_blocks, dim3(128), dim3(256), 0, st, w.w2, MST_FF, MST_D, MST_FF, w.wsm_2);
+    HIPCHECK(hipGetLastError());
+    w.small_dirty = false;
+    return 0;
+}
+
 static int ensure_packed(mst_engine* e, hipStream_t st, bool layers = true) {
     if (e->pose_in_dirty) {
         hipLaunchKernelGGL(k_pack_wave_blocks, dim3(256), dim3(256), 0, st, e->w_pose_in, e->kin_pad, MST_D, e->kin_pad / 32, 4, e->w_pose_in_pk);
@@ -822,6 +854,7 @@ static int ensure_packed(mst_engine* e, hipStream_t st, bool layers = true) {
             HIPCHECK(hipGetLastError());
             w.tail_dirty = false;
         }
+        if (e->small_fast && e->small_m > 0) CHECK(ensure_small_packed(e, l, st));
     }
     return 0;
 }
@@ -928,12 +961,17 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
     f16* const att_lo = precise ? ws.hid : nullptr;
     f16* const hid_lo = precise ? ws.qkv : nullptr;
     const f16* const hl_in = precise ? ws.hl : nullptr;
+    // round 4: without split operands the four GEMMs run as resident-tile / streamed-weight kernels (mst_small.h; MST_SMALL_FAST=0: the ring)
+    const bool fast = small && !precise && e->small_fast;
     for (int l = 0; small && l < e->cfg.num_layers; l++) {
         const LayerW& w = e->L[l];
         {
             ProfScope ps(e, FAM_QKV, st);
+            if (fast) CHECK((launch_rows_gemm<16, 0>(M, 3 * MST_D, ws.hx, w.wsm_in, w.b_in, ws.qkv, 3 * MST_D, st)));
+            else {
             DEpiBiasF16<false> epi{w.b_in, ws.qkv, 3 * MST_D, M};
             CHECK(launch_small(M, 3 * MST_D, RowsDirect{ws.hx, MST_D, hl_in, e->precise ? w.w_in_lo : nullptr}, w.w_in, MST_D, MST_D, epi, st));
+            }
         }
         DBG_STOP(1)
         {
@@ -943,22 +981,31 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
         DBG_STOP(2)
         {
             ProfScope ps(e, FAM_OUTPROJ_LN, st);
+            if (fast) CHECK((launch_rows_gemm<16, 2>(M, MST_D, ws.att, w.wsm_out, nullptr, ws.zacc, MST_D, st)));
+            else {
             DEpiPlainF32 epi{ws.zacc, MST_D, M};
             CHECK(launch_small(M, MST_D, RowsDirect{ws.att, MST_D, att_lo, e->precise ? w.w_out_lo : nullptr}, w.w_out, MST_D, MST_D, epi, st));
+            }
             hipLaunchKernelGGL(k_ln_rows, dim3((M + 3) / 4), dim3(256), 0, st, ws.zacc, w.b_out, w.g1, w.be1, ws.hx, ws.hl, M);
             HIPCHECK(hipGetLastError());
         }
         DBG_STOP(3)
         {
             ProfScope ps(e, FAM_FFN1, st);
+            if (fast) CHECK((launch_rows_gemm<16, 1>(M, MST_FF, ws.hx, w.wsm_1, w.b1, ws.hid, MST_FF, st)));
+            else {
             DEpiBiasF16<true> epi{w.b1, ws.hid, MST_FF, M, hid_lo};
             CHECK(launch_small(M, MST_FF, RowsDirect{ws.hx, MST_D, hl_in, e->precise ? w.w1_lo : nullptr}, w.w1, MST_D, MST_D, epi, st));
+            }
         }
         DBG_STOP(4)
         {
             ProfScope ps(e, FAM_FFN2_LN, st);
+            if (fast) CHECK((launch_rows_gemm<32, 2>(M, MST_D, ws.hid, w.wsm_2, nullptr, ws.zacc, MST_D, st)));
+            else {
             DEpiPlainF32 epi{ws.zacc, MST_D, M};
             CHECK(launch_small(M, MST_D, RowsDirect{ws.hid, MST_FF, hid_lo, e->precise ? w.w2_lo : nullptr}, w.w2, MST_FF, MST_FF, epi, st));
+            }
             hipLaunchKernelGGL(k_ln_rows, dim3((M + 3) / 4), dim3(256), 0, st, ws.zacc, w.b2, w.g2, w.be2, ws.hx, ws.hl, M);
             HIPCHECK(hipGetLastError());
         }
@@ -1286,7 +1333,7 @@ extern "C" int mst_sample_loop(mst_engine* e, const mst_schedule* s, const mst_l
     std::vector<long long> key = {a->batch, a->frames, a->cfg, a->sampler, a->noise_mode, a->mask_noise, a->clip_denoised,
                                   a->inpainting_mask_dev != nullptr, a->inpainted_motion_dev != nullptr, a->xstart_dump_dev != nullptr,
                                   a->scale_dev != nullptr, p.nsl, U, (long long)(size_t)s->tab, s->n, e->small_m, e->fuse_tail,
-                                  e->fuse_qkv_attn, e->ln128_min_m, e->precise, e->tail_ntb, e->embed_fast};      // every switch run_trunk / loop_slices_for branch on
+                                  e->fuse_qkv_attn, e->ln128_min_m, e->precise, e->tail_ntb, e->embed_fast, e->small_fast};      // every switch run_trunk / loop_slices_for branch on
     const bool use_graph = e->graph_on && !e->prof_on && e->dbg_stage < 0 && nrun >= 2 * U;
     bool forked = false;
     auto steps = [&]() -> int {

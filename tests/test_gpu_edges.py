@@ -215,6 +215,37 @@ def test_chained_frame_rows_equal_the_transpose_kernel(monkeypatch):
     assert torch.equal(outs[0][0][:, :3], motion[:, :3])
 
 
+def test_small_launch_gemms_resident_tile_equals_slab_ring(monkeypatch):
+    """A clip or two (<= MST_SMALL_M stream rows) runs the four layer GEMMs as k_rows_gemm (mst_small.h: token tile resident in
+    LDS, weights streamed as fragments); MST_SMALL_FAST=0 keeps the round-1..3 slab ring.  Same f16 operands and fp32 accumulation,
+    another order of the k sum: the two agree far inside the 1e-3 bar, forward and through a loop, and re-uploaded weights reach the
+    packed fragments (weights of another seed -> another result, equal to the ring's again)."""
+    from mst_amd.engine import DenoiserEngine, Schedule, SAMPLER_DDPM
+    from oracle import denoiser, schedule
+    F, T, B = 181, 76, 2
+    shape = (B, F, 1, T)
+    x, txt, t = syn.normal(SEED, "xs", shape), syn.normal(SEED, "ts", (B, 512)), np.array([3, 977])
+    tab, tmap = schedule.make("cosine", 1000, "100")
+    sch = Schedule(tab, tmap, dev())
+    fast, w, pe = make(F, T, B)
+    monkeypatch.setenv("MST_SMALL_FAST", "0")
+    ring, _, _ = make(F, T, B)
+    res = []
+    for eng in (fast, ring):
+        eng.set_text(cu(txt))
+        res.append((eng.forward(cu(x), cu(t)).cpu().numpy(), eng.sample_loop(sch, cu(x), 99, 90, SAMPLER_DDPM, seed=4).cpu().numpy()))
+    e_f, e_l = rel_l2(res[0][0], res[1][0]), rel_l2(res[0][1], res[1][1])
+    e_o = rel_l2(res[0][0], denoiser.forward(w, pe, x, t, txt).numpy())
+    print(f"resident tile vs ring: forward {e_f:.2e}, 10-step loop {e_l:.2e}; vs oracle {e_o:.2e}")
+    assert e_f < 1e-4 and e_l < 2e-4 and e_o < TOL
+    w2 = syn.denoiser_state(SEED + 1, F)
+    for eng in (fast, ring):
+        eng.load_state_dict({k: torch.from_numpy(v) for k, v in w2.items()}, pe=torch.from_numpy(pe))
+        eng.set_text(cu(txt))
+    o_f, o_r = fast.forward(cu(x), cu(t)).cpu().numpy(), ring.forward(cu(x), cu(t)).cpu().numpy()
+    assert rel_l2(o_f, o_r) < 1e-4 and rel_l2(o_f, res[0][0]) > 1e-2
+
+
 def test_argument_errors_surface_as_exceptions():
     from mst_amd.engine import DenoiserEngine, Schedule
     from oracle import schedule
