@@ -132,7 +132,10 @@ __global__ __launch_bounds__(256) void k_rowwise_linear(const float* __restrict_
 // 64 x 128 tiles + DEpiPlainF32) -- the fused whole-row epilogue would leave all but 4 CUs idle at one clip.
 __global__ __launch_bounds__(256) void k_ln_rows(const float* __restrict__ acc, const float* __restrict__ bias,
                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                 f16* __restrict__ hi, f16* __restrict__ lo, int M) {
+                                                 f16* hi, f16* lo, int M, f16* ohi = nullptr, f16* olo = nullptr) {
+    // (ohi, olo): the normalised rows go there instead of over the residual (the last LayerNorm of a stack whose other LayerNorms ran
+    // inside the GEMM behind them, mst_small.h: its residual sits in the second stream buffer, its consumer reads the first)
+    if (!ohi) { ohi = hi; olo = lo; }
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const int fa = lane * 4, fb = 256 + lane * 4;
@@ -171,11 +174,11 @@ __global__ __launch_bounds__(256) void k_ln_rows(const float* __restrict__ acc, 
     }
     uint2 h, l;
     split4_f16(ya, h, l);
-    *reinterpret_cast<uint2*>(hi + off + fa) = h;
-    *reinterpret_cast<uint2*>(lo + off + fa) = l;
+    *reinterpret_cast<uint2*>(ohi + off + fa) = h;
+    *reinterpret_cast<uint2*>(olo + off + fa) = l;
     split4_f16(yb, h, l);
-    *reinterpret_cast<uint2*>(hi + off + fb) = h;
-    *reinterpret_cast<uint2*>(lo + off + fb) = l;
+    *reinterpret_cast<uint2*>(ohi + off + fb) = h;
+    *reinterpret_cast<uint2*>(olo + off + fb) = l;
 }
 
 // debug / tests: the stream as float32

@@ -171,6 +171,7 @@ struct mst_engine {
     float *b_pose_in = nullptr, *b_pose_out = nullptr;
     f16 *w_pose_in_pk = nullptr, *w_pose_out_pk = nullptr;      // the two projections as per-wave fragment streams (mst_embed.h, k_pack_wave_blocks)
     bool pose_in_dirty = true, pose_out_dirty = true;          // ... older than w_pose_in / w_pose_out: repacked by ensure_packed()
+    int small_ln = 1, small_ln_m = 512;   // ... with the LayerNorms inside the consuming GEMMs, up to this many stream rows (MST_SMALL_LN, MST_SMALL_LN_M; tools/r4_small_sweep.sh: ahead through 2 clips x 197 rows, behind from 4)
     int small_fast = 1;                   // small launches: the layer GEMMs as the kernels of mst_small.h (MST_SMALL_FAST=0: the slab ring)
     int fuse_embed = 1;                   // a sampling step's output projection also embeds the next step (MST_FUSE_EMBED=0: two launches)
     int embed_fast = 1;                   // K3 / K9 as the latency kernels of mst_embed.h; MST_EMBED_FAST=0: the ring GEMMs of rounds 1-3
@@ -178,6 +179,7 @@ struct mst_engine {
     float* pe = nullptr;
     // workspace
     f16* hl = nullptr;        // lo half of the stream (hx is the hi half)
+    f16 *hx2 = nullptr, *hl2 = nullptr;   // second stream buffer: small launches with the LayerNorms inside the GEMMs (mst_small.h, LnRows)
     f16 *hx = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr, *xt = nullptr;
     float* gelu_tab = nullptr;      // Phi(x) interpolation table of the fused layer tail's GELU stage (TailCfg::GELU_N entries {Phi, dPhi})
     f16* xt_lo = nullptr;     // lo half of the frame rows: the pose embedding multiplies x_t as hi + lo (RowsDirect::Xlo)
@@ -338,6 +340,8 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     CHECK(dmalloc(&e->pe, (size_t)c->pe_len * MST_D));
     CHECK(dmalloc(&e->hl, (size_t)e->M_pad * MST_D));
     CHECK(dmalloc(&e->hx, (size_t)e->M_pad * MST_D));
+    CHECK(dmalloc(&e->hx2, (size_t)e->M_pad * MST_D));
+    CHECK(dmalloc(&e->hl2, (size_t)e->M_pad * MST_D));
     CHECK(dmalloc(&e->qkv, (size_t)e->M_pad * 3 * MST_D));
     CHECK(dmalloc(&e->att, (size_t)e->M_pad * MST_D));
     CHECK(dmalloc(&e->hid, (size_t)e->M_pad * MST_FF));
@@ -375,6 +379,8 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     if (const char* v = getenv("MST_EMBED_FAST")) e->embed_fast = atoi(v) != 0;
     if (const char* v = getenv("MST_FUSE_EMBED")) e->fuse_embed = atoi(v) != 0;
     if (const char* v = getenv("MST_SMALL_FAST")) e->small_fast = atoi(v) != 0;
+    if (const char* v = getenv("MST_SMALL_LN")) e->small_ln = atoi(v) != 0;
+    if (const char* v = getenv("MST_SMALL_LN_M")) e->small_ln_m = atoi(v);
     if (const char* v = getenv("MST_TAIL_NTB")) { int n = atoi(v); e->tail_ntb = (n >= 2 && n <= 4) ? n : 0; }
     if (const char* v = getenv("MST_WGRAD_STREAM")) e->wgrad_stream_on = atoi(v) != 0;
     if (const char* v = getenv("MST_SMALL_M")) e->small_m = atoi(v);
@@ -412,7 +418,7 @@ extern "C" void mst_engine_destroy(mst_engine* e) {
         for (void* q : p) (void)hipFree(q);
     }
     void* p[] = {e->w_pose_in_pk, e->w_pose_out_pk, e->w_pose_in_lo, e->w_pose_out_lo, e->w_pose_in, e->b_pose_in, e->w_pose_out, e->b_pose_out, e->w_pose_inT, e->w_pose_outT, e->w_t0, e->b_t0, e->w_t2, e->b_t2,
-                 e->w_text, e->b_text, e->pe, e->hl, e->hx, e->qkv, e->att, e->hid, e->xt, e->xt_lo, e->gelu_tab, e->temb_hid, e->temb, e->textproj, e->zacc};
+                 e->w_text, e->b_text, e->pe, e->hl, e->hx, e->hx2, e->hl2, e->qkv, e->att, e->hid, e->xt, e->xt_lo, e->gelu_tab, e->temb_hid, e->temb, e->textproj, e->zacc};
     for (void* q : p) (void)hipFree(q);
     for (int i = 0; i < mst_engine::MAX_SLICES - 1; i++) {
         if (e->aux_stream[i]) (void)hipStreamDestroy(e->aux_stream[i]);
@@ -691,10 +697,17 @@ static int launch_small(int M, int N, const SRC& xs, const f16* W, int ldw, int 
 
 // The small-launch GEMMs of mst_small.h: 64 x 128 tiles, the token tile resident in LDS, the weights streamed as fragments.
 template <int KS, int MODE>
-static int launch_rows_gemm(int M, int N, const f16* X, const f16* wpk, const float* bias, void* out, int ldo, hipStream_t st) {
+static int launch_rows_gemm(int M, int N, const f16* X, const f16* wpk, const float* bias, void* out, int ldo, hipStream_t st, const LnRows* ln = nullptr) {
     constexpr int smem = 64 * (KS / 16) * 1024;
+    if constexpr (KS == 16 && MODE != 2) {
+        if (ln) {                                                  // 16-token tiles (mst_small.h)
+            hipLaunchKernelGGL((k_rows_gemm<KS, MODE, 1, 1>), dim3((M + 15) / 16, N / 128), dim3(512), 16 * 1024, st, X, wpk, bias, out, ldo, M, *ln);
+            HIPCHECK(hipGetLastError());
+            return 0;
+        }
+    }
     CHECK(ensure_dyn_lds((const void*)k_rows_gemm<KS, MODE>, smem));
-    hipLaunchKernelGGL((k_rows_gemm<KS, MODE>), dim3((M + 63) / 64, N / 128), dim3(512), smem, st, X, wpk, bias, out, ldo, M);
+    hipLaunchKernelGGL((k_rows_gemm<KS, MODE>), dim3((M + 63) / 64, N / 128), dim3(512), smem, st, X, wpk, bias, out, ldo, M, LnRows{});
     HIPCHECK(hipGetLastError());
     return 0;
 }
@@ -803,13 +816,13 @@ extern "C" int mst_set_text(mst_engine* e, const float* text_emb, const float* k
 // A slice of the workspace: clips [r0, r0 + n) of the batch get their own rows of every buffer, so slices can
 // run concurrently on different streams (tiles may over-READ into a neighbour's rows; they never write them).
 struct WS {
-    f16 *hl, *hx, *qkv, *att, *hid, *xt; float* textproj; float* zacc; f16* xt_lo;
+    f16 *hl, *hx, *qkv, *att, *hid, *xt; float* textproj; float* zacc; f16* xt_lo; f16 *hx2, *hl2;
 };
 static WS ws_slice(const mst_engine* e, int r0, int T) {
     const size_t row = (size_t)r0 * (T + 1);
     return WS{e->hl + row * MST_D, e->hx + row * MST_D, e->qkv + row * 3 * MST_D, e->att + row * MST_D, e->hid + row * MST_FF,
               e->xt + (size_t)r0 * T * e->kin_pad, e->textproj + (size_t)r0 * MST_D, e->zacc + row * MST_D,
-              e->xt_lo + (size_t)r0 * T * e->kin_pad};
+              e->xt_lo + (size_t)r0 * T * e->kin_pad, e->hx2 + row * MST_D, e->hl2 + row * MST_D};
 }
 
 // Packed weight copies of the two fused kernels, refreshed where stale: on the stream the sampling launch is about to use (the caller
@@ -963,11 +976,19 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
     const f16* const hl_in = precise ? ws.hl : nullptr;
     // round 4: without split operands the four GEMMs run as resident-tile / streamed-weight kernels (mst_small.h; MST_SMALL_FAST=0: the ring)
     const bool fast = small && !precise && e->small_fast;
-    for (int l = 0; small && l < e->cfg.num_layers; l++) {
+    // ... and the LayerNorms inside the GEMM behind them (LnRows): LN1 in FFN1, which leaves the stream in (hx2, hl2); LN2 in the next
+    // layer's QKV GEMM, which brings it back to (hx, hl); the last LN2 as the rows kernel (MST_SMALL_LN=0: every LayerNorm a launch)
+    const bool lnf = fast && e->small_ln && e->dbg_stage < 0 && M <= e->small_ln_m;
+    const int NL = e->cfg.num_layers;
+    for (int l = 0; small && l < NL; l++) {
         const LayerW& w = e->L[l];
         {
             ProfScope ps(e, FAM_QKV, st);
-            if (fast) CHECK((launch_rows_gemm<16, 0>(M, 3 * MST_D, ws.hx, w.wsm_in, w.b_in, ws.qkv, 3 * MST_D, st)));
+            if (lnf && l > 0) {
+                const LayerW& p = e->L[l - 1];
+                const LnRows ln{ws.zacc, p.b2, p.g2, p.be2, ws.hx2, ws.hl2, ws.hx, ws.hl};
+                CHECK((launch_rows_gemm<16, 0>(M, 3 * MST_D, nullptr, w.wsm_in, w.b_in, ws.qkv, 3 * MST_D, st, &ln)));
+            } else if (fast) CHECK((launch_rows_gemm<16, 0>(M, 3 * MST_D, ws.hx, w.wsm_in, w.b_in, ws.qkv, 3 * MST_D, st)));
             else {
             DEpiBiasF16<false> epi{w.b_in, ws.qkv, 3 * MST_D, M};
             CHECK(launch_small(M, 3 * MST_D, RowsDirect{ws.hx, MST_D, hl_in, e->precise ? w.w_in_lo : nullptr}, w.w_in, MST_D, MST_D, epi, st));
@@ -986,13 +1007,16 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
             DEpiPlainF32 epi{ws.zacc, MST_D, M};
             CHECK(launch_small(M, MST_D, RowsDirect{ws.att, MST_D, att_lo, e->precise ? w.w_out_lo : nullptr}, w.w_out, MST_D, MST_D, epi, st));
             }
-            hipLaunchKernelGGL(k_ln_rows, dim3((M + 3) / 4), dim3(256), 0, st, ws.zacc, w.b_out, w.g1, w.be1, ws.hx, ws.hl, M);
+            if (!lnf) hipLaunchKernelGGL(k_ln_rows, dim3((M + 3) / 4), dim3(256), 0, st, ws.zacc, w.b_out, w.g1, w.be1, ws.hx, ws.hl, M, (f16*)nullptr, (f16*)nullptr);
             HIPCHECK(hipGetLastError());
         }
         DBG_STOP(3)
         {
             ProfScope ps(e, FAM_FFN1, st);
-            if (fast) CHECK((launch_rows_gemm<16, 1>(M, MST_FF, ws.hx, w.wsm_1, w.b1, ws.hid, MST_FF, st)));
+            if (lnf) {
+                const LnRows ln{ws.zacc, w.b_out, w.g1, w.be1, ws.hx, ws.hl, ws.hx2, ws.hl2};
+                CHECK((launch_rows_gemm<16, 1>(M, MST_FF, nullptr, w.wsm_1, w.b1, ws.hid, MST_FF, st, &ln)));
+            } else if (fast) CHECK((launch_rows_gemm<16, 1>(M, MST_FF, ws.hx, w.wsm_1, w.b1, ws.hid, MST_FF, st)));
             else {
             DEpiBiasF16<true> epi{w.b1, ws.hid, MST_FF, M, hid_lo};
             CHECK(launch_small(M, MST_FF, RowsDirect{ws.hx, MST_D, hl_in, e->precise ? w.w1_lo : nullptr}, w.w1, MST_D, MST_D, epi, st));
@@ -1006,7 +1030,8 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
             DEpiPlainF32 epi{ws.zacc, MST_D, M};
             CHECK(launch_small(M, MST_D, RowsDirect{ws.hid, MST_FF, hid_lo, e->precise ? w.w2_lo : nullptr}, w.w2, MST_FF, MST_FF, epi, st));
             }
-            hipLaunchKernelGGL(k_ln_rows, dim3((M + 3) / 4), dim3(256), 0, st, ws.zacc, w.b2, w.g2, w.be2, ws.hx, ws.hl, M);
+            if (!lnf) hipLaunchKernelGGL(k_ln_rows, dim3((M + 3) / 4), dim3(256), 0, st, ws.zacc, w.b2, w.g2, w.be2, ws.hx, ws.hl, M, (f16*)nullptr, (f16*)nullptr);
+            else if (l == NL - 1) hipLaunchKernelGGL(k_ln_rows, dim3((M + 3) / 4), dim3(256), 0, st, ws.zacc, w.b2, w.g2, w.be2, ws.hx2, ws.hl2, M, ws.hx, ws.hl);
             HIPCHECK(hipGetLastError());
         }
         DBG_STOP(5)
@@ -1333,7 +1358,7 @@ extern "C" int mst_sample_loop(mst_engine* e, const mst_schedule* s, const mst_l
     std::vector<long long> key = {a->batch, a->frames, a->cfg, a->sampler, a->noise_mode, a->mask_noise, a->clip_denoised,
                                   a->inpainting_mask_dev != nullptr, a->inpainted_motion_dev != nullptr, a->xstart_dump_dev != nullptr,
                                   a->scale_dev != nullptr, p.nsl, U, (long long)(size_t)s->tab, s->n, e->small_m, e->fuse_tail,
-                                  e->fuse_qkv_attn, e->ln128_min_m, e->precise, e->tail_ntb, e->embed_fast, e->small_fast};      // every switch run_trunk / loop_slices_for branch on
+                                  e->fuse_qkv_attn, e->ln128_min_m, e->precise, e->tail_ntb, e->embed_fast, e->small_fast, e->small_ln};      // every switch run_trunk / loop_slices_for branch on
     const bool use_graph = e->graph_on && !e->prof_on && e->dbg_stage < 0 && nrun >= 2 * U;
     bool forked = false;
     auto steps = [&]() -> int {

@@ -22,23 +22,38 @@ __global__ __launch_bounds__(256) void k_pack_blocks(const f16* __restrict__ W, 
     }
 }
 
+// LNF = 1: the token rows are not read but MADE: row = LayerNorm(acc + bias + residual) of the GEMM launch in front (k_ln_rows' arithmetic,
+// lane for lane: the same bits), so that the stream's LayerNorm needs no launch of its own between two GEMMs (16 launches of ~3 us plus
+// their boundaries per step at one clip).  Every workgroup of a token tile (N / 128 of them) normalises the tile's 64 rows for itself
+// -- 192 KB of L2 reads against a launch boundary -- and column 0 also writes the rows out as the stream's new (hi, lo) pair: into
+// ANOTHER buffer than the residual it reads, which the other columns are still reading.
+struct LnRows {
+    const float *acc, *bias, *gamma, *beta;     // fp32 GEMM result [M][512]; bias of that GEMM; LayerNorm weight, bias
+    const f16 *res_hi, *res_lo;                 // the residual stream in front of the GEMM
+    f16 *out_hi, *out_lo;                       // the stream behind the LayerNorm
+};
+
 // MODE 0: + bias -> f16 [M][ldo];  1: + bias, erf GELU -> f16;  2: fp32 [M][ldo] as it is (the LayerNorm behind it adds the bias).
 // KS = K / 32 (16 or 32).  LDS: token row r = KS / 16 pieces of 1 KB, 16-B chunk c of a piece at c ^ (r & 15).
-template <int KS, int MODE>
+// NTB: the tile is 16 NTB tokens high.  64 where the rows are read; 16 where they are made -- a workgroup's LayerNorm of 64 rows is
+// ~830 VALU instructions per lane on two waves per SIMD (2.9 us measured on top of the 2.9 us GEMM, more than the launch it replaces),
+// of 16 rows a quarter of that, and at the row counts this path serves (a clip or two) the extra workgroups find idle CUs.
+template <int KS, int MODE, int LNF = 0, int NTB = 4>
 __global__ __launch_bounds__(512) void k_rows_gemm(const f16* __restrict__ X, const f16* __restrict__ wpk, const float* __restrict__ bias,
-                                                   void* __restrict__ out, int ldo, int M) {
+                                                   void* __restrict__ out, int ldo, int M, LnRows ln = {}) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(KS == 16 || KS == 32, "K = 512 or 1024");
-    constexpr int NP = KS / 16, ROWB = NP * 1024, D = 8;
+    static_assert(!LNF || KS == 16, "a LayerNorm row is 512 wide");
+    constexpr int NP = KS / 16, ROWB = NP * 1024, D = 8, RPW = 2 * NTB, LB = RPW < 4 ? RPW : 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t16 = lane & 15, q4 = lane >> 4;
-    const int tok0 = blockIdx.x * 64;
+    const int tok0 = blockIdx.x * (16 * NTB);
     const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    // rows [8 w, 8 w + 8) of the tile: NP pieces each
+    // rows [RPW w, RPW w + RPW) of the tile: NP pieces each
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int r = 8 * wave + j;
+    for (int j = 0; j < (LNF ? 0 : RPW); j++) {
+        const int r = RPW * wave + j;
         int tok = tok0 + r;
         if (tok >= M) tok = M - 1;
 #pragma unroll
@@ -49,21 +64,88 @@ __global__ __launch_bounds__(512) void k_rows_gemm(const f16* __restrict__ X, co
     }
     const int blk = 8 * blockIdx.y + wave;                             // this wave's 16 output features
     const char* wsrc = reinterpret_cast<const char*>(wpk) + (size_t)blk * KS * 1024;
-    f32x4 acc[4];
+    f32x4 acc[NTB];
 #pragma unroll
-    for (int tb = 0; tb < 4; tb++) acc[tb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f16x8 xf[2][4];
+    for (int tb = 0; tb < NTB; tb++) acc[tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f16x8 xf[2][NTB];
     const unsigned xlane = (unsigned)t16 * ROWB, xswz = (unsigned)((q4 ^ t16) << 4);
     auto xread = [&](int k32, int p) {
         const char* src = smem + xlane + (unsigned)(k32 >> 4) * 1024u + (((unsigned)(k32 & 15) << 6) ^ xswz);
 #pragma unroll
-        for (int tb = 0; tb < 4; tb++) xf[p][tb] = *reinterpret_cast<const f16x8*>(src + tb * 16 * ROWB);
+        for (int tb = 0; tb < NTB; tb++) xf[p][tb] = *reinterpret_cast<const f16x8*>(src + tb * 16 * ROWB);
     };
     emb_stream<KS, D>(wsrc, (unsigned)lane * 16u,
         [&](auto jc) {
             constexpr int j = decltype(jc)::value;
             if constexpr (j == 0) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D) : "memory");      // the row pieces are older than the D fragments
+                if constexpr (LNF) {
+                    // (behind the first D weight fragments, which are in flight meanwhile; the compiler's own vmcnt waits for the
+                    // loads below can only be stricter for the older fragment loads being there)
+                    const int fa = lane * 4, fb = 256 + lane * 4;
+                    const f32x4 ba = *reinterpret_cast<const f32x4*>(ln.bias + fa), bb = *reinterpret_cast<const f32x4*>(ln.bias + fb);
+                    const f32x4 ga = *reinterpret_cast<const f32x4*>(ln.gamma + fa), gb = *reinterpret_cast<const f32x4*>(ln.gamma + fb);
+                    const f32x4 ea = *reinterpret_cast<const f32x4*>(ln.beta + fa), eb = *reinterpret_cast<const f32x4*>(ln.beta + fb);
+#pragma unroll
+                    for (int h = 0; h < RPW / LB; h++) {
+                        f32x4 xa[LB], xb[LB], ta[LB], tb[LB];
+#pragma unroll
+                        for (int i = 0; i < LB; i++) {
+                            int tok = tok0 + RPW * wave + LB * h + i;
+                            if (tok >= M) tok = M - 1;
+                            const size_t off = (size_t)tok * MST_D;
+                            xa[i] = join4_f16(*reinterpret_cast<const uint2*>(ln.res_hi + off + fa), *reinterpret_cast<const uint2*>(ln.res_lo + off + fa));
+                            xb[i] = join4_f16(*reinterpret_cast<const uint2*>(ln.res_hi + off + fb), *reinterpret_cast<const uint2*>(ln.res_lo + off + fb));
+                            ta[i] = *reinterpret_cast<const f32x4*>(ln.acc + off + fa);
+                            tb[i] = *reinterpret_cast<const f32x4*>(ln.acc + off + fb);
+                        }
+#pragma unroll
+                        for (int i = 0; i < LB; i++) {
+                            const int r = RPW * wave + LB * h + i, tok = tok0 + r;
+                            float sm = 0.f;
+#pragma unroll
+                            for (int c = 0; c < 4; c++) {
+                                xa[i][c] = ta[i][c] + ba[c] + xa[i][c];
+                                xb[i][c] = tb[i][c] + bb[c] + xb[i][c];
+                                sm += xa[i][c] + xb[i][c];
+                            }
+#pragma unroll
+                            for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+                            const float mean = sm * (1.0f / MST_D);
+                            float s2 = 0.f;
+#pragma unroll
+                            for (int c = 0; c < 4; c++) {
+                                xa[i][c] -= mean;
+                                xb[i][c] -= mean;
+                                s2 += xa[i][c] * xa[i][c] + xb[i][c] * xb[i][c];
+                            }
+#pragma unroll
+                            for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
+                            const float rstd = ln_rstd(s2);
+                            f32x4 ya, yb;
+#pragma unroll
+                            for (int c = 0; c < 4; c++) {
+                                ya[c] = xa[i][c] * rstd * ga[c] + ea[c];
+                                yb[c] = xb[i][c] * rstd * gb[c] + eb[c];
+                            }
+                            uint2 ha, la, hb, lb;
+                            split4_f16(ya, ha, la);
+                            split4_f16(yb, hb, lb);
+                            // features fa .. fa + 3 = bytes 8 lane .. of the row: chunk lane / 2 (fb: 32 + lane / 2), half (lane & 1)
+                            char* dst = smem + r * ROWB + (lane & 1) * 8;
+                            *reinterpret_cast<uint2*>(dst + (((lane >> 1) ^ (r & 15)) << 4)) = ha;
+                            *reinterpret_cast<uint2*>(dst + (((32 + (lane >> 1)) ^ (r & 15)) << 4)) = hb;
+                            if (blockIdx.y == 0 && tok < M) {
+                                const size_t off = (size_t)tok * MST_D;
+                                *reinterpret_cast<uint2*>(ln.out_hi + off + fa) = ha;
+                                *reinterpret_cast<uint2*>(ln.out_lo + off + fa) = la;
+                                *reinterpret_cast<uint2*>(ln.out_hi + off + fb) = hb;
+                                *reinterpret_cast<uint2*>(ln.out_lo + off + fb) = lb;
+                            }
+                        }
+                    }
+                } else {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D) : "memory");      // the row pieces are older than the D fragments
+                }
                 __syncthreads();
                 xread(0, 0);
             }
@@ -72,13 +154,13 @@ __global__ __launch_bounds__(512) void k_rows_gemm(const f16* __restrict__ X, co
         [&](auto jc, f16x8 wf) {
             constexpr int j = decltype(jc)::value;
 #pragma unroll
-            for (int tb = 0; tb < 4; tb++) acc[tb] = mfma16(wf, xf[j & 1][tb], acc[tb]);
+            for (int tb = 0; tb < NTB; tb++) acc[tb] = mfma16(wf, xf[j & 1][tb], acc[tb]);
         });
     const int f = 16 * blk + 4 * q4;
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (MODE != 2) bv = *reinterpret_cast<const f32x4*>(bias + f);
 #pragma unroll
-    for (int tb = 0; tb < 4; tb++) {
+    for (int tb = 0; tb < NTB; tb++) {
         const int tok = tok0 + 16 * tb + t16;
         if (tok >= M) continue;
         f32x4 v = acc[tb] + bv;
