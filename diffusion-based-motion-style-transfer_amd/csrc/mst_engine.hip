@@ -697,7 +697,8 @@ static int launch_small(int M, int N, const SRC& xs, const f16* W, int ldw, int 
 
 // The small-launch GEMMs of mst_small.h: 64 x 128 tiles, the token tile resident in LDS, the weights streamed as fragments.
 template <int KS, int MODE>
-static int launch_rows_gemm(int M, int N, const f16* X, const f16* wpk, const float* bias, void* out, int ldo, hipStream_t st, const LnRows* ln = nullptr) {
+static int launch_rows_gemm(int M, int N, const f16* X, const f16* wpk, const float* bias, void* out, int ldo, hipStream_t st, const LnRows* ln = nullptr,
+                            const FfnTrain* ft = nullptr) {
     constexpr int smem = 64 * (KS / 16) * 1024;
     if constexpr (KS == 16 && MODE != 2) {
         if (ln) {                                                  // 16-token tiles (mst_small.h)
@@ -707,7 +708,7 @@ static int launch_rows_gemm(int M, int N, const f16* X, const f16* wpk, const fl
         }
     }
     CHECK(ensure_dyn_lds((const void*)k_rows_gemm<KS, MODE>, smem));
-    hipLaunchKernelGGL((k_rows_gemm<KS, MODE>), dim3((M + 63) / 64, N / 128), dim3(512), smem, st, X, wpk, bias, out, ldo, M, LnRows{});
+    hipLaunchKernelGGL((k_rows_gemm<KS, MODE>), dim3((M + 63) / 64, N / 128), dim3(512), smem, st, X, wpk, bias, out, ldo, M, LnRows{}, ft ? *ft : FfnTrain{});
     HIPCHECK(hipGetLastError());
     return 0;
 }
@@ -786,7 +787,9 @@ static int launch_attn(const f16* qkv, f16* out, int S, int rows, hipStream_t st
 static int rowwise_linear(const float* in, int ldin, const long long* gather, const float* rowscale, int rows_zero_from,
                           const float* W, const float* b, int K, int N, int act, float* out, int in_row_mod, int rows,
                           hipStream_t st) {
-    hipLaunchKernelGGL(k_rowwise_linear, dim3(rows, 16), dim3(256), 0, st, in, ldin, gather, rowscale, rows_zero_from, W, b,
+    // a wave per output where the rows are few (64 rows x 128 = 8 K blocks; the hoisted timestep rows of a 1000-step loop keep 16 per row)
+    const int gy = rows <= 64 ? (N + 3) / 4 : 16;
+    hipLaunchKernelGGL(k_rowwise_linear, dim3(rows, gy), dim3(256), 0, st, in, ldin, gather, rowscale, rows_zero_from, W, b,
                        K, N, act, out, in_row_mod);
     HIPCHECK(hipGetLastError());
     return 0;
@@ -843,6 +846,26 @@ static int ensure_small_packed(mst_engine* e, int l, hipStream_t st) {
     return 0;
 }
 
+// every stale layer's four matrices in ONE launch (the fine-tune loop re-uploads all of them each iteration)
+static int ensure_small_packed_all(mst_engine* e, hipStream_t st) {
+    PackJobs jobs{};
+    int n = 0;
+    for (int l = 0; l < e->cfg.num_layers && l < 8; l++) {
+        LayerW& w = e->L[l];
+        if (!w.small_dirty) continue;
+        jobs.j[n++] = PackJob{w.w_in, w.wsm_in, MST_D, 3 * MST_D, MST_D, 0};
+        jobs.j[n++] = PackJob{w.w_out, w.wsm_out, MST_D, MST_D, MST_D, 0};
+        jobs.j[n++] = PackJob{w.w1, w.wsm_1, MST_D, MST_FF, MST_D, 0};
+        jobs.j[n++] = PackJob{w.w2, w.wsm_2, MST_FF, MST_D, MST_FF, 0};
+    }
+    if (n) {
+        hipLaunchKernelGGL(k_pack_blocks_multi, dim3(48, n), dim3(256), 0, st, jobs);
+        HIPCHECK(hipGetLastError());
+        for (int l = 0; l < e->cfg.num_layers && l < 8; l++) e->L[l].small_dirty = false;
+    }
+    for (int l = 8; l < e->cfg.num_layers; l++) CHECK(ensure_small_packed(e, l, st));
+    return 0;
+}
 static int ensure_packed(mst_engine* e, hipStream_t st, bool layers = true) {
     if (e->pose_in_dirty) {
         hipLaunchKernelGGL(k_pack_wave_blocks, dim3(256), dim3(256), 0, st, e->w_pose_in, e->kin_pad, MST_D, e->kin_pad / 32, 4, e->w_pose_in_pk);
@@ -867,8 +890,8 @@ static int ensure_packed(mst_engine* e, hipStream_t st, bool layers = true) {
             HIPCHECK(hipGetLastError());
             w.tail_dirty = false;
         }
-        if (e->small_fast && e->small_m > 0) CHECK(ensure_small_packed(e, l, st));
     }
+    if (e->small_fast && e->small_m > 0) CHECK(ensure_small_packed_all(e, st));
     return 0;
 }
 
@@ -1633,28 +1656,40 @@ static int train_stack_forward(mst_engine* e, const Tape& t, int rows, int S, fl
     const uint32_t o0 = (uint32_t)clip0 * MST_H * S * S, o1 = (uint32_t)clip0 * S * MST_D, o2 = (uint32_t)clip0 * S * MST_FF;
     e->prof_now = 0;
     const bool small = e->small_m > 0 && M <= e->small_m;
+    const bool fast = small && e->small_fast;            // the four GEMMs as resident-tile kernels (mst_small.h), as in the sampling path
+    if (fast) CHECK(ensure_small_packed_all(e, st));
     for (int l = 0; small && l < nl; l++) {              // few token rows: 64 x 128 tiles, row-wise LayerNorm, query-split attention
         const LayerW& w = e->L[l];
         const TapeL& a = t.L[l];
-        {
+        if (fast) CHECK((launch_rows_gemm<16, 0>(M, 3 * MST_D, t.sh[l], w.wsm_in, w.b_in, a.qkv, 3 * MST_D, st)));
+        else {
             DEpiBiasF16<false> epi{w.b_in, a.qkv, 3 * MST_D, M};
             CHECK(launch_small(M, 3 * MST_D, RowsDirect{t.sh[l], MST_D}, w.w_in, MST_D, MST_D, epi, st));
         }
         CHECK(launch_attn_train(a.qkv, a.att, S, rows, make_drop(seed, l, 0, p_drop, o0), key_keep, 1, a.lse, st));
         {
+            if (fast) CHECK((launch_rows_gemm<16, 2>(M, MST_D, a.att, w.wsm_out, nullptr, e->zacc, MST_D, st)));
+            else {
             DEpiPlainF32 epi{e->zacc, MST_D, M};
             CHECK(launch_small(M, MST_D, RowsDirect{a.att, MST_D}, w.w_out, MST_D, MST_D, epi, st));
+            }
             hipLaunchKernelGGL(k_ln_rows_train, dim3((M + 3) / 4), dim3(256), 0, st, e->zacc, w.b_out, w.g1, w.be1, t.sh[l], t.sl[l],
                                a.z1h, a.z1l, a.x1h, a.x1l, M, make_drop(seed, l, 1, p_drop, o1));
             HIPCHECK(hipGetLastError());
         }
-        {
+        if (fast) {
+            const FfnTrain ft{a.pre, make_drop(seed, l, 2, p_drop, o2)};
+            CHECK((launch_rows_gemm<16, 3>(M, MST_FF, a.x1h, w.wsm_1, w.b1, a.hid, MST_FF, st, nullptr, &ft)));
+        } else {
             DEpiRowOp<OpFfn1Train> epi{w.b1, M, OpFfn1Train{a.pre, a.hid, MST_FF, make_drop(seed, l, 2, p_drop, o2)}};
             CHECK(launch_small(M, MST_FF, RowsDirect{a.x1h, MST_D}, w.w1, MST_D, MST_D, epi, st));
         }
         {
+            if (fast) CHECK((launch_rows_gemm<32, 2>(M, MST_D, a.hid, w.wsm_2, nullptr, e->zacc, MST_D, st)));
+            else {
             DEpiPlainF32 epi{e->zacc, MST_D, M};
             CHECK(launch_small(M, MST_D, RowsDirect{a.hid, MST_FF}, w.w2, MST_FF, MST_FF, epi, st));
+            }
             hipLaunchKernelGGL(k_ln_rows_train, dim3((M + 3) / 4), dim3(256), 0, st, e->zacc, w.b2, w.g2, w.be2, a.x1h, a.x1l,
                                a.z2h, a.z2l, t.sh[l + 1], t.sl[l + 1], M, make_drop(seed, l, 3, p_drop, o1));
             HIPCHECK(hipGetLastError());
@@ -1753,7 +1788,7 @@ static int wgrad(mst_engine* e, const f16* dY, int n_out, const f16* X, int k_in
         DEpiF32 epi{nullptr, t.part, k_in, n_out};
         hipLaunchKernelGGL(kern, dim3(n_out / 128, k_in / 256, nsplit), dim3(512), WgTile::SMEM, st, dY, n_out, X, k_in, M, kchunk, nelem, epi);
         HIPCHECK(hipGetLastError());
-        hipLaunchKernelGGL(k_splitk_reduce, dim3(256), dim3(256), 0, st, t.part, nsplit, nelem, t.gscale, dW);
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((nelem / 4 + 255) / 256)), dim3(256), 0, st, t.part, nsplit, nelem, t.gscale, dW);
         HIPCHECK(hipGetLastError());
     }
     if (db) {

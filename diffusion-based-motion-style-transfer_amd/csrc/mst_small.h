@@ -10,6 +10,7 @@
 #pragma once
 #include "mst_common.h"
 #include "mst_embed.h"
+#include "mst_train.h"
 
 namespace mst {
 
@@ -33,6 +34,21 @@ struct LnRows {
     f16 *out_hi, *out_lo;                       // the stream behind the LayerNorm
 };
 
+// The same re-layout for up to 32 matrices in one launch (blockIdx.y = job): the training path re-uploads every layer each iteration.
+struct PackJob { const f16* W; f16* dst; int ldw, N, K, pad; };
+struct PackJobs { PackJob j[32]; };
+__global__ __launch_bounds__(256) void k_pack_blocks_multi(PackJobs jobs) {
+    const PackJob& jb = jobs.j[blockIdx.y];
+    const int KS = jb.K / 32, total = (jb.N / 16) * KS * 64;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int lane = i & 63, fi = i >> 6, k32 = fi % KS, b = fi / KS;
+        reinterpret_cast<uint4*>(jb.dst)[i] = *reinterpret_cast<const uint4*>(jb.W + (size_t)(16 * b + (lane & 15)) * jb.ldw + 32 * k32 + 8 * (lane >> 4));
+    }
+}
+
+// MODE 3 (training FFN1, OpFfn1Train's arithmetic): pre = f16(acc + bias) -> ft.pre, out = f16(gelu(pre) * dropout keep-multiplier)
+struct FfnTrain { f16* pre; Drop d; };
+
 // MODE 0: + bias -> f16 [M][ldo];  1: + bias, erf GELU -> f16;  2: fp32 [M][ldo] as it is (the LayerNorm behind it adds the bias).
 // KS = K / 32 (16 or 32).  LDS: token row r = KS / 16 pieces of 1 KB, 16-B chunk c of a piece at c ^ (r & 15).
 // NTB: the tile is 16 NTB tokens high.  64 where the rows are read; 16 where they are made -- a workgroup's LayerNorm of 64 rows is
@@ -40,7 +56,7 @@ struct LnRows {
 // of 16 rows a quarter of that, and at the row counts this path serves (a clip or two) the extra workgroups find idle CUs.
 template <int KS, int MODE, int LNF = 0, int NTB = 4>
 __global__ __launch_bounds__(512) void k_rows_gemm(const f16* __restrict__ X, const f16* __restrict__ wpk, const float* __restrict__ bias,
-                                                   void* __restrict__ out, int ldo, int M, LnRows ln = {}) {
+                                                   void* __restrict__ out, int ldo, int M, LnRows ln = {}, FfnTrain ft = {}) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(KS == 16 || KS == 32, "K = 512 or 1024");
     static_assert(!LNF || KS == 16, "a LayerNorm row is 512 wide");
@@ -164,6 +180,17 @@ __global__ __launch_bounds__(512) void k_rows_gemm(const f16* __restrict__ X, co
         const int tok = tok0 + 16 * tb + t16;
         if (tok >= M) continue;
         f32x4 v = acc[tb] + bv;
+        if constexpr (MODE == 3) {
+            const size_t o = (size_t)tok * ldo + f;
+            const uint2 pv = pack4_f16(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<uint2*>(ft.pre + o) = pv;
+            const f16x4 ph = __builtin_bit_cast(f16x4, pv);
+            float h[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) h[j] = gelu_erf((float)ph[j]) * drop_mul(ft.d, (uint32_t)o + j);
+            *reinterpret_cast<uint2*>(reinterpret_cast<f16*>(out) + o) = pack4_f16(h[0], h[1], h[2], h[3]);
+            continue;
+        }
         if (MODE == 1) v = f32x4{gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])};
         if (MODE == 2) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + (size_t)tok * ldo + f) = v;
         else *reinterpret_cast<uint2*>(reinterpret_cast<f16*>(out) + (size_t)tok * ldo + f) = pack4_f16(v[0], v[1], v[2], v[3]);
