@@ -126,6 +126,33 @@ __device__ __forceinline__ float erf_as(float x) {
 // LayerNorm in the engine (fused tail, GEMM epilogue, training rows) goes through here so the paths agree bit for bit.
 __device__ __forceinline__ float ln_rstd(float sum_sq) { return __builtin_amdgcn_rsqf(sum_sq * (1.0f / MST_D) + 1e-5f); }
 
+// LayerNorm of one 512-wide row held by a wave: lane l has features 4 l .. 4 l + 3 (xa) and 256 + 4 l .. + 3 (xb).  Every multiply-add
+// is spelled as an fma: under -ffp-contract=fast hipcc may fuse `a * a + b * b` either way round, and which way depends on the code
+// around it -- the rows kernel and the GEMM prologue that share this function (mst_elem.h k_ln_rows, mst_small.h) must agree bit for bit.
+__device__ __forceinline__ void ln_row_wave(f32x4& xa, f32x4& xb, const f32x4& ga, const f32x4& gb, const f32x4& ea, const f32x4& eb) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) s += xa[i] + xb[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s * (1.0f / MST_D);
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        xa[i] -= mean;
+        xb[i] -= mean;
+        s2 += __builtin_fmaf(xa[i], xa[i], xb[i] * xb[i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
+    const float rstd = ln_rstd(s2);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        xa[i] = __builtin_fmaf(xa[i] * rstd, ga[i], ea[i]);
+        xb[i] = __builtin_fmaf(xb[i] * rstd, gb[i], eb[i]);
+    }
+}
+
 // GELU(x) = x Phi(x) written as max(x, 0) - |x| E(|x|) with E(a) = erfc(a / sqrt 2) / 2 = (t P(t) / 2) exp(-a^2 / 2), t = 1 / (1 + p a / sqrt 2)
 // (the same Abramowitz-Stegun 7.1.26 polynomial as erf_as; 0.5 folded into its coefficients): 13 VALU ops instead of 18 -- no 1 + erf,
 // no sign transfer, exp2 taken directly -- and no cancellation for x < 0.  The layer tail spends ~7 us per 64-token tile in this

@@ -144,34 +144,15 @@ __global__ __launch_bounds__(256) void k_ln_rows(const float* __restrict__ acc, 
     f32x4 xb = join4_f16(*reinterpret_cast<const uint2*>(hi + off + fb), *reinterpret_cast<const uint2*>(lo + off + fb));
     const f32x4 ta = *reinterpret_cast<const f32x4*>(acc + off + fa), tb = *reinterpret_cast<const f32x4*>(acc + off + fb);
     const f32x4 ba = *reinterpret_cast<const f32x4*>(bias + fa), bb = *reinterpret_cast<const f32x4*>(bias + fb);
-    float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         xa[i] = ta[i] + ba[i] + xa[i];
         xb[i] = tb[i] + bb[i] + xb[i];
-        s += xa[i] + xb[i];
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    const float mean = s * (1.0f / MST_D);
-    float s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        xa[i] -= mean;
-        xb[i] -= mean;
-        s2 += xa[i] * xa[i] + xb[i] * xb[i];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
-    const float rstd = ln_rstd(s2);
     const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + fa), gb = *reinterpret_cast<const f32x4*>(gamma + fb);
     const f32x4 ea = *reinterpret_cast<const f32x4*>(beta + fa), eb = *reinterpret_cast<const f32x4*>(beta + fb);
-    f32x4 ya, yb;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        ya[i] = xa[i] * rstd * ga[i] + ea[i];
-        yb[i] = xb[i] * rstd * gb[i] + eb[i];
-    }
+    ln_row_wave(xa, xb, ga, gb, ea, eb);
+    const f32x4 ya = xa, yb = xb;
     uint2 h, l;
     split4_f16(ya, h, l);
     *reinterpret_cast<uint2*>(ohi + off + fa) = h;

@@ -117,32 +117,13 @@ __global__ __launch_bounds__(512) void k_rows_gemm(const f16* __restrict__ X, co
 #pragma unroll
                         for (int i = 0; i < LB; i++) {
                             const int r = RPW * wave + LB * h + i, tok = tok0 + r;
-                            float sm = 0.f;
 #pragma unroll
                             for (int c = 0; c < 4; c++) {
                                 xa[i][c] = ta[i][c] + ba[c] + xa[i][c];
                                 xb[i][c] = tb[i][c] + bb[c] + xb[i][c];
-                                sm += xa[i][c] + xb[i][c];
                             }
-#pragma unroll
-                            for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
-                            const float mean = sm * (1.0f / MST_D);
-                            float s2 = 0.f;
-#pragma unroll
-                            for (int c = 0; c < 4; c++) {
-                                xa[i][c] -= mean;
-                                xb[i][c] -= mean;
-                                s2 += xa[i][c] * xa[i][c] + xb[i][c] * xb[i][c];
-                            }
-#pragma unroll
-                            for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
-                            const float rstd = ln_rstd(s2);
-                            f32x4 ya, yb;
-#pragma unroll
-                            for (int c = 0; c < 4; c++) {
-                                ya[c] = xa[i][c] * rstd * ga[c] + ea[c];
-                                yb[c] = xb[i][c] * rstd * gb[c] + eb[c];
-                            }
+                            ln_row_wave(xa[i], xb[i], ga, gb, ea, eb);
+                            const f32x4 ya = xa[i], yb = xb[i];
                             uint2 ha, la, hb, lb;
                             split4_f16(ya, ha, la);
                             split4_f16(yb, hb, lb);

@@ -246,6 +246,30 @@ def test_small_launch_gemms_resident_tile_equals_slab_ring(monkeypatch):
     assert rel_l2(o_f, o_r) < 5e-4 and rel_l2(o_f, res[0][0]) > 1e-2
 
 
+@pytest.mark.parametrize("F,T,B", [(181, 76, 1), (263, 196, 2), (190, 75, 5), (150, 61, 3)])
+def test_layernorm_inside_the_consuming_gemm_is_bitwise_the_rows_kernel(monkeypatch, F, T, B):
+    """Up to 512 stream rows the small-launch path makes each LayerNorm inside the GEMM that consumes it (k_rows_gemm<.., LNF = 1>,
+    16-token tiles, the stream alternating between two buffers); MST_SMALL_LN=0 launches k_ln_rows between the GEMMs.  Same per-lane
+    arithmetic and the same order of the k sum: bit-identical forwards and loops, also where the last tile is ragged."""
+    from mst_amd.engine import Schedule, SAMPLER_DDPM
+    from oracle import schedule
+    assert B * (T + 1) <= 512
+    shape = (B, F, 1, T)
+    x, txt = syn.normal(SEED, "xl", shape), syn.normal(SEED, "tl", (B, 512))
+    t = np.array([5, 400, 998, 77, 650][:B])
+    tab, tmap = schedule.make("cosine", 1000, "")
+    sch = Schedule(tab, tmap, dev())
+    fused, _, _ = make(F, T, B)
+    monkeypatch.setenv("MST_SMALL_LN", "0")
+    rows, _, _ = make(F, T, B)
+    res = []
+    for eng in (fused, rows):
+        eng.set_text(cu(txt))
+        res.append((eng.forward(cu(x), cu(t)), eng.sample_loop(sch, cu(x), 999, 992, SAMPLER_DDPM, seed=9)))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
+
+
 def test_argument_errors_surface_as_exceptions():
     from mst_amd.engine import DenoiserEngine, Schedule
     from oracle import schedule
