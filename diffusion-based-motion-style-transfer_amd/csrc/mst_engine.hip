@@ -696,6 +696,9 @@ static int launch_small(int M, int N, const SRC& xs, const f16* W, int ldw, int 
 }
 
 // The small-launch GEMMs of mst_small.h: 64 x 128 tiles, the token tile resident in LDS, the weights streamed as fragments.
+static int g_rows_ntb1_m = [] { const char* v = getenv("MST_SMALL_NTB1_M"); return v ? atoi(v) : 800; }();
+// (tools/r4_ntb1_sweep.sh, r4_ntb2_sweep.sh: 16-token tiles ahead through 4 clips x 197 rows, behind at 6; 32-token tiles 4 % ahead at 8 and 9 clips, level at 6, behind at 5)
+static int g_rows_ntb2_from = [] { const char* v = getenv("MST_SMALL_NTB2_FROM"); return v ? atoi(v) : 1300; }();
 template <int KS, int MODE>
 static int launch_rows_gemm(int M, int N, const f16* X, const f16* wpk, const float* bias, void* out, int ldo, hipStream_t st, const LnRows* ln = nullptr,
                             const FfnTrain* ft = nullptr) {
@@ -703,6 +706,18 @@ static int launch_rows_gemm(int M, int N, const f16* X, const f16* wpk, const fl
     if constexpr (KS == 16 && MODE != 2) {
         if (ln) {                                                  // 16-token tiles (mst_small.h)
             hipLaunchKernelGGL((k_rows_gemm<KS, MODE, 1, 1>), dim3((M + 15) / 16, N / 128), dim3(512), 16 * 1024, st, X, wpk, bias, out, ldo, M, *ln);
+            HIPCHECK(hipGetLastError());
+            return 0;
+        }
+    }
+    if constexpr (MODE != 3) {
+        if (M <= g_rows_ntb1_m) {                                  // a clip or two: 16-token tiles here too (a quarter of the DMA burst in front of the first MFMA)
+            hipLaunchKernelGGL((k_rows_gemm<KS, MODE, 0, 1>), dim3((M + 15) / 16, N / 128), dim3(512), smem / 4, st, X, wpk, bias, out, ldo, M, LnRows{}, FfnTrain{});
+            HIPCHECK(hipGetLastError());
+            return 0;
+        }
+        if (M > g_rows_ntb2_from) {
+            hipLaunchKernelGGL((k_rows_gemm<KS, MODE, 0, 2>), dim3((M + 31) / 32, N / 128), dim3(512), smem / 2, st, X, wpk, bias, out, ldo, M, LnRows{}, FfnTrain{});
             HIPCHECK(hipGetLastError());
             return 0;
         }
