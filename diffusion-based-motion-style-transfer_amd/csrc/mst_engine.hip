@@ -710,14 +710,14 @@ static int launch_rows_gemm(int M, int N, const f16* X, const f16* wpk, const fl
             return 0;
         }
     }
-    if constexpr (MODE != 3) {
+    {
         if (M <= g_rows_ntb1_m) {                                  // a clip or two: 16-token tiles here too (a quarter of the DMA burst in front of the first MFMA)
-            hipLaunchKernelGGL((k_rows_gemm<KS, MODE, 0, 1>), dim3((M + 15) / 16, N / 128), dim3(512), smem / 4, st, X, wpk, bias, out, ldo, M, LnRows{}, FfnTrain{});
+            hipLaunchKernelGGL((k_rows_gemm<KS, MODE, 0, 1>), dim3((M + 15) / 16, N / 128), dim3(512), smem / 4, st, X, wpk, bias, out, ldo, M, LnRows{}, ft ? *ft : FfnTrain{});
             HIPCHECK(hipGetLastError());
             return 0;
         }
         if (M > g_rows_ntb2_from) {
-            hipLaunchKernelGGL((k_rows_gemm<KS, MODE, 0, 2>), dim3((M + 31) / 32, N / 128), dim3(512), smem / 2, st, X, wpk, bias, out, ldo, M, LnRows{}, FfnTrain{});
+            hipLaunchKernelGGL((k_rows_gemm<KS, MODE, 0, 2>), dim3((M + 31) / 32, N / 128), dim3(512), smem / 2, st, X, wpk, bias, out, ldo, M, LnRows{}, ft ? *ft : FfnTrain{});
             HIPCHECK(hipGetLastError());
             return 0;
         }
