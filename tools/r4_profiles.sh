@@ -3,6 +3,16 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r04; rm -rf $O; mkdir -p $O
 P=diffusion-based-motion-style-transfer_amd/csrc/probes/bin
 step() { echo "== $1"; }
+step "pmc traffic (first: bench.py quotes roofline.traffic only from a file whose source hash is this build's; the stand-alone embed kernels: MST_FUSE_EMBED=0)"
+B="python3 bench.py --steps 1 --warmup 0 --denoise-steps 12 --no-cpu-baseline --no-boundary"
+MST_STREAMS=1 MST_FUSE_EMBED=0 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmcF -- $B > $O/pmcF.log 2>&1 &&
+MST_STREAMS=1 MST_FUSE_EMBED=0 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmcW -- $B > $O/pmcW.log 2>&1 &&
+MST_STREAMS=1 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmcF2 -- $B > $O/pmcF2.log 2>&1 &&
+MST_STREAMS=1 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmcW2 -- $B > $O/pmcW2.log 2>&1 || exit 1
+python3 tools/pmc_traffic.py $O/pmcF $O/pmcW > $O/r04_pmc_traffic.json; head -30 $O/r04_pmc_traffic.json
+python3 tools/pmc_traffic.py $O/pmcF2 $O/pmcW2 > $O/r04_pmc_traffic_fused_step.json
+cp $O/r04_pmc_traffic.json profiles/r04_pmc_traffic.json
+find $O/pmc?* -name "*kernel_trace.csv" -delete
 step "bench default";  timeout -k 10 600 python bench.py > $O/bench_default.log 2>&1 || exit 1; tail -1 $O/bench_default.log > $O/r04_bench_default.json; cut -c1-400 $O/r04_bench_default.json
 step "bench cfg";      timeout -k 10 300 python bench.py --cfg --steps 2 --warmup 1 --no-cpu-baseline --no-boundary > $O/bench_cfg.log 2>&1 || exit 1; tail -1 $O/bench_cfg.log > $O/r04_bench_cfg.json; cut -c1-200 $O/r04_bench_cfg.json
 step "bench batch 128"; timeout -k 10 300 python bench.py --batch 128 --steps 2 --warmup 1 --no-cpu-baseline --no-boundary > $O/bench_b128.log 2>&1 || exit 1; tail -1 $O/bench_b128.log > $O/r04_bench_batch128.json; cut -c1-200 $O/r04_bench_batch128.json
@@ -20,12 +30,7 @@ head -6 $O/r04_kernel_stats_bench_steps1_streams1.csv | cut -c1-160
 step "kernel trace, three slices (the timed path)"
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace3 -- python3 bench.py --steps 1 --warmup 1 --denoise-steps 40 --no-cpu-baseline --no-boundary > $O/trace3.log 2>&1 || exit 1
 python3 tools/r4_trace.py $O/trace3 > $O/r04_three_slice_trace_summary.txt; grep -E "^queue|dur  (tail|attn|embed)" $O/r04_three_slice_trace_summary.txt | head -20
-step "pmc traffic"
 export MST_STREAMS=1
-B="python3 bench.py --steps 1 --warmup 0 --denoise-steps 12 --no-cpu-baseline --no-boundary"
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmcF -- $B > $O/pmcF.log 2>&1 &&
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmcW -- $B > $O/pmcW.log 2>&1 || exit 1
-python3 tools/pmc_traffic.py $O/pmcF $O/pmcW > $O/r04_pmc_traffic.json; head -30 $O/r04_pmc_traffic.json
 step "pmc mfma / lds"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmcA -- $B > $O/pmcA.log 2>&1 || exit 1
 python3 tools/pmc_summary.py $O/pmcA > $O/r04_pmc_mfma_lds.txt 2>&1; grep -E "embed|qkv_att|layer_tail" $O/r04_pmc_mfma_lds.txt | cut -c1-300
@@ -40,7 +45,9 @@ step "tail probe at a slice's size"; ( timeout -k 10 100 $P/tail_clock 64 4334 |
 step "host enqueue share"; timeout -k 10 300 python tools/host_bound.py 2>&1 | grep "^B=" > $O/r04_host_bound.txt; cat $O/r04_host_bound.txt
 step "latency batch 1"; timeout -k 10 300 python tools/latency_b1.py 2>&1 | grep "^F=" > $O/r04_latency_batch1.txt; cat $O/r04_latency_batch1.txt
 step "single-clip step by kernel family"; timeout -k 10 300 python tools/r4_b1_families.py 2>&1 | tail -9 > $O/r04_single_clip_families.txt; cat $O/r04_single_clip_families.txt
+step "the same with round 3's small-launch kernels (slab ring, LayerNorm launches)"; ( MST_SMALL_FAST=0 timeout -k 10 300 python tools/latency_b1.py 2>&1 | grep "^F="; MST_SMALL_FAST=0 timeout -k 10 300 python tools/r4_b1_families.py 2>&1 | tail -9 ) > $O/r04_single_clip_ring_kernels.txt; cat $O/r04_single_clip_ring_kernels.txt
+step "small path over the batch size"; bash tools/r4_small_sweep.sh > $O/r04_small_path_sweep.txt 2>&1; tail -12 $O/r04_small_path_sweep.txt
 step "embed kernels by mode"; ( timeout -k 10 200 python tools/r4_embed_modes.py 2>&1 | tail -4; EB=21 timeout -k 10 200 python tools/r4_embed_modes.py 2>&1 | tail -4; MST_EMBED_FAST=0 EB=21 timeout -k 10 200 python tools/r4_embed_modes.py 2>&1 | tail -4 ) > $O/r04_embed_kernels_by_mode.txt; cat $O/r04_embed_kernels_by_mode.txt
 step "train stack"; timeout -k 10 300 python tools/train_bench.py > $O/train.log 2>&1; tail -1 $O/train.log > $O/r04_train_stack_bench.json; cut -c1-300 $O/r04_train_stack_bench.json
-rm -rf $O/prof $O/prof_ft $O/pmcF $O/pmcW $O/pmcA $O/trace3
+rm -rf $O/prof $O/prof_ft $O/pmcF $O/pmcW $O/pmcF2 $O/pmcW2 $O/pmcA $O/trace3
 ls $O
