@@ -132,7 +132,7 @@ struct LayerW {
     bool tail_dirty = true, qkv_dirty = true;   // wtail / wqkv are older than w_out | w1 | w2 / w_in: repacked by ensure_packed() before the next sampling launch
     f16* wqkv = nullptr;            // W_in as the fused QKV+attention kernel's per-(head, wave) fragment streams (mst_attn.h, k_pack_qkv)
     f16 *wsm_in = nullptr, *wsm_out = nullptr, *wsm_1 = nullptr, *wsm_2 = nullptr;   // the four matrices as [16-row block][k-step] fragments: the small-launch GEMMs (mst_small.h)
-    bool small_dirty = true;        // ... older than the plain matrices: repacked by the first small launch that follows an upload
+    bool small_dirty = true;        // ... older than the plain matrices (ensure_packed / the training forward repack them, all stale layers in one launch)
 };
 
 // engine-owned scratch of the backward pass, allocated on the first training call
@@ -1782,9 +1782,12 @@ static int train_ws(mst_engine* e) {
 // dW[n_out][k_in] += unscale * dY^T X   (dY: [M][n_out] f16, X: [M][k_in] f16), db += unscale * colsum(dY) if db
 static int wgrad(mst_engine* e, const f16* dY, int n_out, const f16* X, int k_in, int M, float* dW, float* db, hipStream_t st) {
     TrainWS& t = e->tw;
-    // ~one block per CU: tiles x splits ~ 256; every split contracts a whole number of 32-token slabs
+    // tiles x splits ~ 128 workgroups (MST_WGRAD_WGS): the partials' round trip grows with the splits -- stack backward at 64 clips 3.11 / 2.96 / 2.85 /
+    // 2.95 / 3.11 / 3.37 ms at 64 / 96 / 128 / 256 / 384 / 512, and the dgrad chain on the other stream uses the CUs left; every split contracts a
+    // whole number of 32-token slabs
     const int tiles = (n_out / 128) * (k_in / 256);
-    int nsplit = (256 + tiles - 1) / tiles;
+    static const int wg_target = [] { const char* v = getenv("MST_WGRAD_WGS"); return v ? atoi(v) : 128; }();
+    int nsplit = (wg_target + tiles - 1) / tiles;
     const int slabs = (M + 31) / 32;
     if (nsplit > slabs) nsplit = slabs;
     if ((size_t)nsplit > t.split_cap) nsplit = (int)t.split_cap;
