@@ -1028,8 +1028,8 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
                 CHECK((launch_rows_gemm<16, 0>(M, 3 * MST_D, nullptr, w.wsm_in, w.b_in, ws.qkv, 3 * MST_D, st, &ln)));
             } else if (fast) CHECK((launch_rows_gemm<16, 0>(M, 3 * MST_D, ws.hx, w.wsm_in, w.b_in, ws.qkv, 3 * MST_D, st)));
             else {
-            DEpiBiasF16<false> epi{w.b_in, ws.qkv, 3 * MST_D, M};
-            CHECK(launch_small(M, 3 * MST_D, RowsDirect{ws.hx, MST_D, hl_in, e->precise ? w.w_in_lo : nullptr}, w.w_in, MST_D, MST_D, epi, st));
+                DEpiBiasF16<false> epi{w.b_in, ws.qkv, 3 * MST_D, M};
+                CHECK(launch_small(M, 3 * MST_D, RowsDirect{ws.hx, MST_D, hl_in, e->precise ? w.w_in_lo : nullptr}, w.w_in, MST_D, MST_D, epi, st));
             }
         }
         DBG_STOP(1)
@@ -1042,8 +1042,8 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
             ProfScope ps(e, FAM_OUTPROJ_LN, st);
             if (fast) CHECK((launch_rows_gemm<16, 2>(M, MST_D, ws.att, w.wsm_out, nullptr, ws.zacc, MST_D, st)));
             else {
-            DEpiPlainF32 epi{ws.zacc, MST_D, M};
-            CHECK(launch_small(M, MST_D, RowsDirect{ws.att, MST_D, att_lo, e->precise ? w.w_out_lo : nullptr}, w.w_out, MST_D, MST_D, epi, st));
+                DEpiPlainF32 epi{ws.zacc, MST_D, M};
+                CHECK(launch_small(M, MST_D, RowsDirect{ws.att, MST_D, att_lo, e->precise ? w.w_out_lo : nullptr}, w.w_out, MST_D, MST_D, epi, st));
             }
             if (!lnf) hipLaunchKernelGGL(k_ln_rows, dim3((M + 3) / 4), dim3(256), 0, st, ws.zacc, w.b_out, w.g1, w.be1, ws.hx, ws.hl, M, (f16*)nullptr, (f16*)nullptr);
             HIPCHECK(hipGetLastError());
@@ -1056,8 +1056,8 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
                 CHECK((launch_rows_gemm<16, 1>(M, MST_FF, nullptr, w.wsm_1, w.b1, ws.hid, MST_FF, st, &ln)));
             } else if (fast) CHECK((launch_rows_gemm<16, 1>(M, MST_FF, ws.hx, w.wsm_1, w.b1, ws.hid, MST_FF, st)));
             else {
-            DEpiBiasF16<true> epi{w.b1, ws.hid, MST_FF, M, hid_lo};
-            CHECK(launch_small(M, MST_FF, RowsDirect{ws.hx, MST_D, hl_in, e->precise ? w.w1_lo : nullptr}, w.w1, MST_D, MST_D, epi, st));
+                DEpiBiasF16<true> epi{w.b1, ws.hid, MST_FF, M, hid_lo};
+                CHECK(launch_small(M, MST_FF, RowsDirect{ws.hx, MST_D, hl_in, e->precise ? w.w1_lo : nullptr}, w.w1, MST_D, MST_D, epi, st));
             }
         }
         DBG_STOP(4)
@@ -1065,8 +1065,8 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
             ProfScope ps(e, FAM_FFN2_LN, st);
             if (fast) CHECK((launch_rows_gemm<32, 2>(M, MST_D, ws.hid, w.wsm_2, nullptr, ws.zacc, MST_D, st)));
             else {
-            DEpiPlainF32 epi{ws.zacc, MST_D, M};
-            CHECK(launch_small(M, MST_D, RowsDirect{ws.hid, MST_FF, hid_lo, e->precise ? w.w2_lo : nullptr}, w.w2, MST_FF, MST_FF, epi, st));
+                DEpiPlainF32 epi{ws.zacc, MST_D, M};
+                CHECK(launch_small(M, MST_D, RowsDirect{ws.hid, MST_FF, hid_lo, e->precise ? w.w2_lo : nullptr}, w.w2, MST_FF, MST_FF, epi, st));
             }
             if (!lnf) hipLaunchKernelGGL(k_ln_rows, dim3((M + 3) / 4), dim3(256), 0, st, ws.zacc, w.b2, w.g2, w.be2, ws.hx, ws.hl, M, (f16*)nullptr, (f16*)nullptr);
             else if (l == NL - 1) hipLaunchKernelGGL(k_ln_rows, dim3((M + 3) / 4), dim3(256), 0, st, ws.zacc, w.b2, w.g2, w.be2, ws.hx2, ws.hl2, M, ws.hx, ws.hl);
@@ -1685,8 +1685,8 @@ static int train_stack_forward(mst_engine* e, const Tape& t, int rows, int S, fl
         {
             if (fast) CHECK((launch_rows_gemm<16, 2>(M, MST_D, a.att, w.wsm_out, nullptr, e->zacc, MST_D, st)));
             else {
-            DEpiPlainF32 epi{e->zacc, MST_D, M};
-            CHECK(launch_small(M, MST_D, RowsDirect{a.att, MST_D}, w.w_out, MST_D, MST_D, epi, st));
+                DEpiPlainF32 epi{e->zacc, MST_D, M};
+                CHECK(launch_small(M, MST_D, RowsDirect{a.att, MST_D}, w.w_out, MST_D, MST_D, epi, st));
             }
             hipLaunchKernelGGL(k_ln_rows_train, dim3((M + 3) / 4), dim3(256), 0, st, e->zacc, w.b_out, w.g1, w.be1, t.sh[l], t.sl[l],
                                a.z1h, a.z1l, a.x1h, a.x1l, M, make_drop(seed, l, 1, p_drop, o1));
@@ -1702,8 +1702,8 @@ static int train_stack_forward(mst_engine* e, const Tape& t, int rows, int S, fl
         {
             if (fast) CHECK((launch_rows_gemm<32, 2>(M, MST_D, a.hid, w.wsm_2, nullptr, e->zacc, MST_D, st)));
             else {
-            DEpiPlainF32 epi{e->zacc, MST_D, M};
-            CHECK(launch_small(M, MST_D, RowsDirect{a.hid, MST_FF}, w.w2, MST_FF, MST_FF, epi, st));
+                DEpiPlainF32 epi{e->zacc, MST_D, M};
+                CHECK(launch_small(M, MST_D, RowsDirect{a.hid, MST_FF}, w.w2, MST_FF, MST_FF, epi, st));
             }
             hipLaunchKernelGGL(k_ln_rows_train, dim3((M + 3) / 4), dim3(256), 0, st, e->zacc, w.b2, w.g2, w.be2, a.x1h, a.x1l,
                                a.z2h, a.z2l, t.sh[l + 1], t.sl[l + 1], M, make_drop(seed, l, 3, p_drop, o1));

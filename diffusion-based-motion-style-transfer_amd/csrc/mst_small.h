@@ -1,12 +1,18 @@
-// The four GEMMs of an encoder layer for a clip or two (the demo's single-clip transfer, configs[0]; mdm_forstyledataset.py:539-546):
-// 64 tokens x 128 features per workgroup over a 2-D grid, so that tens of workgroups share a weight matrix.
+// The four GEMMs of an encoder layer for a clip or a few (the demo's single-clip transfer, BASELINE configs[0]; the fine-tune objective's
+// chained single-clip calls; mdm_forstyledataset.py:539-546): 16 NTB tokens x 128 features per workgroup over a 2-D grid, so that tens of
+// workgroups share a weight matrix.
 //
-// Round 1-3 ran these on the LDS-DMA slab ring (k_gemm_dma<64,128,...>): 8 .. 16 slabs of DMA -> wait -> barrier -> MFMA in series per
-// workgroup, 4 .. 10 us per launch for 2 .. 8 MFLOP-sized tiles -- the slab loop's latency, not its bandwidth (profiles/r04_single_clip_families.txt).
-// Here, as in the round-4 embed kernels (mst_embed.h): the tile's 64 token rows land in LDS in ONE LDS-DMA burst (K = 512: 64 KB,
-// K = 1024: 128 KB) and stay for the whole K range; the weights are wave-private (wave w owns the tile's 16-row block w) and stream
+// Rounds 1-3 ran these on the LDS-DMA slab ring (k_gemm_dma<64,128,...>): 8 .. 16 slabs of DMA -> wait -> barrier -> MFMA in series per
+// workgroup, 4 .. 10 us per launch for tiles of a few MFLOP -- the slab loop's latency, not its bandwidth (profiles/r04_single_clip_ring_kernels.txt).
+// Here, as in the round-4 embed kernels (mst_embed.h): the tile's token rows land in LDS in ONE LDS-DMA burst (K = 512: 1 KB per row,
+// K = 1024: 2 KB) and stay for the whole K range; the weights are wave-private (wave w owns the tile's 16-row feature block w) and stream
 // L2 -> VGPR as pre-packed 1-KB fragments behind hand-counted waits; a lane of the 16x16x32 accumulator holds four consecutive features
 // of one token, which go straight to global memory (rows of a few hundred tokens: no transposition through LDS).
+//
+// Tile height (engine: launch_rows_gemm): 16 tokens up to 800 stream rows (the burst in front of the first MFMA is a quarter of the
+// 64-token tile's, and the extra workgroups find idle CUs), 64 tokens above, 32 above 1 300 (measured: tools/r4_ntb1_sweep.sh, r4_ntb2_sweep.sh).
+// LNF = 1 makes the rows instead of reading them: the LayerNorm between two GEMMs without a launch of its own (below).
+// 2.8 .. 4.4 us per launch at one clip; single-clip step 378 -> 253 us.
 #pragma once
 #include "mst_common.h"
 #include "mst_embed.h"
