@@ -216,7 +216,7 @@ __global__ __launch_bounds__(512) void k_embed_out(RowsFrames xs, const f16* __r
     static_assert(KSN == 0 || (NX == 1 && MODE != 0 && NBW <= 3), "the fused next-step embedding is for plain sampling steps");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using C = EmbCfg;
-    constexpr int KS = MST_D / 32, NFR = KS * NBW, D = 8;               // (8 fragments in flight: the registers go to the staged epilogue)
+    constexpr int KS = MST_D / 32, NFR = KS * NBW, D = (NBW == 3 && NX == 2) ? 4 : 8;               // (8 fragments in flight: the registers go to the staged epilogue; 4 under CFG at three blocks per wave, where 8 spilled one register -- 58.8 -> 59.0 clips/s)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t16 = lane & 15, q4 = lane >> 4;

@@ -703,7 +703,7 @@ template <int KS, int MODE>
 static int launch_rows_gemm(int M, int N, const f16* X, const f16* wpk, const float* bias, void* out, int ldo, hipStream_t st, const LnRows* ln = nullptr,
                             const FfnTrain* ft = nullptr) {
     constexpr int smem = 64 * (KS / 16) * 1024;
-    if constexpr (KS == 16 && MODE != 2) {
+    if constexpr (KS == 16 && (MODE == 0 || MODE == 1)) {
         if (ln) {                                                  // 16-token tiles (mst_small.h)
             hipLaunchKernelGGL((k_rows_gemm<KS, MODE, 1, 1>), dim3((M + 15) / 16, N / 128), dim3(512), 16 * 1024, st, X, wpk, bias, out, ldo, M, *ln);
             HIPCHECK(hipGetLastError());

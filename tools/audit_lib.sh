@@ -14,4 +14,8 @@ rc=0
 for k in k_layer_tailILi2E k_layer_tailILi3E k_layer_tailILi4E k_qkv_attention2ILi2E k_qkv_attention2ILi4E k_qkv_attention2ILi6E k_qkv_attention2ILi8E k_qkv_attention2ILi10E k_qkv_attention2ILi12E k_qkv_attention2ILi13E; do
   python3 $ROOT/tools/audit_stream_isa.py $S $k || rc=1
 done
+# every instantiation of the round-4 streaming kernels (mst_small.h, mst_embed.h)
+for k in $(grep -oE "^_ZN3mst1[01]k_(rows_gemm|embed_out|embed_in)I[A-Za-z0-9]*E" $S | sort -u | sed -E 's/_ZN3mst1[01]//'); do
+  python3 $ROOT/tools/audit_stream_isa.py $S $k || rc=1
+done
 exit $rc
