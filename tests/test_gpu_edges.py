@@ -270,6 +270,32 @@ def test_layernorm_inside_the_consuming_gemm_is_bitwise_the_rows_kernel(monkeypa
     assert torch.equal(res[0][1], res[1][1])
 
 
+def test_small_launch_tile_heights_agree_and_hold_the_oracle():
+    """Eight clips of 196 frames (1576 stream rows: 32-token GEMM tiles), their halves (788 rows each: 16-token tiles) and five of them
+    (985 rows: 64-token tiles) give the same loop up to fp32 summation order, and the 8-clip forward holds the bar against the oracle."""
+    from mst_amd.engine import Schedule, SAMPLER_DDPM
+    from oracle import denoiser, schedule
+    F, T, B = 263, 196, 8
+    eng, w, pe = make(F, T, B)
+    assert eng.loop_slices(B) == 1
+    shape = (B, F, 1, T)
+    x, txt = syn.normal(SEED, "xh", shape), syn.normal(SEED, "th", (B, 512))
+    t = np.array([0, 999, 431, 7, 650, 12, 300, 880])
+    tab, tmap = schedule.make("cosine", 1000, "")
+    sch = Schedule(tab, tmap, dev())
+    nz = cu(np.stack([syn.normal(SEED, f"nzh/{k}", shape) for k in range(5)]))
+    eng.set_text(cu(txt))
+    out = eng.forward(cu(x), cu(t)).cpu().numpy()
+    e = rel_l2(out, denoiser.forward(w, pe, x, t, txt).numpy())
+    print("8 clips, 32-token tiles vs oracle", e)
+    assert e < TOL
+    whole = eng.sample_loop(sch, cu(x), 4, 0, SAMPLER_DDPM, noise=nz)
+    for lo, hi in ((0, 4), (4, 8), (2, 7)):
+        eng.set_text(cu(txt[lo:hi]))
+        part = eng.sample_loop(sch, cu(x[lo:hi]), 4, 0, SAMPLER_DDPM, noise=nz[:, lo:hi].contiguous())
+        assert rel_l2(part.cpu().numpy(), whole[lo:hi].cpu().numpy()) < 1e-6, (lo, hi)
+
+
 def test_argument_errors_surface_as_exceptions():
     from mst_amd.engine import DenoiserEngine, Schedule
     from oracle import schedule

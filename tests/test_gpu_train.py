@@ -354,6 +354,33 @@ def test_train_edge_shapes(rows, S, p):
     assert rel_l2(d_in2.cpu().numpy(), d_in.cpu().numpy()) < 1e-6
 
 
+@pytest.mark.parametrize("rows,p", [(14, 0.1), (20, 0.1)])
+def test_train_small_launch_tile_heights(rows, p):
+    """The small-launch GEMMs pick their tile height by the row count (engine: launch_rows_gemm): 16 tokens up to 800 stream rows (the
+    shapes above), 64 tokens up to 1300 (14 clips x 77 = 1078 rows), 32 tokens above (20 x 77 = 1540 rows) -- the training FFN1 mode
+    (tape pre-activation + dropout) included.  Forward, input gradient and parameter gradients against fp32 autograd with the engine's masks."""
+    from mst_amd.engine import DenoiserEngine
+    S = 77
+    eng = DenoiserEngine(181, 76, rows, device=_dev())
+    w = syn.denoiser_state(SEED, 181, layer_prefix="seqTransEncoder.layers.")
+    eng.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, layer_prefix="seqTransEncoder.layers.",
+                        pe=torch.from_numpy(syn.positional_table(5000, 512)))
+    h = torch.from_numpy(syn.normal(SEED, f"tiles/h/{rows}", (rows, S, D))).to(_dev())
+    r = torch.from_numpy(syn.normal(SEED, f"tiles/r/{rows}", (rows, S, D))).to(_dev())
+    seed = 1234 + rows
+    params = layer_params(w, True)
+    href = h.clone().requires_grad_(True)
+    ref = torch_stack(href, params, engine_masks(eng, seed, p, rows, S))
+    (ref * r).sum().backward()
+    out, tape = eng.train_forward(h, p, seed)
+    grads = [torch.zeros_like(q) for q in params]
+    d_in = eng.train_backward(tape, r, p, seed, grads)
+    assert rel_l2(out.cpu().numpy(), ref.detach().cpu().numpy()) <= TOL_FWD
+    assert rel_l2(d_in.cpu().numpy(), href.grad.cpu().numpy()) <= TOL_GRAD
+    for i in (0, 2, 4, 6, 8, 84 + 0, 84 + 4, 84 + 6):
+        assert rel_l2(grads[i].cpu().numpy(), params[i].grad.cpu().numpy()) <= 2 * TOL_GRAD, (i, LAYER_TENSORS[i % 12])
+
+
 def test_train_key_padding_mask_engine_level():
     """mst_train_forward / backward with key_keep: padded keys get no attention and no K/V gradient; vs torch autograd."""
     eng, w = engine_for("xia")
