@@ -95,10 +95,15 @@ __device__ __forceinline__ void tail_fence() { asm volatile("" ::: "memory"); }
 // by the distance the scheduler happened to leave (found in round 4: the 48-token instantiation interleaved pass 1's last MFMAs with the
 // lo-residual adds and came out 7 % wrong).  tail_acc_settle(): no instruction crosses, and every MFMA issued in front of it has written
 // its result behind it (v_mfma_f32_16x16x32_f16 -> VALU read: 8 wait states by hipcc's own count; 10 here).
+// tools/audit_asm_hazards.py checks the whole class on the compiled library (every inline-asm instruction against the wait states hipcc
+// itself keeps behind an MFMA); `tools/audit_lib.sh --selftest` compiles this header with MST_AUDIT_SELFTEST_NO_SETTLE to prove that the
+// audit reports the kernel without the settle.
 __device__ __forceinline__ void tail_acc_settle() {
+#ifndef MST_AUDIT_SELFTEST_NO_SETTLE
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 9" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+#endif
 }
 __device__ __forceinline__ void tail_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }   // LDS only: the stream stays in flight
 
