@@ -5,8 +5,12 @@
 // chains, one launch each, exactly as mst_sample_loop does.  Stamps (first start / last end per launch) give, per K: wall time per
 // step, the mean number of chains with a kernel running, and the mean gap between a chain's consecutive launches.
 //
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 queues.hip -o bin/queues && bin/queues [us=30] [G=40] [L=400] [prio=0|1]
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 queues.hip -o bin/queues && bin/queues [us=30] [G=40] [L=400] [prio=0|1] [blocked=0|1|2]
 //   prio=1: streams alternate between the three stream priorities (separate hardware-queue pools in ROCclr)
+//   blocked=1: one MORE stream whose queue holds a wait (hipStreamWaitEvent on an event recorded behind the chains' last launches) for
+//              the whole run -- what the CALLER's stream is to mst_sample_loop: ordered behind the loop by ev_out, idle otherwise.
+//   blocked=2: the same stream waits for chain 0's progress again and again (an event recorded on chain 0 after its first launch and
+//              then every 8 launches): its queue is parked behind a barrier packet from the first launch to the last
 //   GPU_MAX_HW_QUEUES=n in the environment sets ROCclr's queue count per priority (default 4)
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -33,6 +37,7 @@ int main(int argc, char** argv) {
     const int G = argc > 2 ? atoi(argv[2]) : 40;
     const int L = argc > 3 ? atoi(argv[3]) : 400;
     const int prio = argc > 4 ? atoi(argv[4]) : 0;
+    const int blocked = argc > 5 ? atoi(argv[5]) : 0;
     const int KMAX = 8;
     CK(hipFuncSetAttribute((const void*)k_idle, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     int lo = 0, hi = 0;
@@ -46,6 +51,11 @@ int main(int argc, char** argv) {
             CK(hipStreamCreateWithPriority(&st[k], hipStreamNonBlocking, p));
         } else CK(hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking));
     }
+    hipStream_t waiter;
+    hipEvent_t ev_done;
+    CK(hipStreamCreateWithFlags(&waiter, hipStreamNonBlocking));
+    CK(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
+    if (blocked) printf("one more stream waits for the chains' end (mode %d)\n", blocked);
     unsigned long long* dstamp;
     const size_t nst = (size_t)KMAX * L * 2;
     CK(hipMalloc(&dstamp, nst * 8));
@@ -57,9 +67,22 @@ int main(int argc, char** argv) {
             CK(hipMemcpy(dstamp, init.data(), nst * 8, hipMemcpyHostToDevice));
             CK(hipDeviceSynchronize());
             const auto t0 = std::chrono::steady_clock::now();
-            for (int j = 0; j < L; j++)
+            for (int j = 0; j < L; j++) {
                 for (int k = 0; k < K; k++)
                     hipLaunchKernelGGL(k_idle, dim3(G), dim3(512), 160 * 1024, st[k], dstamp, k * L + j, (long long)(us * 100.0));
+                if (blocked == 2 && j == 0) {                 // the waiter's queue is parked from here on ...
+                    CK(hipEventRecord(ev_done, st[0]));
+                    CK(hipStreamWaitEvent(waiter, ev_done, 0));
+                }
+                if (blocked == 2 && j > 0 && j % 8 == 0) {    // ... and re-parked every 8 steps (a caller that keeps waiting on the loop)
+                    CK(hipEventRecord(ev_done, st[0]));
+                    CK(hipStreamWaitEvent(waiter, ev_done, 0));
+                }
+            }
+            if (blocked == 1) {
+                CK(hipEventRecord(ev_done, st[0]));
+                CK(hipStreamWaitEvent(waiter, ev_done, 0));
+            }
             const auto t1 = std::chrono::steady_clock::now();
             CK(hipDeviceSynchronize());
             const auto t2 = std::chrono::steady_clock::now();

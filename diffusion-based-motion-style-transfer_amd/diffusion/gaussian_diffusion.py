@@ -406,13 +406,18 @@ class GaussianDiffusion:
         if with_grad:
             # the steps' inputs are cut from each other's graphs (x.detach() in *_with_grad): native model calls on a single clip share
             # one activation tape and ONE backward pass, and may run on a side stream (model/native_stack.ChainedCalls) -- the loop's
-            # set-up (x_T, q_sample of the init image) included, so that it is ordered with them; anything else is untouched
+            # set-up (x_T, q_sample of the init image) included, so that it is ordered with them; anything else is untouched.  The
+            # chain (and its stream) is installed around each step's work only, never across a yield: between two steps the consumer
+            # runs on its own stream with no chain current, and an abandoned generator leaves nothing switched.
             from ..model.native_stack import ChainedCalls
             n = self.num_timesteps - skip_timesteps - (stop_timesteps if stop_timesteps is not None else 0)
-            with ChainedCalls(n, start_event=self.__dict__.get("_chain_start_event")):
+            ev = self.__dict__.get("_chain_start_event")
+            ev, ev_dev = ev if isinstance(ev, tuple) else (ev, None)
+            chain = ChainedCalls(n, start_event=ev, device=ev_dev if ev_dev is not None else device)
+            with chain:
                 device, img, indices = self._loop_setup(model, shape, noise, device, skip_timesteps, init_image, stop_timesteps, model_kwargs)
-                yield from self._grad_steps(ddim, model, img, indices, shape, device, progress, clip_denoised, model_kwargs, eta,
-                                            const_noise, pred_xstart_in_graph)
+            yield from self._grad_steps(ddim, model, img, indices, shape, device, progress, clip_denoised, model_kwargs, eta,
+                                        const_noise, pred_xstart_in_graph, chain)
             return
         device, img, indices = self._loop_setup(model, shape, noise, device, skip_timesteps, init_image, stop_timesteps, model_kwargs)
         denoiser, cfg, _ = _unwrap(model)
@@ -430,34 +435,29 @@ class GaussianDiffusion:
             # drain the GPU once per chained step of the fine-tune objective; a device-side fill gives the same tensor)
             t = th.full((shape[0],), int(i), device=device, dtype=th.long)
             with th.no_grad():
-                if with_grad:
-                    out = (self.ddim_sample_with_grad(model, img, t, clip_denoised=clip_denoised, model_kwargs=model_kwargs, eta=eta,
-                                                      pred_xstart_in_graph=pred_xstart_in_graph) if ddim else
-                           self.p_sample_with_grad(model, img, t, clip_denoised=clip_denoised, model_kwargs=model_kwargs,
-                                                   const_noise=const_noise, pred_xstart_in_graph=pred_xstart_in_graph))
-                else:
-                    out = (self.ddim_sample(model, img, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn,
-                                            model_kwargs=model_kwargs, eta=eta) if ddim else
-                           self.p_sample(model, img, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn,
-                                         model_kwargs=model_kwargs, const_noise=const_noise))
+                out = (self.ddim_sample(model, img, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn,
+                                        model_kwargs=model_kwargs, eta=eta) if ddim else
+                       self.p_sample(model, img, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn,
+                                     model_kwargs=model_kwargs, const_noise=const_noise))
                 yield out
                 img = out["sample"]
 
     def _grad_steps(self, ddim, model, img, indices, shape, device, progress, clip_denoised, model_kwargs, eta, const_noise,
-                    pred_xstart_in_graph):
+                    pred_xstart_in_graph, chain):
         """The *_with_grad loop (reference gaussian_diffusion.py:775-794 with cond_fn_with_grad): every step's x0-hat stays in the graph."""
         if progress:
             from tqdm.auto import tqdm
             indices = tqdm(indices)
         for i in indices:
-            t = th.full((shape[0],), int(i), device=device, dtype=th.long)
-            with th.no_grad():
-                out = (self.ddim_sample_with_grad(model, img, t, clip_denoised=clip_denoised, model_kwargs=model_kwargs, eta=eta,
-                                                  pred_xstart_in_graph=pred_xstart_in_graph) if ddim else
-                       self.p_sample_with_grad(model, img, t, clip_denoised=clip_denoised, model_kwargs=model_kwargs,
-                                               const_noise=const_noise, pred_xstart_in_graph=pred_xstart_in_graph))
-                yield out
-                img = out["sample"]
+            with chain:
+                t = th.full((shape[0],), int(i), device=device, dtype=th.long)
+                with th.no_grad():
+                    out = (self.ddim_sample_with_grad(model, img, t, clip_denoised=clip_denoised, model_kwargs=model_kwargs, eta=eta,
+                                                      pred_xstart_in_graph=pred_xstart_in_graph) if ddim else
+                           self.p_sample_with_grad(model, img, t, clip_denoised=clip_denoised, model_kwargs=model_kwargs,
+                                                   const_noise=const_noise, pred_xstart_in_graph=pred_xstart_in_graph))
+            yield out
+            img = out["sample"]
 
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                                   model_kwargs=None, device=None, progress=False, skip_timesteps=0, init_image=None,
@@ -528,7 +528,8 @@ class GaussianDiffusion:
         chain_start = None
         if x_start.is_cuda:
             chain_start = th.cuda.Event()
-            chain_start.record()
+            chain_start.record(th.cuda.current_stream(x_start.device))
+            chain_start = (chain_start, x_start.device)
         x_t = self.q_sample(x_start, t, noise=noise_t2m, model_kwargs=model_t2m_kwargs)
         model_output = model(x_t, self._scale_timesteps(t), **model_t2m_kwargs)
         if semantic_guidance:

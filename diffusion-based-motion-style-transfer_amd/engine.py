@@ -123,9 +123,19 @@ class DenoiserEngine:
             self.handle = None
 
     # ------------------------------------------------------------------------------ weights
-    def load_tensor(self, name, tensor):
+    def _remember_source(self, name, tensor):
+        """Weights go up WITHOUT their lo halves while precise mode is off (34 MB nobody reads); `set_precise(True)` later uploads them
+        again from the caller's tensor, so a reference to it (not to the device temporary) is kept until then -- and only until then:
+        with precise mode on every upload is complete and the entry is dropped.  The reference sees what the caller's tensor holds at
+        THAT time: a tensor mutated in place since (an optimizer step) is uploaded with its current values, as any later load would."""
         self._sources = getattr(self, "_sources", {})
-        self._sources[name] = tensor                       # the caller's tensor (not the device temporary): set_precise re-uploads from it
+        if getattr(self, "_precise_on", False):
+            self._sources.pop(name, None)
+        else:
+            self._sources[name] = tensor
+
+    def load_tensor(self, name, tensor):
+        self._remember_source(name, tensor)
         t = _f32c(tensor, self.device, name)
         shape = (C.c_int64 * t.dim())(*t.shape)
         N.check(N.lib().mst_load_weight(self.handle, name.encode(), N.ptr(t), shape, t.dim(), N.stream_ptr(self.device)))
@@ -138,9 +148,8 @@ class DenoiserEngine:
                 raise ValueError("load_layers wants float32 contiguous tensors on the engine's device")
         arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
         N.check(N.lib().mst_load_layers(self.handle, arr, N.stream_ptr(self.device)))
-        self._sources = getattr(self, "_sources", {})
         for i, t in enumerate(tensors):
-            self._sources[f"seqTransEncoder.layers.{i // 12}.{LAYER_TENSORS[i % 12]}"] = t
+            self._remember_source(f"seqTransEncoder.layers.{i // 12}.{LAYER_TENSORS[i % 12]}", t)
 
     def load_state_dict(self, sd, layer_prefix="seqTransEncoder.layers.", prior_prefix="motion_enc.mdm_model.",
                         pe=None):
@@ -357,7 +366,7 @@ class DenoiserEngine:
         rc = N.lib().mst_set_precise(self.handle, int(bool(on)))
         if rc == 2:                                        # weights went up without their lo halves: upload again, now with them
             for name, tensor in list(getattr(self, "_sources", {}).items()):
-                self.load_tensor(name, tensor)
+                self.load_tensor(name, tensor)             # (precise is on now: each entry is dropped as it goes up)
             torch.cuda.current_stream(self.device).synchronize()
             rc = 0
         N.check(rc)

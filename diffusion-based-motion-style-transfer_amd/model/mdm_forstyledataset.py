@@ -14,6 +14,7 @@ tests/torch_reference.py, and install it on an instance when they need one.)
 CLIP stays third-party: `encode_text` uses the `clip` package when it is installed, a callable set
 with `set_text_encoder`, or a precomputed `y['text_embed']` ([B, clip_dim]).
 """
+import contextlib
 import os
 
 import numpy as np
@@ -170,9 +171,15 @@ class _EngineHost:
         eng.set_text(emb, keep=keep, cfg=cfg)
 
     def _native_forward(self, x, timesteps, y):
-        eng = self.mst_engine(x.shape[0], x.shape[-1])
-        self.mst_prepare(eng, y, False)
-        return eng.forward(x, timesteps)
+        from .native_stack import ChainedCalls
+        block = ChainedCalls.current        # inside a side-stream block of chained training calls: this call is not one of them
+        with (block.foreign_call(x, timesteps) if block is not None else contextlib.nullcontext()):
+            eng = self.mst_engine(x.shape[0], x.shape[-1])
+            self.mst_prepare(eng, y, False)
+            out = eng.forward(x, timesteps)
+            if block is not None and block.side is not None:
+                out.record_stream(block.side)
+        return out
 
     def _encoder_stack(self, seq, key_keep=None):
         """seqTransEncoder(seq) as the native training node; seq: [S, B, d]; key_keep: None or bool [B, S].

@@ -22,6 +22,8 @@ Data-parallel overlap.  The sink counts the nodes the forward pass created; the 
 (`host._native_layer_ready`) as soon as its native backward call has returned -- the call only enqueues GPU
 work -- and the reducer starts every layer's all-reduce behind that layer's gradient event
 (mst_train_wait_layer_grads), layer 7 first, while the GPU is still differentiating the layers below."""
+import contextlib
+
 import torch
 from torch.autograd import Variable
 
@@ -173,39 +175,71 @@ class ChainedCalls:
     current = None
     _side = {}
 
-    def __init__(self, n, start_event=None):
+    def __init__(self, n, start_event=None, device=None):
         """start_event: a CUDA event recorded (on the caller's stream) where everything the chain reads was ready -- the chain's forward
         calls then run on a SIDE stream behind that event, on a second engine instance, beside whatever the caller's stream has been
         given since (the fine-tune objective: the 64-clip text-to-motion call and the frozen motion encoder, neither of which the
-        chain depends on; six launch-bound single-clip calls use a few CUs each).  The caller's stream waits for the side stream when
-        the block ends; the chain's ONE backward pass runs on the caller's stream (parameter gradients are accumulated in place: the
-        passes of one iteration stay ordered on one stream)."""
+        chain depends on; six launch-bound single-clip calls use a few CUs each).  The chain's ONE backward pass runs on the caller's
+        stream (parameter gradients are accumulated in place: the passes of one iteration stay ordered on one stream).
+        device: the tensors' device (the streams are taken there, not on torch's current device).
+        The side stream is taken only when the calls are really chained (MST_CHAIN on): an unchained single-clip call works on the
+        module's ONE engine, whose workspace and gradient accumulators the caller's stream is using."""
         self.n, self.k, self.reported, self.done = int(n), 0, 0, False
         self.tape = self.seed = self.dbuf = self.ctx0 = None
         self.key = None
-        self.start_event = start_event if _CHAIN_STREAM_ON() else None
+        self.start_event = start_event if (_CHAIN_STREAM_ON() and _CHAIN_ON()) else None
+        self.device = device
         self.main = self.side = self._sctx = None
+        self.prev = None
+        self._depth = 0
 
+    # The block is entered PER STEP of the *_with_grad loop (`with chain: model call`), never across a generator's yield: between two
+    # steps the consumer runs with its own current stream and no chain installed (ADVICE round 4).
     def __enter__(self):
+        self._depth += 1
+        if self._depth > 1:
+            return self
         self.prev, ChainedCalls.current = ChainedCalls.current, self
         if self.start_event is not None and torch.cuda.is_available():
-            dev = torch.cuda.current_device()
-            self.main = torch.cuda.current_stream(dev)
-            self.side = ChainedCalls._side.get(dev)
             if self.side is None:
-                self.side = ChainedCalls._side[dev] = torch.cuda.Stream(dev)
-            self.side.wait_event(self.start_event)
+                dev = self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
+                dev = torch.device(dev)
+                idx = dev.index if dev.index is not None else torch.cuda.current_device()
+                self.main = torch.cuda.current_stream(idx)
+                self.side = ChainedCalls._side.get(idx)
+                if self.side is None:
+                    self.side = ChainedCalls._side[idx] = torch.cuda.Stream(idx)
+                self.side.wait_event(self.start_event)
             self._sctx = torch.cuda.stream(self.side)
             self._sctx.__enter__()
         return self
 
     def __exit__(self, *exc):
+        self._depth -= 1
+        if self._depth > 0:
+            return False
         ChainedCalls.current = self.prev
         if self._sctx is not None:
             self._sctx.__exit__(*exc)
             self._sctx = None
-            self.main.wait_stream(self.side)               # what follows on the caller's stream reads the chain's outputs
+            self.main.wait_stream(self.side)               # what follows on the caller's stream may read the step's outputs
         return False
+
+    @contextlib.contextmanager
+    def foreign_call(self, *tensors):
+        """A native call inside the block that does NOT join the chain (frozen stack, other shape, MST_CHAIN off ...): it works on the
+        module's one engine, so it goes to the CALLER's stream, ordered behind what the side stream produced and in front of what the
+        side stream does next; autograd then runs its backward on the caller's stream as well."""
+        if self.side is None or self._sctx is None:
+            yield
+            return
+        self.main.wait_stream(self.side)
+        for t in tensors:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(self.main)
+        with torch.cuda.stream(self.main):
+            yield
+        self.side.wait_stream(self.main)
 
     def accepts(self, key):
         """Same engine, shape and dropout rates as the chain's first call, and a free slot."""
@@ -233,7 +267,9 @@ class ChainedCalls:
             views = _sink_views(ctx, True, self.dbuf.device)
             if self.main is not None:
                 # autograd runs this node on the side stream (its forward's); the pass itself belongs on the caller's stream, behind
-                # the gradients the side stream has just copied in and in line with the iteration's other backward passes
+                # the gradients the side stream has just copied in (report() ran there; through the end-of-pass callback this code is on
+                # the caller's stream already, so the side stream is named) and in line with the iteration's other backward passes
+                self.main.wait_stream(self.side)
                 self.main.wait_stream(torch.cuda.current_stream(self.dbuf.device))
                 with torch.cuda.stream(self.main):
                     ctx.eng.train_model_backward(tape, self.dbuf, ctx.p_drop, ctx.p_pe, self.seed, views, need_input_grad=False)
@@ -257,25 +293,35 @@ class DenoiserTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, host, p_drop, p_pe, timesteps, text_emb, *params):
         B, F, one, T = x.shape
-        chain = ChainedCalls.current if _CHAIN_ON() else None
+        block = ChainedCalls.current
+        chain = block if _CHAIN_ON() else None
         if chain is not None and not (B == 1 and not ctx.needs_input_grad[0] and any(ctx.needs_input_grad[6:])):
             chain = None
-        # (a chain on a side stream works on an engine instance of its own: workspace, text projection and weight copies)
-        eng = host.mst_engine(max(B, chain.n), T, slot="chain" if chain.side is not None else None) if chain is not None else host.mst_engine(B, T)
-        eng.set_text(text_emb.detach())
         seed = _draw_seed(max(p_drop, p_pe))
-        ctx.eng, ctx.p_drop, ctx.p_pe, ctx.host, ctx.params, ctx.chain = eng, p_drop, p_pe, host, params, None
-        key = (id(eng), B, F, T, float(p_drop), float(p_pe))
-        if chain is not None and chain.accepts(key):
-            if chain.k == 0:
-                chain.key, chain.seed, chain.tape = key, seed, eng.train_tape(chain.n, T + 1, zero=True)
-                _sink_of(host, params).open_nodes += 1          # the chain is ONE native backward call
-            out, _ = eng.train_model_forward(x.detach(), timesteps, p_drop, p_pe, chain.seed, tape=chain.tape, clip0=chain.k,
-                                             tape_clips=chain.n)
-            ctx.chain, ctx.slot, ctx.tape, ctx.seed = chain, chain.k, None, chain.seed
-            chain.k += 1
-            return out
-        out, tape = eng.train_model_forward(x.detach(), timesteps, p_drop, p_pe, seed)
+        ctx.p_drop, ctx.p_pe, ctx.host, ctx.params, ctx.chain = p_drop, p_pe, host, params, None
+        if chain is not None:
+            # (a chain on a side stream works on an engine instance of its own: workspace, text projection and weight copies)
+            eng = host.mst_engine(max(B, chain.n), T, slot="chain" if chain.side is not None else None)
+            key = (id(eng), B, F, T, float(p_drop), float(p_pe))
+            if chain.accepts(key):
+                eng.set_text(text_emb.detach())
+                ctx.eng = eng
+                if chain.k == 0:
+                    chain.key, chain.seed, chain.tape = key, seed, eng.train_tape(chain.n, T + 1, zero=True)
+                    _sink_of(host, params).open_nodes += 1          # the chain is ONE native backward call
+                out, _ = eng.train_model_forward(x.detach(), timesteps, p_drop, p_pe, chain.seed, tape=chain.tape, clip0=chain.k,
+                                                 tape_clips=chain.n)
+                ctx.chain, ctx.slot, ctx.tape, ctx.seed = chain, chain.k, None, chain.seed
+                chain.k += 1
+                return out
+        # a call of its own: the module's one engine, on the caller's stream (inside a side-stream block too: foreign_call)
+        with (block.foreign_call(x, timesteps, text_emb) if block is not None else contextlib.nullcontext()):
+            eng = host.mst_engine(B, T)
+            eng.set_text(text_emb.detach())
+            ctx.eng = eng
+            out, tape = eng.train_model_forward(x.detach(), timesteps, p_drop, p_pe, seed)
+            if block is not None and block.side is not None:
+                out.record_stream(block.side)
         ctx.tape, ctx.seed = tape, seed
         if any(ctx.needs_input_grad[6:]):
             _sink_of(host, params).open_nodes += 1

@@ -33,12 +33,6 @@ def cu(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
 
 
-def make_args():
-    return types.SimpleNamespace(dataset="stylexia_posrot", latent_dim=512, layers=8, cond_mask_prob=0.1, arch="trans_enc",
-                                 emb_trans_dec=False, diffusion_steps=1000, noise_schedule="cosine", sigma_small=True,
-                                 lambda_vel=0.0, lambda_rcxyz=0.0, lambda_fc=0.0)
-
-
 @contextlib.contextmanager
 def recorded_noise(tag):
     """The same draw sequence tests/golden/make_golden.py fed the reference."""
@@ -67,10 +61,17 @@ def recorded_noise(tag):
 _CACHE = {}
 
 
-def build():
-    if "m" not in _CACHE:
-        model, d_ddim, d_plain = model_util.creat_serval_diffusion(make_args(), StyleDiffusion, "ddim20")
-        _, d_100, d_full = model_util.creat_ddpm_ddim_diffusion(make_args(), StyleDiffusion, "100")
+def make_args(dataset="stylexia_posrot"):
+    return types.SimpleNamespace(dataset=dataset, latent_dim=512, layers=8, cond_mask_prob=0.1, arch="trans_enc",
+                                 emb_trans_dec=False, diffusion_steps=1000, noise_schedule="cosine", sigma_small=True,
+                                 lambda_vel=0.0, lambda_rcxyz=0.0, lambda_fc=0.0)
+
+
+def build(dataset="stylexia_posrot"):
+    """Model + diffusion objects through the reference's factories; `humanml`: the (263, 1, 196) denoiser."""
+    if dataset not in _CACHE:
+        model, d_ddim, d_plain = model_util.creat_serval_diffusion(make_args(dataset), StyleDiffusion, "ddim20")
+        _, d_100, d_full = model_util.creat_ddpm_ddim_diffusion(make_args(dataset), StyleDiffusion, "100")
         sd = {k: torch.from_numpy(np.ascontiguousarray(syn.tensor_for(SEED, k, tuple(v.shape))))
               for k, v in model.state_dict().items() if not k.endswith(".pe") and "clip_model" not in k}
         missing, unexpected = model.load_state_dict(sd, strict=False)
@@ -78,8 +79,8 @@ def build():
         model.motion_enc.mdm_model.set_text_encoder(
             lambda texts: torch.stack([torch.from_numpy(syn.normal(SEED, "text/" + t, (512,))) for t in texts]))
         model = model.to(dev()).eval()
-        _CACHE.update(m=model, ddim=d_ddim, plain=d_plain, r100=d_100, full=d_full)
-    return _CACHE
+        _CACHE[dataset] = dict(m=model, ddim=d_ddim, plain=d_plain, r100=d_100, full=d_full)
+    return _CACHE[dataset]
 
 
 def inputs():
@@ -285,6 +286,176 @@ def test_finetune_objective_matches_reference(golden):
         bias.copy_(saved)
         again = model(x, t, y=y)
     assert not torch.equal(before, after) and torch.equal(before, again)
+
+
+def _fold_project(name, g):
+    """tests/golden/make_golden_grads.py::fold_project (the fixture's 64-d random projection of a flat gradient)."""
+    g = np.asarray(g, dtype=np.float64).reshape(-1)
+    rows = (g.size + 4095) // 4096
+    buf = np.zeros(rows * 4096, dtype=np.float64)
+    buf[:g.size] = g
+    w = syn.normal(SEED, f"gradproj/rows/{name}", (rows,)).astype(np.float64)
+    a = syn.normal(SEED, "gradproj/matrix", (64, 4096)).astype(np.float64)
+    return float(np.linalg.norm(g)), a @ (w @ buf.reshape(rows, 4096))
+
+
+# Declared tolerances of the training path against the REFERENCE's own gradients (tests/golden/ft_grads.npz): 16-bit MFMA operands in
+# every forward, dgrad and wgrad product of six chained model calls plus the text-to-motion call on TWO clips (few values per weight
+# gradient element to average the operand rounding over): 5e-3 per tensor on the norm, on the 64-d projection (relative to the
+# projection's own norm: the estimate of a relative error from 64 random directions is good to ~10 %) and on every 1-D gradient in full;
+# at the per-GPU size of configs[3] (64 clips, tests/test_gpu_train_fullsize.py) the same kernels measure <= 7e-4 against fp32 autograd.
+GRAD_TOL = 5e-3
+
+
+@pytest.mark.parametrize("case", ["xia|ft1", "xia|ft0", "hml|ft1"])
+def test_finetune_gradients_all_96_tensors_and_input_gradient_vs_reference(case):
+    """the fine-tune objective's gradients pinned to the REFERENCE (gaussian_diffusion.py:1317-1399 run on CPU,
+    tests/golden/make_golden_grads.py), every one of the 96 trainable tensors and d loss / d x_start -- not two probes."""
+    g = np.load(os.path.join(GOLDEN, "ft_grads.npz"))
+    base, ft = case.split("|")
+    use_ddim = int(ft[-1])
+    Fc, Tc = (181, 76) if base == "xia" else (263, 196)
+    c = build("stylexia_posrot" if base == "xia" else "humanml")
+    model, dd = c["m"], (c["ddim"] if use_ddim else c["full"])
+    shp = (1, Fc, 1, Tc)
+    mask = cu(syn.root_horizontal_mask(2, Fc, Tc))
+    motion = cu(syn.normal(SEED, f"{base}/motion", (2, Fc, 1, Tc)))
+    y1 = {"y": {"text": PROMPTS[:1], "mask": torch.ones(1, 1, 1, Tc, device=dev()), "inpainting_mask": mask[:1], "inpainted_motion": motion[:1]}}
+    t2m = cu(syn.normal(SEED, f"{base}/t2m", (2, Fc, 1, Tc)))
+    fm = torch.ones(2, 1, 1, Tc, device=dev())
+    fm[1, ..., Tc - 9:] = 0
+    y_t2m = {"y": {"text": PROMPTS, "mask": fm, "inpainting_mask": mask.double(), "inpainted_motion": t2m}}
+    style = cu(syn.normal(SEED, f"{base}/style", shp))
+    tt = torch.tensor([2, 4], device=dev())
+    # d loss / d x_start: q_sample is a forward-only kernel here, so x_t is made the leaf and the chain rule's last factor
+    # (x_t = sqrt(abar_t) x_start + ..., gaussian_diffusion.py:267-285) is applied by hand
+    leaf = {}
+    orig_q = dd.q_sample
+
+    def q_leaf(x_start, t, noise=None, model_kwargs=None):
+        xt = orig_q(x_start, t, noise=noise, model_kwargs=model_kwargs).detach().requires_grad_(True)
+        leaf["xt"], leaf["t"] = xt, t
+        return xt
+
+    model.zero_grad()
+    dd.q_sample = q_leaf
+    try:
+        with recorded_noise(f"{base}/ft{use_ddim}"):
+            terms = dd.few_shot_style_finetune_losses(model, t2m, tt, motion[:1], style, skip_steps=700 if use_ddim else 995, model_kwargs=y1,
+                                                      model_t2m_kwargs=y_t2m, semantic_guidance=1, use_ddim=use_ddim, Ls=10)
+        terms["loss"].backward()
+    finally:
+        del dd.q_sample
+    assert rel_l2(terms["rot_mse"].detach().cpu().numpy(), g[f"{case}|rot_mse"]) < 1e-4
+    assert abs(float(terms["text_cosine"]) - float(g[f"{case}|text_cosine"])) < 1e-4
+    assert abs(float(terms["loss"]) - float(g[f"{case}|loss"])) < 1e-3 * abs(float(g[f"{case}|loss"]))
+    grads = dict(model.named_parameters())
+    names = [str(n) for n in g[f"{case}|names"]]
+    assert len(names) == 96 and sorted(names) == sorted(n for n, p in grads.items() if p.grad is not None)
+    worst = {"norm": (0.0, ""), "proj": (0.0, ""), "full": (0.0, "")}
+    for n in names:
+        mine = grads[n].grad.detach().cpu().numpy()
+        nrm, pr = _fold_project(n, mine)
+        gn, gp = float(g[f"{case}|norm|{n}"]), g[f"{case}|proj|{n}"]
+        errs = {"norm": abs(nrm - gn) / gn, "proj": float(np.linalg.norm(pr - gp) / np.linalg.norm(gp))}
+        if mine.ndim == 1:
+            errs["full"] = rel_l2(mine, g[f"{case}|full|{n}"])
+        for k, e in errs.items():
+            if e > worst[k][0]:
+                worst[k] = (e, n)
+    sa = torch.from_numpy(np.asarray(dd.sqrt_alphas_cumprod, dtype=np.float32)).to(dev())[leaf["t"]].view(-1, 1, 1, 1)
+    gx = (leaf["xt"].grad * sa).cpu().numpy()
+    nrm, pr = _fold_project("x_start", gx)
+    e_dx = {"norm": abs(nrm - float(g[f"{case}|dx_norm"])) / float(g[f"{case}|dx_norm"]),
+            "proj": float(np.linalg.norm(pr - g[f"{case}|dx_proj"]) / np.linalg.norm(g[f"{case}|dx_proj"]))}
+    if base == "xia":
+        e_dx["full"] = rel_l2(gx, g[f"{case}|dx_full"])
+    print(case, "worst gradient errors vs the reference:", {k: (f"{v[0]:.2e}", v[1]) for k, v in worst.items()}, "d loss / d x_start:", {k: f"{v:.2e}" for k, v in e_dx.items()})
+    for k, (e, n) in worst.items():
+        assert e < GRAD_TOL, (case, k, n, e)
+    for k, e in e_dx.items():
+        assert e < GRAD_TOL, (case, "d loss / d x_start", k, e)
+    assert all(p.grad is None for p in model.motion_enc.parameters())
+    model.zero_grad()
+
+
+def test_chain_and_side_stream_switches_give_the_same_gradients(monkeypatch):
+    """the objective's six chained single-clip calls may (a) share one tape and one backward pass (MST_CHAIN) and (b) run
+    their forward passes on a side stream and a second engine beside the text-to-motion call (MST_CHAIN_STREAM).  All four switch
+    combinations must give the same loss and the same 96 gradients: the side stream changes no arithmetic (bit-identical for a given
+    MST_CHAIN), the shared pass rounds its f16 wgrad operands behind ONE power-of-two scale instead of one per call (< 2e-3).  With
+    MST_CHAIN=0 the side stream must not be taken at all (an unchained call works on the module's one engine).  Second part: a loss
+    that reads only SOME of the chained steps' x0-hats -- the nodes without a gradient are differentiated as zeros by the
+    end-of-pass callback -- agrees with the unchained run too."""
+    from mst_amd.model import native_stack
+    c = build()
+    model, dd = c["m"], c["ddim"]
+    x, t, y, mask, motion = inputs()
+    shp = (1, F, 1, T)
+    y1 = {"y": {"text": PROMPTS[:1], "mask": torch.ones(1, 1, 1, T, device=dev()), "inpainting_mask": mask[:1], "inpainted_motion": motion[:1]}}
+    t2m = cu(syn.normal(SEED, "xia/t2m", (2, F, 1, T)))
+    fm = torch.ones(2, 1, 1, T, device=dev())
+    fm[1, ..., T - 9:] = 0
+    y_t2m = {"y": {"text": PROMPTS, "mask": fm, "inpainting_mask": mask.double(), "inpainted_motion": t2m}}
+    style = cu(syn.normal(SEED, "xia/style", shp))
+    names = [n for n, p in model.named_parameters() if not n.startswith("motion_enc.")]
+
+    def objective():
+        model.zero_grad()
+        with recorded_noise("xia/ft1"):
+            terms = dd.few_shot_style_finetune_losses(model, t2m, torch.tensor([2, 4], device=dev()), motion[:1], style, skip_steps=700,
+                                                      model_kwargs=y1, model_t2m_kwargs=y_t2m, semantic_guidance=1, use_ddim=1, Ls=10)
+        terms["loss"].backward()
+        torch.cuda.synchronize()
+        grads = dict(model.named_parameters())
+        return float(terms["loss"]), [grads[n].grad.clone() for n in names]
+
+    def partial():                       # only steps 0, 2 and 5 of the six reach the loss: three nodes get no gradient
+        model.zero_grad()
+        with recorded_noise("xia/ft1p"):
+            dump = dd.ddim_sample_loop(model, shp, clip_denoised=False, model_kwargs=y1, skip_timesteps=14, init_image=motion[:1],
+                                       cond_fn_with_grad=True, pred_xstart_in_graph=True, dump_all_xstart=True)
+        assert len(dump) == 6
+        loss = sum(((dump[k] - style) ** 2).mean() for k in (0, 2, 5))
+        loss.backward()
+        torch.cuda.synchronize()
+        grads = dict(model.named_parameters())
+        return float(loss), [grads[n].grad.clone() for n in names]
+
+    for p_ in model.parameters_wo_enc():
+        p_.requires_grad_(True)
+    res, side_taken = {}, {}
+    for chain_on in ("1", "0"):
+        for stream_on in ("1", "0"):
+            monkeypatch.setenv("MST_CHAIN", chain_on)
+            monkeypatch.setenv("MST_CHAIN_STREAM", stream_on)
+            taken = []
+            orig_enter = native_stack.ChainedCalls.__enter__
+
+            def spy(self, _o=orig_enter, _t=taken):
+                r = _o(self)
+                _t.append(self.side is not None)
+                return r
+
+            monkeypatch.setattr(native_stack.ChainedCalls, "__enter__", spy)
+            res[(chain_on, stream_on)] = (objective(), partial())
+            side_taken[(chain_on, stream_on)] = any(taken)
+            monkeypatch.setattr(native_stack.ChainedCalls, "__enter__", orig_enter)
+    assert side_taken[("1", "1")] and not side_taken[("1", "0")]
+    assert not side_taken[("0", "1")] and not side_taken[("0", "0")], "an unchained call must stay on the caller's stream"
+    for part in (0, 1):
+        for chain_on in ("1", "0"):
+            la, ga = res[(chain_on, "1")][part]
+            lb, gb = res[(chain_on, "0")][part]
+            assert la == lb and all(torch.equal(a, b) for a, b in zip(ga, gb)), ("side stream changed the arithmetic", chain_on, part)
+        la, ga = res[("1", "1")][part]
+        lb, gb = res[("0", "0")][part]
+        assert abs(la - lb) <= 1e-6 * abs(lb)
+        worst = max(rel_l2(a.cpu().numpy(), b.cpu().numpy()) for a, b in zip(ga, gb))
+        print("part", part, "chained vs unchained, worst of 96 tensors:", worst)
+        assert worst < 2e-3
+    assert len(names) == 96
+    model.zero_grad()
 
 
 def test_neutralisation_prepass_all_100_xstarts_vs_reference():
