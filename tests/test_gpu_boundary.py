@@ -299,12 +299,13 @@ def _fold_project(name, g):
     return float(np.linalg.norm(g)), a @ (w @ buf.reshape(rows, 4096))
 
 
-# Declared tolerances of the training path against the REFERENCE's own gradients (tests/golden/ft_grads.npz): 16-bit MFMA operands in
-# every forward, dgrad and wgrad product of six chained model calls plus the text-to-motion call on TWO clips (few values per weight
-# gradient element to average the operand rounding over): 5e-3 per tensor on the norm, on the 64-d projection (relative to the
-# projection's own norm: the estimate of a relative error from 64 random directions is good to ~10 %) and on every 1-D gradient in full;
-# at the per-GPU size of configs[3] (64 clips, tests/test_gpu_train_fullsize.py) the same kernels measure <= 7e-4 against fp32 autograd.
-GRAD_TOL = 5e-3
+# Declared tolerances of the training path against the REFERENCE's own gradients (tests/golden/ft_grads.npz; 16-bit MFMA operands in every
+# forward, dgrad and wgrad product of six chained model calls plus the text-to-motion call on two clips): per tensor 1.5e-3 relative L2 on
+# every 1-D gradient compared in full and on d loss / d x_start (the figure tests/test_gpu_train.py declares against fp32 autograd), 1e-3
+# on every tensor's norm, 3e-3 on the 64-d projection relative to the projection's own norm (an estimate of the relative error from 64
+# random directions, good to ~15 %, and the worst of 96 is asserted).  Measured on MI355X (round 5): norms <= 1.5e-4, full 1-D tensors
+# <= 9.1e-4, projections <= 2.0e-3 (layers.7.linear2.weight in all three cases), d loss / d x_start 8.8e-4 / 9.1e-4 in full.
+GRAD_TOL = {"norm": 1e-3, "full": 1.5e-3, "proj": 3e-3}
 
 
 @pytest.mark.parametrize("case", ["xia|ft1", "xia|ft0", "hml|ft1"])
@@ -333,9 +334,11 @@ def test_finetune_gradients_all_96_tensors_and_input_gradient_vs_reference(case)
     orig_q = dd.q_sample
 
     def q_leaf(x_start, t, noise=None, model_kwargs=None):
-        xt = orig_q(x_start, t, noise=noise, model_kwargs=model_kwargs).detach().requires_grad_(True)
-        leaf["xt"], leaf["t"] = xt, t
-        return xt
+        xt = orig_q(x_start, t, noise=noise, model_kwargs=model_kwargs)
+        if "xt" in leaf:                  # (the sampling loop's q_sample of the content clip: not the text-to-motion batch)
+            return xt
+        leaf["xt"], leaf["t"] = xt.detach().requires_grad_(True), t
+        return leaf["xt"]
 
     model.zero_grad()
     dd.q_sample = q_leaf
@@ -372,9 +375,9 @@ def test_finetune_gradients_all_96_tensors_and_input_gradient_vs_reference(case)
         e_dx["full"] = rel_l2(gx, g[f"{case}|dx_full"])
     print(case, "worst gradient errors vs the reference:", {k: (f"{v[0]:.2e}", v[1]) for k, v in worst.items()}, "d loss / d x_start:", {k: f"{v:.2e}" for k, v in e_dx.items()})
     for k, (e, n) in worst.items():
-        assert e < GRAD_TOL, (case, k, n, e)
+        assert e < GRAD_TOL[k], (case, k, n, e)
     for k, e in e_dx.items():
-        assert e < GRAD_TOL, (case, "d loss / d x_start", k, e)
+        assert e < GRAD_TOL[k], (case, "d loss / d x_start", k, e)
     assert all(p.grad is None for p in model.motion_enc.parameters())
     model.zero_grad()
 
