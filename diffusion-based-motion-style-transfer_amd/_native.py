@@ -84,6 +84,8 @@ SIGNATURES = {
     "mst_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int32),
                                    C.c_int32]),
     "mst_set_precise": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mst_set_trunk_groups": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mst_trunk_check": (C.c_int, [C.c_void_p]),
     "mst_debug_stop_after": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "mst_debug_copy": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p]),
 }

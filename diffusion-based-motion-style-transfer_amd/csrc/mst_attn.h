@@ -511,27 +511,23 @@ __device__ __forceinline__ void qa_glds1(unsigned voff, unsigned long long sbase
                  : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
 }
 
-template <int NT16>
-__global__ __launch_bounds__(512) void k_qkv_attention2(const f16* __restrict__ hx, const f16* __restrict__ wq,
-                                                        const float* __restrict__ b_in, f16* __restrict__ out, int S) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// The kernel's body as a function of (clip, head): k_qkv_attention2 = one call per workgroup; the resident-group trunk (mst_trunk.h) calls it
+// once per layer with PERSIST = true: the workgroup's weight / bias prefetch is issued, THEN it waits for its clip's stream rows
+// (group_wait), the attention output goes through the wave's own (dead) Q rows so that it leaves as 16-byte write-through stores in
+// whole 128-byte lines, and every wave returns (no early exit: the caller's barriers want all eight).
+template <int NT16, bool PERSIST>
+__device__ __forceinline__ void qa2_body(char* smem, const f16* __restrict__ hx, const f16* __restrict__ wq, const float* __restrict__ b_in,
+                                         f16* __restrict__ out, int S, int clip, int head, const GroupSync sync, bool wait_input, int wave_in) {
     using TL = QA2Tile<NT16>;
     constexpr int NKT = TL::NKT, P = TL::PER, KT = TL::KT;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // (PERSIST: the lane index is recomputed in every phase and the wave index arrives in a scalar register, so that no per-lane
+    // constant stays alive across the other phases' bodies)
+    int lane, wave;
+    if constexpr (PERSIST) { lane = lane_id_now(); wave = opaque_uniform(wave_in); }      // (opaque: nothing derived from it is hoisted out of the phase loop)
+    else { lane = threadIdx.x & 63; wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
+    const int tid = wave * 64 + lane;
+    (void)tid;
     QA_MARK(0)
-    // (clip, head) of this workgroup: the four heads of a clip share id % 8 = one XCD's L2 (see k_qkv_attention)
-    const int nclip = gridDim.x / MST_H, full = (nclip / 8) * 8 * MST_H;
-    int clip, head;
-    if ((int)blockIdx.x < full) {
-        const int grp = blockIdx.x >> 5, within = blockIdx.x & 31;
-        clip = grp * 8 + (within & 7);
-        head = within >> 3;
-    } else {
-        const int r = blockIdx.x - full;
-        clip = (nclip / 8) * 8 + r / MST_H;
-        head = r % MST_H;
-    }
     const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     const char* xb = reinterpret_cast<const char*>(hx + (size_t)clip * S * MST_D);
     // the head's q | k | v bias (3 x 512 B) -> LDS by two DMA pieces of wave 0: the oldest operations of its queue
@@ -551,6 +547,9 @@ __global__ __launch_bounds__(512) void k_qkv_attention2(const f16* __restrict__ 
     QA2_LOAD(0, 0); QA2_LOAD(1, 1); QA2_LOAD(2, 2); QA2_LOAD(3, 3); QA2_LOAD(4, 4); QA2_LOAD(5, 5);
     DmaPlan<TL> plan;
     plan.init(wave, lane, [&](int row) { return (unsigned)(row < S ? row : S - 1) * (unsigned)(MST_D * 2); });
+    if constexpr (PERSIST) {
+        if (wait_input) group_wait(sync, wave);               // the clip's stream rows are complete (and this CU holds no stale copy of them)
+    }
 #pragma unroll
     for (int s = 0; s < 3; s++) plan.issue(smem_base, s, s, xb, xb);
 
@@ -647,7 +646,10 @@ __global__ __launch_bounds__(512) void k_qkv_attention2(const f16* __restrict__ 
     }
     __syncthreads();
     QA_MARK(2)
-    if (wave >= NKT) return;
+    if constexpr (!PERSIST) {
+        if (wave >= NKT) return;
+    }
+    if (wave < NKT) {
 
     // ---- attention core (k_attention's; q from its image, natural d order)
     const int hh = lane >> 5, l31 = lane & 31;
@@ -680,7 +682,7 @@ __global__ __launch_bounds__(512) void k_qkv_attention2(const f16* __restrict__ 
             sc[kt][r] = v;
             m = fmaxf(m, v);
         }
-    m = fmaxf(m, __shfl_xor(m, 32));
+    if constexpr (PERSIST) m = xor32_max(m); else m = fmaxf(m, __shfl_xor(m, 32));
     float l = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NKT; kt++)
@@ -690,7 +692,7 @@ __global__ __launch_bounds__(512) void k_qkv_attention2(const f16* __restrict__ 
             sc[kt][r] = p;
             l += p;
         }
-    l += __shfl_xor(l, 32);
+    if constexpr (PERSIST) l = xor32_add(l); else l += __shfl_xor(l, 32);
     const float inv_l = 1.0f / l;
     QA_MARK(3)
     f16x8 pf[NKT][2];
@@ -723,7 +725,13 @@ __global__ __launch_bounds__(512) void k_qkv_attention2(const f16* __restrict__ 
                 f16x8 vf = __builtin_shufflevector(lo_h, hi_h, 0, 1, 2, 3, 4, 5, 6, 7);
                 o = mfma_f16(vf, pf[kt][s2], o);
             }
-        if (tok < S) {
+        if constexpr (PERSIST) {
+            // -> the wave's own Q rows (read into qf above, by this wave only; rows 208.. are pad rows), natural d order
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++)
+                *reinterpret_cast<uint2*>(qs_img + k_off(tok, dt * 4 + gq) + 8 * hh) =
+                    pack4_f16(o[4 * gq] * inv_l, o[4 * gq + 1] * inv_l, o[4 * gq + 2] * inv_l, o[4 * gq + 3] * inv_l);
+        } else if (tok < S) {
 #pragma unroll
             for (int gq = 0; gq < 4; gq++) {
                 int dd = dt * 32 + 8 * gq + 4 * hh;
@@ -732,7 +740,38 @@ __global__ __launch_bounds__(512) void k_qkv_attention2(const f16* __restrict__ 
             }
         }
     }
+    if constexpr (PERSIST) {
+        // the tile leaves as whole lines: one wave instruction = 4 query rows x 256 B (the head's 128 features), 16 B per lane, write-through
+        asm volatile("" ::: "memory");                      // the read-back below is of another type than the stores above: no reordering across
+        const int ch = lane & 15;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int row = wave * 32 + 4 * j + (lane >> 4);
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(qs_img + k_off(row, ch));
+            if (row < S) store16_sc1(out + ((size_t)clip * S + row) * MST_D + head * MST_HD + ch * 8, v);
+        }
+    }
     QA_MARK(4)
+    }
+}
+
+template <int NT16>
+__global__ __launch_bounds__(512) void k_qkv_attention2(const f16* __restrict__ hx, const f16* __restrict__ wq,
+                                                        const float* __restrict__ b_in, f16* __restrict__ out, int S) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // (clip, head) of this workgroup: the four heads of a clip share id % 8 = one XCD's L2 (see k_qkv_attention)
+    const int nclip = gridDim.x / MST_H, full = (nclip / 8) * 8 * MST_H;
+    int clip, head;
+    if ((int)blockIdx.x < full) {
+        const int grp = blockIdx.x >> 5, within = blockIdx.x & 31;
+        clip = grp * 8 + (within & 7);
+        head = within >> 3;
+    } else {
+        const int r = blockIdx.x - full;
+        clip = (nclip / 8) * 8 + r / MST_H;
+        head = r % MST_H;
+    }
+    qa2_body<NT16, false>(smem, hx, wq, b_in, out, S, clip, head, GroupSync{nullptr, 0u, nullptr}, false, 0);
 }
 
 }  // namespace mst

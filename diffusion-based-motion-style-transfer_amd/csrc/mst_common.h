@@ -71,6 +71,93 @@ template <int OFF> __device__ __forceinline__ void tail_wload(u32x4& d, unsigned
 template <int N> __device__ __forceinline__ void tail_wwait(u32x4& d) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(d) : "n"(N)); }
 __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
+// ---- hand-offs between the resident workgroups of ONE clip (mst_trunk.h: a persistent launch in which the four workgroups of a clip run
+// head i of the fused QKV + attention phase, then token tile i of the layer tail, layer after layer).  cdna guide 6, Guideline 16, recipe R1:
+// the payload is stored write-through (`sc1`), every storing wave drains (`s_waitcnt vmcnt(0)`), the workgroup meets at a barrier, ONE lane
+// adds to the clip's counter (agent scope); a consumer polls that ONE word (relaxed, `sc1`), has invalidated its L1 once, drains, meets
+// its workgroup at a barrier and then loads.  The invalidate is issued at the END of the consumer's own previous phase, in front of the
+// poll: legal here because the CU reads none of the handed-off lines between that point and the flag (its own stores do not allocate),
+// and 0.4 us cheaper per hand-off (csrc/probes/group_chain.hip, profiles/r05_group_handoff_probe.txt: 2.9-3.9 us per hand-off under
+// the traffic of all 64 groups, every 16-byte chunk tag-checked).  Spins are bounded: a give-up sets *err and lets the launch drain.
+// Lane index recomputed where it is needed (two VALU instructions), never kept in a register across the phases of a resident launch:
+// `threadIdx.x` lives in v0 from kernel entry and would stay allocated (or spilled) through every phase's body.
+__device__ __forceinline__ int lane_id_now() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+// x (+) its partner across the wave halves (lanes l, l ^ 32) / across neighbouring 16-lane rows (l, l ^ 16) for a COMMUTATIVE op, without a
+// lane index: v_permlane32_swap(x, x) leaves {own half's value, other half's value} in its two results in an order that depends on the
+// half -- irrelevant to a + b or max(a, b), whose result is the same bits either way (csrc/probes/probe_permlane.hip has the lane maps).
+// __shfl_xor needs __lane_id(), which hipcc hoists to kernel entry and keeps in a VGPR through every phase of a resident launch.
+__device__ __forceinline__ float xor32_add(float x) {
+    const unsigned a = __builtin_bit_cast(unsigned, x), b = a;
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    const unsigned r0 = r[0], r1 = r[1];          // (hipcc 7.2: __builtin_bit_cast of a vector ELEMENT reads element 0 for every index)
+    return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+}
+__device__ __forceinline__ float xor32_max(float x) {
+    const unsigned a = __builtin_bit_cast(unsigned, x), b = a;
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    return fmaxf(__builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1));
+}
+__device__ __forceinline__ float xor16_add(float x) {
+    const unsigned a = __builtin_bit_cast(unsigned, x), b = a;
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    const unsigned r0 = r[0], r1 = r[1];          // (hipcc 7.2: __builtin_bit_cast of a vector ELEMENT reads element 0 for every index)
+    return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+}
+// A wave-uniform value made opaque to the optimiser AND still known to be uniform: through a VGPR copy that an empty asm statement
+// "modifies", then v_readfirstlane.  (An asm output constrained to "s" is treated as divergent by hipcc's uniformity analysis: address
+// arithmetic on it moves to the VALU and inline-asm "s" operands derived from it silently become VGPRs.)  Used by the phases of a
+// resident launch so that nothing derived from the wave index or a per-layer pointer is hoisted out of the phase loop and kept alive.
+__device__ __forceinline__ int opaque_uniform(int x) {
+    asm volatile("" : "+v"(x));
+    return __builtin_amdgcn_readfirstlane(x);
+}
+template <class T> __device__ __forceinline__ T* opaque_uniform_ptr(T* p) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = (unsigned)opaque_uniform((int)(unsigned)u), hi = (unsigned)opaque_uniform((int)(unsigned)(u >> 32));
+    return (T*)(((unsigned long long)hi << 32) | lo);
+}
+struct GroupSync {
+    unsigned* cnt;                 // the clip's arrival counter (a 128-byte line of its own)
+    unsigned target;               // the value that says "every producer of my input has signalled"
+    unsigned* err;                 // host-visible word: non-zero after a give-up
+};
+typedef __attribute__((address_space(1))) unsigned gu32;
+__device__ __forceinline__ void group_wait(const GroupSync& g, int wave) {
+    if (wave == 0 && lane_id_now() == 0) {
+        unsigned spins = 0;
+        while ((int)(__hip_atomic_load((gu32*)g.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g.target) < 0) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 23)) { __hip_atomic_store((gu32*)g.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the poll's loads and the invalidate issued by group_signal() in front of them
+    }
+    __builtin_amdgcn_s_barrier();
+}
+// reset_at: the count that says "this was the clip's last arrival of the launch" -- whoever brings the counter there puts it back to 0 (nobody
+// polls it any more: the launch's last phase has no consumer inside the launch), so every launch finds every counter at 0.
+__device__ __forceinline__ void group_signal(unsigned* cnt, int wave, unsigned reset_at) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores; LDS reads are done
+    __builtin_amdgcn_s_barrier();
+    if (wave == 0 && lane_id_now() == 0) {
+        const unsigned old = __hip_atomic_fetch_add((gu32*)cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1u == reset_at) __hip_atomic_store((gu32*)cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");        // this CU's L1 copies of what its partners are rewriting: dropped before the next poll
+    }
+}
+// 16- / 8-byte write-through stores (the trailing s_nop: cdna guide 5.7 item 1, the data registers may be reused right behind an asm store)
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store16_sc1(void* p, u32x4_t v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void store8_sc1(void* p, uint2 v) {
+    const u32x2_t w = {v.x, v.y};
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
+}
+
 // y -> (hi, lo) f16 pairs with hi = f16(y), lo = f16(y - hi): the stream's storage format (~22 significant bits)
 __device__ __forceinline__ void split4_f16(const f32x4& y, uint2& hi, uint2& lo) {
     f16x4 h = {(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};

@@ -19,6 +19,7 @@
 #include "mst_elem.h"
 #include "mst_gemm_dma.h"
 #include "mst_tail.h"
+#include "mst_trunk.h"
 #ifdef EMB_PROBE            // diagnostic build only (tools/r4_embed_stamps.sh): wave 0..7 of every workgroup stamp the 100 MHz clock at the phase marks
 __device__ unsigned long long g_emb_stamp[512][8][8];
 #define EMB_MARK(i) if ((threadIdx.x & 63) == 0 && blockIdx.x < 512) g_emb_stamp[blockIdx.x][threadIdx.x >> 6][i] = __builtin_amdgcn_s_memrealtime();
@@ -195,6 +196,10 @@ struct mst_engine {
     int fuse_tail = 1;                    // K6 + K7 + K8 as one kernel per 64-token tile (mst_tail.h); MST_FUSE_TAIL=0 keeps them apart
     int tail_ntb = 0;                     // fused layer tail: 16-token blocks per tile; 0 = per launch (launch_tail), MST_TAIL_NTB=2..4 fixes it
     int cur_slices = 1;                   // clip slices the launches being enqueued share the chip with (mst_sample_loop; 1 = a lone launch sequence)
+    int trunk_groups = 0;                 // MST_TRUNK=1: the encoder stack of a sampling step as ONE launch of resident workgroup groups (mst_trunk.h)
+    unsigned* trunk_cnt = nullptr;        // [max_rows][32]: a clip's arrival counter (one 128-byte line each); every launch finds it at 0 and leaves it at 0
+    unsigned* trunk_err = nullptr;        // pinned host word the kernel sets when a bounded spin gives up (mst_trunk_check)
+    void* trunk_layers = nullptr;         // TrunkLayer[num_layers] in device memory: the layers' pointers (fixed at creation), uploaded at the first such launch
     int fuse_frames = 1;                  // sampling loop: a step's epilogue writes the next step's f16 frame rows; MST_FUSE_FRAMES=0 runs k_frames_f16 every step
     int precise = 0;                      // mst_set_precise / MST_PRECISE=1: every layer GEMM of the sampling path multiplies its activation as hi + lo (the small-tile
                                           // kernels at any size, ~2x their MFMA work): for checkpoints whose outlier channels put f16 operands above the 1e-3 bar
@@ -386,6 +391,10 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     if (const char* v = getenv("MST_SMALL_M")) e->small_m = atoi(v);
     if (const char* v = getenv("MST_PRECISE")) e->precise = atoi(v) != 0;
     if (const char* v = getenv("MST_LN128_M")) e->ln128_min_m = atoi(v);
+    if (const char* v = getenv("MST_TRUNK")) e->trunk_groups = atoi(v) != 0;
+    CHECK(dmalloc(&e->trunk_cnt, (size_t)c->max_rows * 32));
+    HIPCHECK(hipHostMalloc((void**)&e->trunk_err, 64, hipHostMallocDefault));
+    e->trunk_err[0] = 0;
     CHECK(dmalloc(&e->zacc, (size_t)e->M_pad * MST_D));
     CHECK(dmalloc(&e->ld_dev, 1));
     CHECK(dmalloc(&e->rowflag, (size_t)c->max_rows * c->feats));
@@ -425,6 +434,9 @@ extern "C" void mst_engine_destroy(mst_engine* e) {
         if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]);
     }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->trunk_cnt) (void)hipFree(e->trunk_cnt);
+    if (e->trunk_layers) (void)hipFree(e->trunk_layers);
+    if (e->trunk_err) (void)hipHostFree(e->trunk_err);
     if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
     if (e->loop_stream) (void)hipStreamDestroy(e->loop_stream);
     if (e->ev_in) (void)hipEventDestroy(e->ev_in);
@@ -939,6 +951,42 @@ static int launch_tail(const mst_engine* e, const LayerW& w, const WS& ws, int M
     return 0;
 }
 
+// The whole stack of a sampling step as one launch of resident groups (mst_trunk.h): frame counts whose token count is 13 blocks of 16
+// (193 .. 208 tokens: the model's 196 frames), the default fused kernels, no debug stop, no instrumented step, at most 8 layers.
+static bool trunk_groups_fit(const mst_engine* e, int S) {
+    return e->trunk_groups && (S + 15) / 16 == 13 && e->fuse_qkv_attn == 1 && e->fuse_tail && e->tail_ntb == 0 && e->dbg_stage < 0 && !e->precise &&
+           e->cfg.num_layers <= 8;
+}
+static int launch_trunk_groups(mst_engine* e, const WS& ws, int S, int rows, hipStream_t st) {
+    using TT = TrunkTile<13>;
+    if (e->trunk_err[0]) return fail("resident-group trunk: a hand-off wait gave up in an earlier launch (results of that loop are invalid)");
+    TrunkArgs a{};
+    if (!e->trunk_layers) {
+        TrunkLayer tab[8];
+        for (int l = 0; l < e->cfg.num_layers; l++) {
+            const LayerW& w = e->L[l];
+            tab[l] = TrunkLayer{w.wqkv, w.b_in, w.wtail, w.b_out, w.g1, w.be1, w.b1, w.b2, w.g2, w.be2};
+        }
+        HIPCHECK(hipMalloc(&e->trunk_layers, sizeof(tab)));
+        HIPCHECK(hipMemcpy(e->trunk_layers, tab, sizeof(tab), hipMemcpyHostToDevice));
+    }
+    a.L = static_cast<const TrunkLayer*>(e->trunk_layers);
+    a.hx = ws.hx; a.hl = ws.hl; a.att = ws.att; a.gelu_tab = e->gelu_tab;
+    a.cnt = e->trunk_cnt + (size_t)((ws.hx - e->hx) / ((size_t)S * MST_D)) * 32;       // the slice's first clip
+    a.err = e->trunk_err;
+    a.S = S; a.nclips = rows; a.nlayers = e->cfg.num_layers;
+    const int groups = rows < 64 ? rows : 64;
+    CHECK(ensure_dyn_lds((const void*)k_trunk_groups<13>, TT::SMEM));
+    hipLaunchKernelGGL(k_trunk_groups<13>, dim3(4 * groups), dim3(512), TT::SMEM, st, a);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+extern "C" int mst_trunk_check(mst_engine* e) {          // after a synchronisation: did every hand-off of the resident-group launches arrive?
+    if (!e) return fail("mst_trunk_check: null engine");
+    if (e->trunk_err[0]) return fail("resident-group trunk: a hand-off wait gave up");
+    return 0;
+}
+
 // K3 .. K8: token stream through the encoder stack.  rows = clips through the transformer.
 // K1-K3: conditioning token + pose embedding of the frames -> token stream rows (ws.hx / ws.hl)
 struct LoopRef { const LoopDev* ld = nullptr; int joff = 0; unsigned long long eo = 0; bool frames_ready = false; bool stream_ready = false; };   // stream_ready: the previous step's k_embed_out already embedded this step (token stream and conditioning tokens are in ws.hx / ws.hl)   // frames_ready: the previous step's epilogue already wrote ws.xt   // loop mode of a step's kernels (see LoopDev)
@@ -1073,6 +1121,10 @@ static int run_trunk(mst_engine* e, const WS& ws, const float* x, int clips_x, i
             HIPCHECK(hipGetLastError());
         }
         DBG_STOP(5)
+    }
+    if (!small && !e->prof_now && trunk_groups_fit(e, S)) {
+        CHECK(launch_trunk_groups(e, ws, S, rows, st));
+        return 0;
     }
     for (int l = 0; !small && l < e->cfg.num_layers; l++) {
         const LayerW& w = e->L[l];
@@ -1263,6 +1315,7 @@ static int loop_slices_for(const mst_engine* e, int batch, int cfg, int frames) 
     if (!e || e->dbg_stage >= 0) return 1;
     const int rows = (cfg ? 2 : 1) * batch;
     int n = e->nsplit;
+    if (n == 0 && trunk_groups_fit(e, frames + 1) && !(e->small_m > 0 && (long long)rows * (frames + 1) <= e->small_m)) return 1;   // every clip is a chain of its own inside ONE launch
     if (n == 0) {
         const long long M = (long long)rows * (frames + 1);
         const bool small = e->precise || (e->small_m > 0 && M <= e->small_m);
@@ -2210,6 +2263,17 @@ extern "C" int mst_set_precise(mst_engine* e, int32_t on) {
 }
 
 // ------------------------------------------------------------------------------------------ debug ABI
+extern "C" int mst_set_trunk_groups(mst_engine* e, int32_t on) {
+    if (!e) return fail("mst_set_trunk_groups: null engine");
+    e->trunk_groups = on != 0;
+    if (e->trunk_err[0]) {                   // after a give-up: the counters hold whatever the abandoned launch left -- start clean
+        ON_DEVICE(e->cfg.device);
+        HIPCHECK(hipDeviceSynchronize());
+        HIPCHECK(hipMemset(e->trunk_cnt, 0, (size_t)e->cfg.max_rows * 32 * sizeof(unsigned)));
+        e->trunk_err[0] = 0;
+    }
+    return 0;
+}
 extern "C" int mst_debug_stop_after(mst_engine* e, int32_t layer, int32_t stage) {
     if (!e) return fail("mst_debug_stop_after: null engine");
     e->dbg_layer = layer;

@@ -126,20 +126,27 @@ __device__ __forceinline__ void tail_glds1(unsigned voff, unsigned long long sba
 // a lone launch of fewer tokens.  A tile streams all 2.5 MB of the layer through its CU's L1 (64 B / clk: 41 k cycles) whatever its
 // height; at 64 tokens its MFMA work is another 41 k cycles on every SIMD.  csrc/probes/tail_clock.hip, 4 334 tokens alone on the
 // chip: 64-token tiles (68 workgroups) 37.5 us per launch, 48-token (91) 32.6 us, 32-token (136) 30.4 us.
-template <int NTB>
-__global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att, const f16* __restrict__ wt,
-                                                    const float* __restrict__ b_out, const float* __restrict__ g1, const float* __restrict__ be1,
-                                                    const float* __restrict__ b1, const float* __restrict__ b2,
-                                                    const float* __restrict__ g2, const float* __restrict__ be2,
-                                                    f16* __restrict__ hx, f16* __restrict__ hl, const float* __restrict__ gelu_tab, int M) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// The kernel's body for the tile that starts at token row tok0 (rows >= M are clamped on load and never stored).  k_layer_tail = one call per
+// workgroup; the resident-group trunk (mst_trunk.h) calls it once per layer with PERSIST = true: the tables, the FFN1 bias and the first D
+// weight fragments are requested, THEN the workgroup waits for its clip's four attention heads (group_wait) and only then requests its
+// att rows; LayerNorm2's rows leave as write-through stores.
+template <int NTB, bool PERSIST>
+__device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ att, const f16* __restrict__ wt,
+                                          const float* __restrict__ b_out, const float* __restrict__ g1, const float* __restrict__ be1,
+                                          const float* __restrict__ b1, const float* __restrict__ b2,
+                                          const float* __restrict__ g2, const float* __restrict__ be2,
+                                          f16* __restrict__ hx, f16* __restrict__ hl, const float* __restrict__ gelu_tab, int M, int tok0,
+                                          const GroupSync sync, int wave_in) {
     using C = TailCfg;
     constexpr int D = C::D;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // (PERSIST: the lane index is recomputed in every phase and the wave index arrives in a scalar register, so that no per-lane
+    // constant stays alive across the other phases' bodies)
+    int lane, wave;
+    if constexpr (PERSIST) { lane = lane_id_now(); wave = opaque_uniform(wave_in); }      // (opaque: nothing derived from it is hoisted out of the phase loop)
+    else { lane = threadIdx.x & 63; wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
+    const int tid = wave * 64 + lane;
     const int t16 = lane & 15, q4 = lane >> 4;                       // accumulator map: token 16 tb + t16, features .. + 4 q4 + i
     constexpr int BT = 16 * NTB, RPW = 2 * NTB;                      // tile rows; rows per wave in the row-wise stages (DMA, LayerNorm2)
-    const int tok0 = blockIdx.x * BT;
     const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     TAIL_MARK(0)
 
@@ -171,14 +178,17 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
         }
     };
     constexpr int ROW_OPS = RPW;
+    auto att_rows = [&]() {
 #pragma unroll
-    for (int j = 0; j < RPW; j++) {
-        const int r = RPW * wave + j;
-        int tok = tok0 + r;
-        if (tok >= M) tok = M - 1;
-        const unsigned voff = (unsigned)tok * (unsigned)(MST_D * 2) + (unsigned)((lane ^ (r & 15)) << 4);
-        tail_glds1(voff, (unsigned long long)att, __builtin_amdgcn_readfirstlane(smem_base + C::OFF_ATT + r * 1024));
-    }
+        for (int j = 0; j < RPW; j++) {
+            const int r = RPW * wave + j;
+            int tok = tok0 + r;
+            if (tok >= M) tok = M - 1;
+            const unsigned voff = (unsigned)tok * (unsigned)(MST_D * 2) + (unsigned)((lane ^ (r & 15)) << 4);
+            tail_glds1(voff, (unsigned long long)att, __builtin_amdgcn_readfirstlane(smem_base + C::OFF_ATT + r * 1024));
+        }
+    };
+    if constexpr (!PERSIST) att_rows();
     if (wave < 4) tail_glds1((unsigned)lane * 16u, (unsigned long long)(b1 + 256 * wave), __builtin_amdgcn_readfirstlane(smem_base + C::OFF_B1 + 1024 * wave));
     tail_glds1((unsigned)lane * 16u, (unsigned long long)(gelu_tab + 256 * wave), __builtin_amdgcn_readfirstlane(smem_base + C::OFF_TAB + 1024 * wave));
     if (wave < 5) tail_glds1((unsigned)lane * 16u, (unsigned long long)(gelu_tab + 256 * (8 + wave)), __builtin_amdgcn_readfirstlane(smem_base + C::OFF_TAB + 1024 * (8 + wave)));
@@ -280,7 +290,13 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
         for (int rb = 0; rb < 2; rb++)
 #pragma unroll
             for (int tb = 0; tb < NTB; tb++) acc[nh][rb][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D + 1) : "memory");       // this wave's att rows have landed (behind them: 1 .. 3 table pieces and the D fragments)
+    if constexpr (PERSIST) {
+        group_wait(sync, wave);                                        // the clip's four heads have written att (and this CU holds no stale copy)
+        att_rows();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the att rows are the YOUNGEST operations here: tables and fragments landed long ago
+    } else {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D + 1) : "memory");   // this wave's att rows have landed (behind them: 1 .. 3 table pieces and the D fragments)
+    }
     tail_barrier();                                                    // ... and everybody's
     TAIL_MARK(1)
     {
@@ -340,6 +356,7 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
                 }
             }
         auto quad_sum = [](float v) {                                  // over the four q4 groups (lanes l, l ^ 16, l ^ 32, l ^ 48)
+            if constexpr (PERSIST) return xor32_add(xor16_add(v));     // (the same two additions: a + b is commutative bit for bit)
             v += __shfl_xor(v, 16);
             return v + __shfl_xor(v, 32);
         };
@@ -516,16 +533,32 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
                 const size_t off = (size_t)tok * MST_D;
                 uint2 h, l;
                 split4_f16(xa[r] * (ga * rstd[r]) + ea, h, l);
-                *reinterpret_cast<uint2*>(hx + off + fa) = h;
-                *reinterpret_cast<uint2*>(hl + off + fa) = l;
+                if constexpr (PERSIST) { store8_sc1(hx + off + fa, h); store8_sc1(hl + off + fa, l); }
+                else {
+                    *reinterpret_cast<uint2*>(hx + off + fa) = h;
+                    *reinterpret_cast<uint2*>(hl + off + fa) = l;
+                }
                 split4_f16(xb[r] * (gb * rstd[r]) + eb, h, l);
-                *reinterpret_cast<uint2*>(hx + off + fb) = h;
-                *reinterpret_cast<uint2*>(hl + off + fb) = l;
+                if constexpr (PERSIST) { store8_sc1(hx + off + fb, h); store8_sc1(hl + off + fb, l); }
+                else {
+                    *reinterpret_cast<uint2*>(hx + off + fb) = h;
+                    *reinterpret_cast<uint2*>(hl + off + fb) = l;
+                }
             }
         }
     }
     TAIL_MARK(5)
 #undef TAIL_ISSUE
+}
+
+template <int NTB>
+__global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att, const f16* __restrict__ wt,
+                                                    const float* __restrict__ b_out, const float* __restrict__ g1, const float* __restrict__ be1,
+                                                    const float* __restrict__ b1, const float* __restrict__ b2,
+                                                    const float* __restrict__ g2, const float* __restrict__ be2,
+                                                    f16* __restrict__ hx, f16* __restrict__ hl, const float* __restrict__ gelu_tab, int M) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    tail_body<NTB, false>(smem, att, wt, b_out, g1, be1, b1, b2, g2, be2, hx, hl, gelu_tab, M, blockIdx.x * (16 * NTB), GroupSync{nullptr, 0u, nullptr}, 0);
 }
 
 }  // namespace mst

@@ -371,6 +371,14 @@ class DenoiserEngine:
             rc = 0
         N.check(rc)
 
+    def set_trunk_groups(self, on=True):
+        """The encoder stack of a sampling step as ONE launch of resident workgroup groups (csrc/mst_trunk.h); bit-identical results."""
+        N.check(N.lib().mst_set_trunk_groups(self.handle, int(bool(on))))
+
+    def trunk_check(self):
+        """After a synchronisation: raises when a hand-off wait of a resident-group launch gave up."""
+        N.check(N.lib().mst_trunk_check(self.handle))
+
     def debug_stop_after(self, layer=-1, stage=-1):
         N.check(N.lib().mst_debug_stop_after(self.handle, layer, stage))
 

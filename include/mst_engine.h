@@ -344,6 +344,15 @@ int mst_profile_read(mst_engine* e, const char** names, float* total_ms, int32_t
  * mst_sample_loop fail until then). */
 int mst_set_precise(mst_engine* e, int32_t on);
 
+/* Resident-group trunk (no reference counterpart; csrc/mst_trunk.h).  on != 0: a sampling step's encoder stack (the 8 x [fused QKV +
+ * attention, fused layer tail] of model/mdm_forstyledataset.py:539-546, 602-625) runs as ONE launch in which the four workgroups of a
+ * clip stay resident and hand their phase outputs to each other through a per-clip arrival counter; shapes it does not cover (token
+ * counts other than 193 .. 208, precise mode, debug stops, instrumented steps) keep the two launches per layer.  Results are
+ * bit-identical either way.  Also MST_TRUNK=1 / 0.  mst_trunk_check: after the caller has synchronised, 0 when every hand-off of every
+ * such launch arrived (a bounded wait that gives up sets a host-visible word instead of hanging the device). */
+int mst_set_trunk_groups(mst_engine* e, int32_t on);
+int mst_trunk_check(mst_engine* e);
+
 /* Debug / test hooks (no reference counterpart): stop the encoder stack after (layer, stage) --
  * stage 0 = token stream assembled, 1 = QKV, 2 = attention, 3 = out-proj + LayerNorm1, 4 = FFN1,
  * 5 = FFN2 + LayerNorm2; layer = stage = -1 runs everything -- and copy a workspace buffer
