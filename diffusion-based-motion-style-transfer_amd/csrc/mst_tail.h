@@ -373,7 +373,7 @@ __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ at
 #pragma unroll
                 for (int rb = 0; rb < 2; rb++) {
                     const f32x4 d = acc[nh][rb][tb] - mw[tb];
-                    sq += d * d;
+                    sq = __builtin_elementwise_fma(d, d, sq);
                 }
             m2[tb] = quad_sum((sq[0] + sq[1]) + (sq[2] + sq[3]));
             if (q4 == 0) exch[wave * 64 + 16 * tb + t16] = make_float2(mw[tb], m2[tb]);
@@ -388,7 +388,9 @@ __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ at
             const float mu = (((e0.x + e1.x) + (e2.x + e3.x)) + ((e4.x + e5.x) + (e6.x + e7.x))) * 0.125f;
             const float d0 = e0.x - mu, d1 = e1.x - mu, d2 = e2.x - mu, d3 = e3.x - mu, d4 = e4.x - mu, d5 = e5.x - mu, d6 = e6.x - mu, d7 = e7.x - mu;
             const float within = ((e0.y + e1.y) + (e2.y + e3.y)) + ((e4.y + e5.y) + (e6.y + e7.y));
-            const float between = ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + ((d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7));
+            // (every multiply-add spelled as an fma: under -ffp-contract=fast hipcc fuses `a * a + b * b` either way round, and which way has
+            // differed between the tile-height instantiations of this function -- they must agree bit for bit)
+            const float between = (fmaf(d0, d0, d1 * d1) + fmaf(d2, d2, d3 * d3)) + (fmaf(d4, d4, d5 * d5) + fmaf(d6, d6, d7 * d7));
             mean[tb] = mu;
             rstd[tb] = ln_rstd(fmaf(64.0f, between, within));
         }
@@ -400,7 +402,7 @@ __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ at
                 const f32x4 g = *reinterpret_cast<const f32x4*>(g1 + f), be = *reinterpret_cast<const f32x4*>(be1 + f);
 #pragma unroll
                 for (int tb = 0; tb < NTB; tb++) {
-                    const f32x4 y = (acc[nh][rb][tb] - mean[tb]) * (g * rstd[tb]) + be;
+                    const f32x4 y = __builtin_elementwise_fma(acc[nh][rb][tb] - mean[tb], g * rstd[tb], be);
                     acc[nh][rb][tb] = y;
                     *reinterpret_cast<uint2*>(x1img + slot1k(nh, rb, tb)) = pack4_f16(y[0], y[1], y[2], y[3]);
                 }
@@ -523,7 +525,8 @@ __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ at
         for (int r = 0; r < RPW; r++) {
             xa[r] -= mean[r];
             xb[r] -= mean[r];
-            const f32x4 sq = xa[r] * xa[r] + xb[r] * xb[r];
+            const f32x4 sq = {fmaf(xa[r][0], xa[r][0], xb[r][0] * xb[r][0]), fmaf(xa[r][1], xa[r][1], xb[r][1] * xb[r][1]),
+                              fmaf(xa[r][2], xa[r][2], xb[r][2] * xb[r][2]), fmaf(xa[r][3], xa[r][3], xb[r][3] * xb[r][3])};
             rstd[r] = ln_rstd(wave_sum((sq[0] + sq[1]) + (sq[2] + sq[3])));
         }
 #pragma unroll
@@ -532,13 +535,13 @@ __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ at
             if (tok < M) {
                 const size_t off = (size_t)tok * MST_D;
                 uint2 h, l;
-                split4_f16(xa[r] * (ga * rstd[r]) + ea, h, l);
+                split4_f16(__builtin_elementwise_fma(xa[r], ga * rstd[r], ea), h, l);
                 if constexpr (PERSIST) { store8_sc1(hx + off + fa, h); store8_sc1(hl + off + fa, l); }
                 else {
                     *reinterpret_cast<uint2*>(hx + off + fa) = h;
                     *reinterpret_cast<uint2*>(hl + off + fa) = l;
                 }
-                split4_f16(xb[r] * (gb * rstd[r]) + eb, h, l);
+                split4_f16(__builtin_elementwise_fma(xb[r], gb * rstd[r], eb), h, l);
                 if constexpr (PERSIST) { store8_sc1(hx + off + fb, h); store8_sc1(hl + off + fb, l); }
                 else {
                     *reinterpret_cast<uint2*>(hx + off + fb) = h;
