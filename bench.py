@@ -415,19 +415,38 @@ def finetune_flops(B):
     return 3 * 7.353e9 * (B + 6) + 2 * 7.3e9 * B
 
 
-def finetune_roofline(B, world, s_per_iter):
-    """Whole-iteration MFMA roofline (the kernels have no per-launch events on the training path) + the dominant kernel by rocprof
-    symbol with its average duration, read from the committed summary of the SAME command under rocprofv3 (tools/finetune_profile.sh
-    -> profiles/r03_finetune_kernel_stats_streams1.csv), when that file is present."""
+def wgrad_flops(B):
+    """Algorithmic FLOPs of all k_wgrad_tr launches of ONE iteration: dW = dY^T X over the token rows of every trainable pass (the B-clip
+    call and the six chained single-clip steps, differentiated in one pass), four weight matrices per layer, eight layers."""
+    rows = (B + 6) * 197
+    return 8 * 2.0 * rows * (1536 * 512 + 512 * 512 + 2 * 1024 * 512)
+
+
+def finetune_roofline(B, world, s_per_iter, wgrad=None):
+    """Whole-iteration MFMA roofline + the training path's dominant kernel (k_wgrad_tr by rocprofv3 share, profiles/r0*_finetune_kernel_
+    stats_streams1.csv), timed IN THIS RUN with HIP events on the stream it is launched on (`wgrad`: total ms, launches, event-pair
+    overhead of a few extra iterations behind the timed region); the committed rocprofv3 summary of an earlier run stays beside it."""
     fl = finetune_flops(B)
     achieved = world * fl / s_per_iter * 1e-12
     out = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS * world, "unit": "TFLOP/s",
            "frac": round(achieved / (MFMA_PEAK_TFLOPS * world), 4), "traffic": None,
            "algorithmic_gflop_per_iteration_per_gpu": round(fl * 1e-9, 1),
            "kernel": None, "note": "whole iteration (objective + backward + AdamW) over the dense MFMA peak"}
-    # The dominant kernel is NOT measured in this run: what follows is read from a committed rocprofv3 summary of another command
-    # (tools/finetune_bench.py under the profiler), possibly another build -- kept apart under `reference_profile`, with the file's hash.
-    for name in ("r04_finetune_kernel_stats_streams1.csv", "r03_finetune_kernel_stats_streams1.csv"):
+    if wgrad and wgrad.get("launches"):
+        n, iters = wgrad["launches"], wgrad["iterations"]
+        avg_us = 1e3 * wgrad["total_ms"] / n - wgrad["event_pair_overhead_us"]
+        tflops = wgrad_flops(B) * iters / (avg_us * 1e-6 * n) * 1e-12
+        out["kernel"] = "k_wgrad_tr"
+        out["dominant_kernel"] = {
+            "kernel": "k_wgrad_tr (weight gradients dW = dY^T X, both operands read transposed from row-major activations)",
+            "measured": f"HIP events on the launch stream around every launch of {iters} extra iterations behind the timed region",
+            "launches_timed": n, "launches_per_iteration": n // iters, "avg_launch_us": round(avg_us, 2),
+            "event_pair_overhead_us_subtracted": round(wgrad["event_pair_overhead_us"], 2),
+            "algorithmic_gflop_per_iteration": round(wgrad_flops(B) * 1e-9, 1), "achieved_tflops": round(tflops, 1),
+            "frac_of_mfma_peak": round(tflops / MFMA_PEAK_TFLOPS, 4)}
+    # A committed rocprofv3 summary of the same command from an earlier run (possibly another build), with the file's hash: the share of
+    # device time that names the dominant kernel comes from there.
+    for name in ("r05_finetune_kernel_stats_streams1.csv", "r04_finetune_kernel_stats_streams1.csv", "r03_finetune_kernel_stats_streams1.csv"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             import csv
@@ -530,6 +549,25 @@ def finetune_main(args):
                 "exposed_ms": round(1e3 * exposed / args.steps, 3),
                 "fraction_hidden": round(1.0 - min(1.0, exposed / dt_ar), 3) if dt_ar > 0 else None,
                 "launched_during_backward": red.launched_in.count("backward"), "launched_after_backward": red.launched_in.count("flush")}
+    wgrad = None
+    if rank == 0 and dev.type == "cuda":
+        # the dominant kernel, timed in this run: a few MORE iterations with every k_wgrad_tr launch bracketed by HIP events
+        try:
+            engines = [ent["eng"] for ent in model.__dict__.get("_mst_engines", {}).values()]      # the module's engine + the chain's own instance
+            for eng in engines:
+                eng.profile(True, 1)
+            for _ in range(3):
+                iteration(reduce=False)
+            torch.cuda.synchronize(dev)
+            tot, n, ov = 0.0, 0, 0.0
+            for eng in engines:
+                ms, k = eng.profile_read().get("wgrad_tr", (0.0, 0))
+                tot, n, ov = tot + ms, n + k, max(ov, eng.profile_event_overhead_us())
+                eng.profile(False)
+            if n:
+                wgrad = {"total_ms": tot, "launches": n, "iterations": 3, "event_pair_overhead_us": ov}
+        except Exception as exc:                                  # never lose the bench line to the instrumentation
+            wgrad = {"error": repr(exc)[:200]}
     if rank == 0:
         value = world * B * args.steps / dt
         line = {"metric": "fine-tune text-to-motion clips/sec (few_shot_style_finetune_losses, ddim20 / skip 700, Bx263x196)",
@@ -540,7 +578,7 @@ def finetune_main(args):
                            "6 chained single-clip steps + frozen motion encoder + backward + AdamW per iteration",
                            "global_batch": world * B, "parallelism": f"dp{world}, 8 per-layer gradient buckets, all-reduce overlapped with backward"},
                 "iterations_per_s": round(args.steps / dt, 3), "final_loss": round(loss, 5), "allreduce": comm}
-        line["roofline"] = finetune_roofline(B, world, dt / args.steps)
+        line["roofline"] = finetune_roofline(B, world, dt / args.steps, wgrad)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -16,6 +16,14 @@
 #include "mst_common.h"
 #include "mst_gemm_dma.h"   // ring_off, DmaPlan, wait_vmcnt
 
+#ifndef MST_QA_OUT
+// k_qkv_attention2's output stores.  0: 8 bytes per lane straight from the accumulator layout (rounds 2-4: partial 128-byte lines; written
+// through they cost 25.9 -> 30.3 us per launch, round 3).  1: through the wave's own (dead) Q rows, then 16 bytes per lane = whole lines,
+// plain.  2 (default since round 5): those whole-line stores write-through (`sc1`), which takes the 12.9 MB of att out of the dirty bytes
+// the launch boundary waits for (profiles/r03_launch_boundary_probe.txt).  Same-box A/B of three library builds, three interleaved
+// rounds (tools/r5_qa_out_ab.sh, profiles/r05_ab_attention_output_stores.txt): 104.85 / 104.48 / 105.42 clips/s for 0 / 1 / 2.
+#define MST_QA_OUT 2
+#endif
 #ifndef QA_MARK              // probes/attn_clock.hip defines it (under MST_PROBE_BUILD) to stamp the phases; the product build has none
 #define QA_MARK(i)
 #endif
@@ -725,7 +733,7 @@ __device__ __forceinline__ void qa2_body(char* smem, const f16* __restrict__ hx,
                 f16x8 vf = __builtin_shufflevector(lo_h, hi_h, 0, 1, 2, 3, 4, 5, 6, 7);
                 o = mfma_f16(vf, pf[kt][s2], o);
             }
-        if constexpr (PERSIST) {
+        if constexpr (PERSIST || MST_QA_OUT != 0) {
             // -> the wave's own Q rows (read into qf above, by this wave only; rows 208.. are pad rows), natural d order
 #pragma unroll
             for (int gq = 0; gq < 4; gq++)
@@ -740,7 +748,7 @@ __device__ __forceinline__ void qa2_body(char* smem, const f16* __restrict__ hx,
             }
         }
     }
-    if constexpr (PERSIST) {
+    if constexpr (PERSIST || MST_QA_OUT != 0) {
         // the tile leaves as whole lines: one wave instruction = 4 query rows x 256 B (the head's 128 features), 16 B per lane, write-through
         asm volatile("" ::: "memory");                      // the read-back below is of another type than the stores above: no reordering across
         const int ch = lane & 15;
@@ -748,7 +756,11 @@ __device__ __forceinline__ void qa2_body(char* smem, const f16* __restrict__ hx,
         for (int j = 0; j < 8; j++) {
             const int row = wave * 32 + 4 * j + (lane >> 4);
             const u32x4_t v = *reinterpret_cast<const u32x4_t*>(qs_img + k_off(row, ch));
-            if (row < S) store16_sc1(out + ((size_t)clip * S + row) * MST_D + head * MST_HD + ch * 8, v);
+            f16* dst = out + ((size_t)clip * S + row) * MST_D + head * MST_HD + ch * 8;
+            if (row < S) {
+                if constexpr (PERSIST || MST_QA_OUT == 2) store16_sc1(dst, v);
+                else *reinterpret_cast<u32x4_t*>(dst) = v;
+            }
         }
     }
     QA_MARK(4)

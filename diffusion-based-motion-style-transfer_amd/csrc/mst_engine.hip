@@ -155,10 +155,10 @@ struct TrainWS {
     size_t split_cap = 0;
 };
 
-enum Family { FAM_COND = 0, FAM_EMBED_IN, FAM_QKV, FAM_ATTN, FAM_OUTPROJ_LN, FAM_FFN1, FAM_FFN2_LN, FAM_EMBED_OUT, FAM_QKV_ATTN, FAM_TAIL, FAM_COUNT };
+enum Family { FAM_COND = 0, FAM_EMBED_IN, FAM_QKV, FAM_ATTN, FAM_OUTPROJ_LN, FAM_FFN1, FAM_FFN2_LN, FAM_EMBED_OUT, FAM_QKV_ATTN, FAM_TAIL, FAM_WGRAD, FAM_COUNT };
 static const char* kFamilyNames[FAM_COUNT] = {"cond_token", "embed_in", "qkv_gemm", "attention", "outproj_ln_gemm",
                                               "ffn1_gelu_gemm", "ffn2_ln_gemm", "embed_out_step", "qkv_attention_fused",
-                                              "layer_tail_fused"};
+                                              "layer_tail_fused", "wgrad_tr"};
 
 struct ProfPoint { int fam; hipEvent_t a, b; };
 
@@ -1851,13 +1851,25 @@ static int wgrad(mst_engine* e, const f16* dY, int n_out, const f16* X, int k_in
     CHECK(ensure_dyn_lds((const void*)kern, WgTile::SMEM));
     static_assert(DEpiF32::smem_bytes<128, 256>() <= WgTile::SMEM, "epilogue tile must fit the ring");
     const size_t nelem = (size_t)n_out * k_in;
+    // profiling on (mst_profile_enable): every k_wgrad_tr launch of a training pass is bracketed by HIP events on ITS stream (bench.py --mode
+    // finetune reads the family "wgrad_tr": the training path's dominant kernel, timed in the run that reports it)
+    const int prof_keep = e->prof_now;
+    e->prof_now = e->prof_on;
     if (nsplit == 1) {
         DEpiF32 epi{dW, dW, k_in, n_out, t.gscale};
-        hipLaunchKernelGGL(kern, dim3(n_out / 128, k_in / 256, 1), dim3(512), WgTile::SMEM, st, dY, n_out, X, k_in, M, kchunk, nelem, epi);
+        {
+            ProfScope ps(e, FAM_WGRAD, st);
+            hipLaunchKernelGGL(kern, dim3(n_out / 128, k_in / 256, 1), dim3(512), WgTile::SMEM, st, dY, n_out, X, k_in, M, kchunk, nelem, epi);
+        }
+        e->prof_now = prof_keep;
         HIPCHECK(hipGetLastError());
     } else {
         DEpiF32 epi{nullptr, t.part, k_in, n_out};
-        hipLaunchKernelGGL(kern, dim3(n_out / 128, k_in / 256, nsplit), dim3(512), WgTile::SMEM, st, dY, n_out, X, k_in, M, kchunk, nelem, epi);
+        {
+            ProfScope ps(e, FAM_WGRAD, st);
+            hipLaunchKernelGGL(kern, dim3(n_out / 128, k_in / 256, nsplit), dim3(512), WgTile::SMEM, st, dY, n_out, X, k_in, M, kchunk, nelem, epi);
+        }
+        e->prof_now = prof_keep;
         HIPCHECK(hipGetLastError());
         hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((nelem / 4 + 255) / 256)), dim3(256), 0, st, t.part, nsplit, nelem, t.gscale, dW);
         HIPCHECK(hipGetLastError());
