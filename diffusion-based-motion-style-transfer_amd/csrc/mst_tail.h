@@ -30,6 +30,10 @@
 #include "mst_common.h"
 #include "mst_gemm_dma.h"
 
+#ifndef MST_TAIL_OUT
+#define MST_TAIL_OUT 0        // k_layer_tail's LayerNorm2 stores: 0 = 8 bytes per lane, plain; 1 = those write-through; 2 = 16 bytes per lane (a lane holds
+                              // 8 consecutive features), plain; 3 = those write-through (tools/r5_tail_out_ab.sh)
+#endif
 #ifndef TAIL_MARK            // probes/tail_clock.hip defines it (with MST_PROBE_BUILD) to stamp the phases; the product build has none
 #define TAIL_MARK(i)
 #endif
@@ -507,7 +511,10 @@ __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ at
                     *reinterpret_cast<f32x4*>(trow + (256 * nh + 32 * wave + 16 * rb + 4 * q4) * 4) = acc[nh][rb][tb];
         }
         tail_barrier();
-        const int fa = lane * 4, fb = 256 + lane * 4;
+        // MST_TAIL_OUT < 2: a lane holds features 4 l .. + 3 of both row halves (8-byte stores: 512 contiguous bytes per wave instruction);
+        // >= 2: features 8 l .. + 7 (ONE 16-byte store per lane and stream half: a whole 1-KB row per wave instruction)
+        constexpr bool WIDE = MST_TAIL_OUT >= 2;
+        const int fa = WIDE ? lane * 8 : lane * 4, fb = WIDE ? lane * 8 + 4 : 256 + lane * 4;
         const f32x4 ba = *reinterpret_cast<const f32x4*>(b2 + fa), bb = *reinterpret_cast<const f32x4*>(b2 + fb);
         const f32x4 ga = *reinterpret_cast<const f32x4*>(g2 + fa), gb = *reinterpret_cast<const f32x4*>(g2 + fb);
         const f32x4 ea = *reinterpret_cast<const f32x4*>(be2 + fa), eb = *reinterpret_cast<const f32x4*>(be2 + fb);
@@ -529,23 +536,30 @@ __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ at
                               fmaf(xa[r][2], xa[r][2], xb[r][2] * xb[r][2]), fmaf(xa[r][3], xa[r][3], xb[r][3] * xb[r][3])};
             rstd[r] = ln_rstd(wave_sum((sq[0] + sq[1]) + (sq[2] + sq[3])));
         }
+        constexpr bool THROUGH = PERSIST || MST_TAIL_OUT == 1 || MST_TAIL_OUT == 3;      // write-through stores
 #pragma unroll
         for (int r = 0; r < RPW; r++) {
             const int tok = tok0 + RPW * wave + r;
             if (tok < M) {
                 const size_t off = (size_t)tok * MST_D;
-                uint2 h, l;
-                split4_f16(__builtin_elementwise_fma(xa[r], ga * rstd[r], ea), h, l);
-                if constexpr (PERSIST) { store8_sc1(hx + off + fa, h); store8_sc1(hl + off + fa, l); }
-                else {
-                    *reinterpret_cast<uint2*>(hx + off + fa) = h;
-                    *reinterpret_cast<uint2*>(hl + off + fa) = l;
-                }
-                split4_f16(__builtin_elementwise_fma(xb[r], gb * rstd[r], eb), h, l);
-                if constexpr (PERSIST) { store8_sc1(hx + off + fb, h); store8_sc1(hl + off + fb, l); }
-                else {
-                    *reinterpret_cast<uint2*>(hx + off + fb) = h;
-                    *reinterpret_cast<uint2*>(hl + off + fb) = l;
+                uint2 ha, la, hb, lb;
+                split4_f16(__builtin_elementwise_fma(xa[r], ga * rstd[r], ea), ha, la);
+                split4_f16(__builtin_elementwise_fma(xb[r], gb * rstd[r], eb), hb, lb);
+                if constexpr (WIDE) {
+                    const u32x4_t h4 = {ha.x, ha.y, hb.x, hb.y}, l4 = {la.x, la.y, lb.x, lb.y};
+                    if constexpr (THROUGH) { store16_sc1(hx + off + fa, h4); store16_sc1(hl + off + fa, l4); }
+                    else {
+                        *reinterpret_cast<u32x4_t*>(hx + off + fa) = h4;
+                        *reinterpret_cast<u32x4_t*>(hl + off + fa) = l4;
+                    }
+                } else if constexpr (THROUGH) {
+                    store8_sc1(hx + off + fa, ha); store8_sc1(hl + off + fa, la);
+                    store8_sc1(hx + off + fb, hb); store8_sc1(hl + off + fb, lb);
+                } else {
+                    *reinterpret_cast<uint2*>(hx + off + fa) = ha;
+                    *reinterpret_cast<uint2*>(hl + off + fa) = la;
+                    *reinterpret_cast<uint2*>(hx + off + fb) = hb;
+                    *reinterpret_cast<uint2*>(hl + off + fb) = lb;
                 }
             }
         }
