@@ -172,7 +172,7 @@ struct mst_engine {
     float *b_pose_in = nullptr, *b_pose_out = nullptr;
     f16 *w_pose_in_pk = nullptr, *w_pose_out_pk = nullptr;      // the two projections as per-wave fragment streams (mst_embed.h, k_pack_wave_blocks)
     bool pose_in_dirty = true, pose_out_dirty = true;          // ... older than w_pose_in / w_pose_out: repacked by ensure_packed()
-    int small_ln = 1, small_ln_m = 512;   // ... with the LayerNorms inside the consuming GEMMs, up to this many stream rows (MST_SMALL_LN, MST_SMALL_LN_M; tools/r4_small_sweep.sh: ahead through 2 clips x 197 rows, behind from 4)
+    int small_ln = 1, small_ln_m = 512;   // ... with the LayerNorms inside the consuming GEMMs, up to this many stream rows (MST_SMALL_LN, MST_SMALL_LN_M; tools/experiments/r4_small_sweep.sh: ahead through 2 clips x 197 rows, behind from 4)
     int small_fast = 1;                   // small launches: the layer GEMMs as the kernels of mst_small.h (MST_SMALL_FAST=0: the slab ring)
     int fuse_embed = 1;                   // a sampling step's output projection also embeds the next step (MST_FUSE_EMBED=0: two launches)
     int embed_fast = 1;                   // K3 / K9 as the latency kernels of mst_embed.h; MST_EMBED_FAST=0: the ring GEMMs of rounds 1-3
@@ -204,7 +204,7 @@ struct mst_engine {
     int precise = 0;                      // mst_set_precise / MST_PRECISE=1: every layer GEMM of the sampling path multiplies its activation as hi + lo (the small-tile
                                           // kernels at any size, ~2x their MFMA work): for checkpoints whose outlier channels put f16 operands above the 1e-3 bar
     int small_m = 1900;                   // launches of at most this many token rows take the small-tile path (MST_SMALL_M, 0 = never).
-                                          // Round 4, with 32-token tiles in the fused tail of a lone launch (tools/r4_batch_sweep.sh, clips/s of a
+                                          // Round 4, with 32-token tiles in the fused tail of a lone launch (tools/experiments/r4_batch_sweep.sh, clips/s of a
                                           // 200-step loop, small / large tiles): 4 clips 46.2 / 41.0, 8: 85.6 / 83.2, 12: 105.8 / 125.1, 16: 139.2 / 167.5
                                           // -- hand-over between 9 and 10 clips (it was 16 clips = 3200 rows with 64-token tiles only)
     float* zacc = nullptr;                // fp32 GEMM result feeding k_ln_rows on that path
@@ -709,7 +709,7 @@ static int launch_small(int M, int N, const SRC& xs, const f16* W, int ldw, int 
 
 // The small-launch GEMMs of mst_small.h: 64 x 128 tiles, the token tile resident in LDS, the weights streamed as fragments.
 static int g_rows_ntb1_m = [] { const char* v = getenv("MST_SMALL_NTB1_M"); return v ? atoi(v) : 800; }();
-// (tools/r4_ntb1_sweep.sh, r4_ntb2_sweep.sh: 16-token tiles ahead through 4 clips x 197 rows, behind at 6; 32-token tiles 4 % ahead at 8 and 9 clips, level at 6, behind at 5)
+// (tools/experiments/r4_ntb1_sweep.sh, r4_ntb2_sweep.sh: 16-token tiles ahead through 4 clips x 197 rows, behind at 6; 32-token tiles 4 % ahead at 8 and 9 clips, level at 6, behind at 5)
 static int g_rows_ntb2_from = [] { const char* v = getenv("MST_SMALL_NTB2_FROM"); return v ? atoi(v) : 1300; }();
 template <int KS, int MODE>
 static int launch_rows_gemm(int M, int N, const f16* X, const f16* wpk, const float* bias, void* out, int ldo, hipStream_t st, const LnRows* ln = nullptr,
@@ -927,7 +927,7 @@ static int launch_tail(const mst_engine* e, const LayerW& w, const WS& ws, int M
     static_assert(TailCfg::SMEM <= 163840, "fused layer tail exceeds the 160 KiB LDS");
     // Tile height (16 NTB tokens; mst_tail.h).  A launch that has the chip to itself and does not fill it runs on more, lower tiles; the
     // clip slices of a sampling loop share the chip (3 x 68 tiles of 64 tokens at the headline batch) and keep the 64-token tile: 48-token
-    // tiles measured 99.4 against 105.3 clips/s there, 32-token tiles 88.3 (tools/r4_ntb_ab.sh).
+    // tiles measured 99.4 against 105.3 clips/s there, 32-token tiles 88.3 (tools/experiments/r4_ntb_ab.sh).
     int ntb = e->tail_ntb;
     if (ntb == 0) {
         ntb = 4;
@@ -1307,7 +1307,7 @@ extern "C" int mst_forward(mst_engine* e, const float* x, const int64_t* t, cons
 }
 
 // How many independent clip slices a loop over `batch` clips of `frames` frames runs as.  Measured, same box, interleaved
-// (tools/streams_ab.sh, tools/streams_ab_configs.sh), round-2 kernels at 196 frames: a batch whose tiles are all resident at
+// (tools/experiments/streams_ab.sh, tools/experiments/streams_ab_configs.sh), round-2 kernels at 196 frames: a batch whose tiles are all resident at
 // once on the large-tile path wanted ONE slice (batch 64: 82.0 / 81.6 / 80.6 clips/s at 1 / 2 / 3 slices; batch 32: 43.8 vs 39.7
 // at 3 -- slices would drop to the small-tile kernels); more tiles than CUs want one slice per round of tiles (batch 128 = 394
 // tiles: 78.5 / 91.2 / 88.0 at 1 / 2 / 3; CFG at 64 clips: 39.8 / 45.5 / 44.6); the small-tile path (batch 16: 22.1 vs 28.8) up to three.

@@ -1,4 +1,4 @@
-# Round 3: the fine-tune / training files of profiles/r03_* (re-collected after the weight re-upload change; same recipe as tools/r3_profiles.sh)
+# Round 3: the fine-tune / training files of profiles/r03_* (re-collected after the weight re-upload change; same recipe as tools/experiments/r3_profiles.sh)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r03t; rm -rf $O; mkdir -p $O
 timeout -k 10 300 python bench.py --mode finetune --steps 10 --warmup 3 > $O/bench_ft.log 2>&1 || exit 1; tail -1 $O/bench_ft.log > $O/r03_finetune_bench_1gpu.json; cut -c1-300 $O/r03_finetune_bench_1gpu.json

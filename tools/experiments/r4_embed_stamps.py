@@ -1,5 +1,5 @@
 """Phase stamps of k_embed_out (diagnostic library build with -DEMB_PROBE, selected through MST_ENGINE_LIB): the median workgroup of the
-last launch of a 40-step loop.   EB=<clips> MST_ENGINE_LIB=$PWD/ab_libs/lib_embprobe.so python tools/r4_embed_stamps.py"""
+last launch of a 40-step loop.   EB=<clips> MST_ENGINE_LIB=$PWD/ab_libs/lib_embprobe.so python tools/experiments/r4_embed_stamps.py"""
 import ctypes as C
 import os
 import sys

@@ -1,4 +1,4 @@
-# Round 4: A/B of library builds in the real loop, interleaved: tools/r4_lib_ab.sh <lib|default> ... [-- bench args]
+# Round 4: A/B of library builds in the real loop, interleaved: tools/experiments/r4_lib_ab.sh <lib|default> ... [-- bench args]
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for r in 1 2 3; do for v in "$@"; do
   if [ "$v" = default ]; then unset MST_ENGINE_LIB; else export MST_ENGINE_LIB=$PWD/$v; fi

@@ -24,6 +24,6 @@ def run(ntb, zero):
 for lib in (None, "ab_libs/lib_schedb.so"):
     if lib: os.environ["MST_ENGINE_LIB"] = os.path.abspath(lib)
     import subprocess
-    code = ("import os,sys,numpy as np;sys.path.insert(0,'.');exec(open('tools/r4_ntb_cmp.py').read().split('for lib in')[0]);"
+    code = ("import os,sys,numpy as np;sys.path.insert(0,'.');exec(open('tools/experiments/r4_ntb_cmp.py').read().split('for lib in')[0]);"
             "d=np.abs(run('3',())-run('4',()));print('%s', np.round(d.max(1)[:192].reshape(-1,16).max(1),3))" % (lib or "in-tree"))
     print(subprocess.run([sys.executable, "-c", code], capture_output=True, text=True).stdout.strip().splitlines()[-1])

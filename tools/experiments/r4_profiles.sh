@@ -21,7 +21,7 @@ step "bench batch 32, 64-token tail tiles"; MST_TAIL_NTB=4 timeout -k 10 300 pyt
 step "bench, ring embed kernels"; MST_EMBED_FAST=0 timeout -k 10 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-boundary > $O/bench_ring.log 2>&1 || exit 1; tail -1 $O/bench_ring.log > $O/r04_bench_ring_embed.json; cut -c1-200 $O/r04_bench_ring_embed.json
 step "finetune bench"; timeout -k 10 300 python bench.py --mode finetune --steps 10 --warmup 3 > $O/bench_ft.log 2>&1 || exit 1; tail -1 $O/bench_ft.log > $O/r04_finetune_bench_1gpu.json; cut -c1-300 $O/r04_finetune_bench_1gpu.json
 step "finetune bench, every model call differentiated alone"; MST_CHAIN=0 timeout -k 10 300 python bench.py --mode finetune --steps 10 --warmup 3 > $O/bench_ft0.log 2>&1 || exit 1; tail -1 $O/bench_ft0.log > $O/r04_finetune_bench_1gpu_unchained.json; cut -c1-200 $O/r04_finetune_bench_1gpu_unchained.json
-step "finetune segments"; timeout -k 10 300 python tools/r4_finetune_segments.py 2>&1 | tail -7 > $O/r04_finetune_segments.txt; cat $O/r04_finetune_segments.txt
+step "finetune segments"; timeout -k 10 300 python tools/finetune_segments.py 2>&1 | tail -7 > $O/r04_finetune_segments.txt; cat $O/r04_finetune_segments.txt
 step "kernel stats, one slice"
 MST_STREAMS=1 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-boundary > $O/prof_bench.log 2>&1 || exit 1
 grep "^{\"metric\"" $O/prof_bench.log | tail -1 > $O/r04_bench_under_rocprof_streams1.json
@@ -29,7 +29,7 @@ cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/r04_kernel_stats_bench
 head -6 $O/r04_kernel_stats_bench_steps1_streams1.csv | cut -c1-160
 step "kernel trace, three slices (the timed path)"
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace3 -- python3 bench.py --steps 1 --warmup 1 --denoise-steps 40 --no-cpu-baseline --no-boundary > $O/trace3.log 2>&1 || exit 1
-python3 tools/r4_trace.py $O/trace3 > $O/r04_three_slice_trace_summary.txt; grep -E "^queue|dur  (tail|attn|embed)" $O/r04_three_slice_trace_summary.txt | head -20
+python3 tools/trace_summary.py $O/trace3 > $O/r04_three_slice_trace_summary.txt; grep -E "^queue|dur  (tail|attn|embed)" $O/r04_three_slice_trace_summary.txt | head -20
 export MST_STREAMS=1
 step "pmc mfma / lds"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmcA -- $B > $O/pmcA.log 2>&1 || exit 1
@@ -44,10 +44,10 @@ step "phase stamps"; bash tools/phase_stamps.sh > /dev/null 2>&1; cp gpurun_out/
 step "tail probe at a slice's size"; ( timeout -k 10 100 $P/tail_clock 64 4334 | tail -3 ) > $O/r04_tail_stamps_slice_size.txt 2>&1; cut -c1-300 $O/r04_tail_stamps_slice_size.txt
 step "host enqueue share"; timeout -k 10 300 python tools/host_bound.py 2>&1 | grep "^B=" > $O/r04_host_bound.txt; cat $O/r04_host_bound.txt
 step "latency batch 1"; timeout -k 10 300 python tools/latency_b1.py 2>&1 | grep "^F=" > $O/r04_latency_batch1.txt; cat $O/r04_latency_batch1.txt
-step "single-clip step by kernel family"; timeout -k 10 300 python tools/r4_b1_families.py 2>&1 | tail -9 > $O/r04_single_clip_families.txt; cat $O/r04_single_clip_families.txt
-step "the same with round 3's small-launch kernels (slab ring, LayerNorm launches)"; ( MST_SMALL_FAST=0 timeout -k 10 300 python tools/latency_b1.py 2>&1 | grep "^F="; MST_SMALL_FAST=0 timeout -k 10 300 python tools/r4_b1_families.py 2>&1 | tail -9 ) > $O/r04_single_clip_ring_kernels.txt; cat $O/r04_single_clip_ring_kernels.txt
-step "small path over the batch size"; bash tools/r4_small_sweep.sh > $O/r04_small_path_sweep.txt 2>&1; tail -12 $O/r04_small_path_sweep.txt
-step "embed kernels by mode"; ( timeout -k 10 200 python tools/r4_embed_modes.py 2>&1 | tail -4; EB=21 timeout -k 10 200 python tools/r4_embed_modes.py 2>&1 | tail -4; MST_EMBED_FAST=0 EB=21 timeout -k 10 200 python tools/r4_embed_modes.py 2>&1 | tail -4 ) > $O/r04_embed_kernels_by_mode.txt; cat $O/r04_embed_kernels_by_mode.txt
+step "single-clip step by kernel family"; timeout -k 10 300 python tools/single_clip_families.py 2>&1 | tail -9 > $O/r04_single_clip_families.txt; cat $O/r04_single_clip_families.txt
+step "the same with round 3's small-launch kernels (slab ring, LayerNorm launches)"; ( MST_SMALL_FAST=0 timeout -k 10 300 python tools/latency_b1.py 2>&1 | grep "^F="; MST_SMALL_FAST=0 timeout -k 10 300 python tools/single_clip_families.py 2>&1 | tail -9 ) > $O/r04_single_clip_ring_kernels.txt; cat $O/r04_single_clip_ring_kernels.txt
+step "small path over the batch size"; bash tools/experiments/r4_small_sweep.sh > $O/r04_small_path_sweep.txt 2>&1; tail -12 $O/r04_small_path_sweep.txt
+step "embed kernels by mode"; ( timeout -k 10 200 python tools/embed_modes.py 2>&1 | tail -4; EB=21 timeout -k 10 200 python tools/embed_modes.py 2>&1 | tail -4; MST_EMBED_FAST=0 EB=21 timeout -k 10 200 python tools/embed_modes.py 2>&1 | tail -4 ) > $O/r04_embed_kernels_by_mode.txt; cat $O/r04_embed_kernels_by_mode.txt
 step "train stack"; timeout -k 10 300 python tools/train_bench.py > $O/train.log 2>&1; tail -1 $O/train.log > $O/r04_train_stack_bench.json; cut -c1-300 $O/r04_train_stack_bench.json
 rm -rf $O/prof $O/prof_ft $O/pmcF $O/pmcW $O/pmcF2 $O/pmcW2 $O/pmcA $O/trace3
 ls $O

@@ -11,7 +11,7 @@ python3 tools/pmc_traffic.py $O/pmcF $O/pmcW > $O/r04_pmc_traffic.json
 python3 tools/pmc_traffic.py $O/pmcF2 $O/pmcW2 > $O/r04_pmc_traffic_fused_step.json
 unset MST_STREAMS
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace3 -- python3 bench.py --steps 1 --warmup 1 --denoise-steps 40 --no-cpu-baseline --no-boundary > $O/trace3.log 2>&1 || exit 1
-python3 tools/r4_trace.py $O/trace3 > $O/r04_three_slice_trace_summary.txt
+python3 tools/trace_summary.py $O/trace3 > $O/r04_three_slice_trace_summary.txt
 rm -rf $O/pmc* $O/trace3
 cp $O/r04_pmc_traffic.json profiles/r04_pmc_traffic.json
 python bench.py --steps 3 --warmup 1 --no-boundary 2>&1 | tail -1 > $O/r04_bench_default_with_traffic.json

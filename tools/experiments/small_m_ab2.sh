@@ -1,5 +1,5 @@
 # Small-tile / large-tile hand-over: clips/s of one loop launch at batches around the crossover with the small path off (0),
-# forced (8192) and the default policy.  gpurun -- 'bash tools/small_m_ab2.sh'
+# forced (8192) and the default policy.  gpurun -- 'bash tools/experiments/small_m_ab2.sh'
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 for b in 8 11 14 16 20 24 30; do

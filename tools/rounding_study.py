@@ -1,6 +1,6 @@
 """Which f16 operand roundings carry the error on ill-conditioned weights?  CPU study with the oracle's arithmetic (oracle/denoiser.py
 encoder_layer, restated here with one switch per product operand) on the stress weights of tests/test_gpu_parity.py
-::test_forward_with_ill_conditioned_weights.  Test infrastructure only (imports oracle/).   python tools/r4_rounding_study.py"""
+::test_forward_with_ill_conditioned_weights.  Test infrastructure only (imports oracle/).   python tools/rounding_study.py"""
 import math, os, sys
 import numpy as np, torch
 import torch.nn.functional as F
