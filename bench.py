@@ -365,7 +365,7 @@ def pmc_traffic(families, rows):
     # file from another build (any csrc/ change since) reads as "no traffic figure", never as a stale number.
     from mst_amd import _native
     have = _native.built_hash()
-    for name in ("r04_pmc_traffic.json",):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json"):
         try:
             doc = json.load(open(os.path.join(prof_dir, name)))
             kernels = doc["kernels"]
@@ -404,9 +404,9 @@ def cpu_baseline(w, pe, tab, tmap, B, F, T, NS, sample_steps, seed):
     return {"value": round(B / (per_step * NS), 5), "unit": "clips/s", "cores": cores, "kind": "port",
             "sample": f"{sample_steps} of {NS} denoise steps at batch {B} ({dt:.1f} s), extrapolated linearly",
             "s_per_denoise_step": round(per_step, 4),
-            # one bounded sample on whatever the host is doing: rounds 3-5 measured 0.101 .. 0.129 clips/s for this same sample on the
+            # one bounded sample on whatever the host is doing: rounds 3-5 measured 0.099 .. 0.129 clips/s for this same sample on the
             # pool's boxes (profiles/r0*_bench_*.json) -- quote the baseline as that range, the GPU / CPU ratio as ~800 .. 1 100
-            "observed_range_clips_per_s": [0.101, 0.129]}
+            "observed_range_clips_per_s": [0.099, 0.129]}
 
 
 # ---------------------------------------------------------------------------------------------- fine-tuning

@@ -160,6 +160,14 @@ def test_forward_with_ill_conditioned_weights(stress):
             e_model = max(e_model, rel_l2(denoiser.forward(w, pe, xp, t, txt, dt=torch.float16).numpy(), denoiser.forward(w, pe, xp, t, txt).numpy()))
     print("ill-conditioned", stress, "engine", e_eng, "operand-rounding model", e_model)
     assert e_eng <= 1.5 * e_model + 2e-4, (e_eng, e_model)
+    # what a user gets: the default path IS above the bar on these checkpoints, and the engine says so when the weights are loaded
+    # (outlier statistics over the LayerNorm gains and the weights' scale, DenoiserEngine.weight_diagnostics) and names the remedy
+    d = eng.weight_diagnostics
+    print("ill-conditioned", stress, "diagnostics", d)
+    assert d["recommend_precise"] and e_eng > 8e-4, (e_eng, d)       # (measured 1.1e-3 / 1.2e-3 / 0.2: at or above the bar)
+    assert (d["max_layernorm_gain_over_median"] >= 8.0) == ln and (d["max_weight_scale_over_init"] >= 2.0) == big, d
+    good, _ = engine_for("xia")
+    assert not good.weight_diagnostics["recommend_precise"], good.weight_diagnostics        # the seeded, well-conditioned weights: no warning
     # the remedy for such checkpoints: activations AND weights as f16 hi + lo pairs in every GEMM (engine.set_precise; measured 2.7e-4 /
     # 3.5e-4 / 0.066 for the three cases -- with the activations alone split it was 8.8e-4 / 1.01e-3: what is left is the weights' rounding)
     eng.set_precise(True)
