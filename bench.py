@@ -253,6 +253,9 @@ def sample_main(args):
     boundary = None
     if rank == 0 and world == 1 and not args.via_boundary and not args.no_boundary:
         boundary = {"call": "diffusion.p_sample_loop(model, (B,263,1,196), noise=x_T, clip_denoised=False, model_kwargs={'y': ...})"}
+        with torch.no_grad():                                # one model call first: the module builds its engine and uploads its weights there (one-time set-up,
+            model(x_T, torch.zeros(B, dtype=torch.long, device=dev),      # not part of a loop's rate)
+                  y={"text_embed": txt, "mask": torch.ones(B, 1, 1, T, device=dev), **({"scale": scale} if args.cfg else {})})
         for mode in ("philox", "torch"):
             boundary_pass(mode) if NS <= 100 else None       # short loops: warm the allocator; 1000-step passes are their own warm-up
             torch.cuda.synchronize(dev)

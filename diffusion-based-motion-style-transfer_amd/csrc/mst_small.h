@@ -12,7 +12,7 @@
 // Tile height (engine: launch_rows_gemm): 16 tokens up to 800 stream rows (the burst in front of the first MFMA is a quarter of the
 // 64-token tile's, and the extra workgroups find idle CUs), 64 tokens above, 32 above 1 300 (measured: tools/experiments/r4_ntb1_sweep.sh, r4_ntb2_sweep.sh).
 // LNF = 1 makes the rows instead of reading them: the LayerNorm between two GEMMs without a launch of its own (below).
-// 2.8 .. 4.4 us per launch at one clip; single-clip step 378 -> 253 us.
+// 2.8 .. 4.4 us per launch at one clip; single-clip step 378 -> 253 us (docs/LAB_NOTES.md section 3.6).
 #pragma once
 #include "mst_common.h"
 #include "mst_embed.h"

@@ -1,4 +1,4 @@
-// What would ONE persistent launch per denoise step cost in hand-offs?  (Round 5)
+// What would ONE persistent launch per denoise step cost in hand-offs?  (Round 5; docs/LAB_NOTES.md R5.2.)
 //
 // The proposed structure: 256 resident workgroups = 64 clips x 4 members.  Member i of a clip runs head i of the fused QKV + attention
 // phase, then token tile i of the layer tail (13 blocks of 16 tokens per 197-token clip: 4 | 3 | 3 | 3), layer after layer; the only

@@ -182,21 +182,35 @@ class DenoiserEngine:
     GAIN_OUTLIER, WEIGHT_SCALE = 8.0, 2.0
 
     def _diagnose(self, layer_tensors):
-        worst_gain, worst_w, where_g, where_w = 1.0, 1.0, "", ""
+        """One stacked reduction per tensor kind and ONE host synchronisation (the tensors may live on the GPU: this runs inside the first
+        call of a freshly loaded model)."""
         init_rms = {"self_attn.in_proj_weight": (2.0 / (4 * self.latent_dim)) ** 0.5}            # xavier_uniform over [3d, d]
+        by_kind = {}
         for name, t in layer_tensors.items():
-            kind = name.split(".", 1)[1]
-            v = t.detach().float()
+            layer, kind = name.split(".", 1)
+            by_kind.setdefault(kind, []).append((int(layer), t.detach().float()))
+        stats, index = [], []
+        for kind, items in by_kind.items():
+            v = torch.stack([t for _, t in items])
             if kind in ("norm1.weight", "norm2.weight"):
                 a = v.abs()
-                r = float(a.max() / a.median().clamp_min(1e-12))
-                if r > worst_gain:
-                    worst_gain, where_g = r, name
-            elif kind.endswith("weight") and v.dim() == 2:
-                ref = init_rms.get(kind, (1.0 / (3.0 * v.shape[1])) ** 0.5)                         # nn.Linear default: U(-1/sqrt(in), 1/sqrt(in))
-                r = float(v.pow(2).mean().sqrt()) / ref
-                if r > worst_w:
-                    worst_w, where_w = r, name
+                r = a.amax(dim=1) / a.median(dim=1).values.clamp_min(1e-12)
+                what = "gain"
+            elif kind.endswith("weight") and v.dim() == 3:
+                ref = init_rms.get(kind, (1.0 / (3.0 * v.shape[2])) ** 0.5)                          # nn.Linear default: U(-1/sqrt(in), 1/sqrt(in))
+                r = v.pow(2).mean(dim=(1, 2)).sqrt() / ref
+                what = "scale"
+            else:
+                continue
+            stats.append(r.reshape(-1).cpu() if not r.is_cuda else r.reshape(-1))
+            index += [(what, f"{layer}.{kind}") for layer, _ in items]
+        vals = torch.cat([x.to(stats[0].device) for x in stats]).tolist() if stats else []
+        worst_gain, worst_w, where_g, where_w = 1.0, 1.0, "", ""
+        for (what, name), r in zip(index, vals):
+            if what == "gain" and r > worst_gain:
+                worst_gain, where_g = r, name
+            if what == "scale" and r > worst_w:
+                worst_w, where_w = r, name
         why = []
         if worst_gain >= self.GAIN_OUTLIER:
             why.append(f"LayerNorm gain outlier x{worst_gain:.0f} over the median (layers.{where_g})")
