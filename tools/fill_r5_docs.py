@@ -23,7 +23,7 @@ for name, sub, key, gflop in (("`k_layer_tail<4>` (dominant)", "k_layer_tailILi4
     t = traffic.get(key) if key else None
     hb = f"{t['fetch_bytes'] / 1e6:.0f} + {t['write_bytes'] / 1e6:.0f} = {t['hbm_bytes'] / 1e6:.0f} MB" if t else "â€“"
     use = ev if ev else us
-    rows.append(f"| {name} | {share / 100:.2f} | {('%.1f' % ev) if ev else 'â€“'} ({us:.1f}, {calls} launches) | {gflop / use * 1e-3 / 2.5:.3f} | {hb} |")
+    rows.append(f"| {name} | {share / 100:.2f} | {('%.1f' % ev) if ev else 'â€“'} ({us:.1f}, {calls} launches) | {gflop / use / 2.5:.3f} | {hb} |")
 r = d["roofline"]
 table = ("| kernel (rocprof symbol) | share of device time (`MST_STREAMS=1`) | Âµs per 64-clip launch: event-timed in the bench (rocprofv3 `--stats`) | frac of 2.5 PF | HBM bytes by PMC (read + written) |\n|---|---|---|---|---|\n"
          + "\n".join(rows) + "\n\n"
@@ -34,14 +34,19 @@ table = ("| kernel (rocprof symbol) | share of device time (`MST_STREAMS=1`) | Â
          f"{r['achieved']:.0f} TFLOP/s = **{r['frac']:.3f}**; `roofline.traffic` {('%.1f MB' % (r['traffic'] / 1e6)) if r.get('traffic') else 'null'} against 67 MB algorithmic.  "
          f"Fine-tune iteration **{ft['ms_per_step']:.2f} ms** ({ft['value']:.0f} clips/s; {ft0['ms_per_step']:.1f} ms with every model call differentiated alone on one stream), "
          f"`k_wgrad_tr` {ft['roofline']['dominant_kernel']['avg_launch_us']:.1f} Âµs per launch in-run = {ft['roofline']['dominant_kernel']['frac_of_mfma_peak']:.3f} of peak.")
-subs = {"R5_TABLE_PLACEHOLDER": table, "R5_HEADLINE": f"{d['value']:.1f}", "R5_DRIVER": f"{drv['value']:.1f}", "R5_FRAC": f"{r['whole_path_frac']:.2f}", "R5_CFG": f"{cfg['value']:.1f}",
-        "R5_B128": f"{b128['value']:.1f}", "R5_B32": f"{b32['value']:.1f}", "R5_FT": f"{ft['ms_per_step']:.1f}"}
-for f in ("README.md", "DESIGN.md"):
-    p = os.path.join(ROOT, f)
-    s = open(p).read()
-    for k, v in subs.items():
-        s = s.replace(k, v)
-    open(p, "w").write(s)
+import re
+p = os.path.join(ROOT, "DESIGN.md")
+s = open(p).read()
+s = re.sub(r"(R5_TABLE_PLACEHOLDER|\| kernel \(rocprof symbol\) \|.*?of peak\.)", lambda m: table, s, count=1, flags=re.S)
+open(p, "w").write(s)
+p = os.path.join(ROOT, "README.md")
+s = open(p).read()
+s = re.sub(r"\*\*Sampling, the headline: \S+ clips/s\*\*", f"**Sampling, the headline: {d['value']:.1f} clips/s**", s)
+s = re.sub(r"\(\S+ in the driver's", f"({drv['value']:.1f} in the driver's", s)
+s = re.sub(r"= \S+ of the dense f16 MFMA peak over the whole path; \S+ with\n  classifier-free guidance, \S+ at batch 128, \S+ at batch 32",
+           f"= {r['whole_path_frac']:.2f} of the dense f16 MFMA peak over the whole path; {cfg['value']:.1f} with\n  classifier-free guidance, {b128['value']:.1f} at batch 128, {b32['value']:.1f} at batch 32", s)
+s = re.sub(r"per-GPU work\): \S+ ms per iteration", f"per-GPU work): {ft['ms_per_step']:.1f} ms per iteration", s)
+open(p, "w").write(s)
 for n in sorted(os.listdir(O)):
     if n.startswith("r05_"):
         shutil.copy(os.path.join(O, n), os.path.join(P, n))
