@@ -51,12 +51,28 @@ class GradSink:
         self.ids = tuple(id(p) for p in params)
         self.flat, self.views, self.active, self.task = None, None, False, -1
         self.open_nodes = 0            # native nodes with parameter gradients created since the last backward pass ended
+        self.pending = None            # (side stream, private accumulators) of a chained backward pass still running beside this one
 
     def abort(self):
         """A backward pass died (the autograd engine drops queued callbacks when a node raises): forget its partial sums."""
         self.flat = self.views = None
         self.active, self.task = False, -1
         self.open_nodes = 0
+        self.pending = None
+
+    def join_chain(self):
+        """The chained single-clip calls were differentiated on a side stream into accumulators of their own (ChainedCalls.finish): wait
+        for that pass on the CURRENT stream and add its sums into this pass's accumulators.  Called before the next native node of the
+        pass accumulates (in the fine-tune objective: the 64-clip call, ~2 ms after the chain's pass started, so nothing waits), before
+        a gradient reducer is told that layers are ready, and at the end of the pass.  x + 0 is exact, so the gradients are bit for bit
+        those of the in-line pass."""
+        if self.pending is None:
+            return
+        side, cviews = self.pending
+        self.pending = None
+        torch.cuda.current_stream(cviews[0].device).wait_stream(side)
+        if self.views is not None:
+            torch._foreach_add_(list(self.views), list(cviews))
 
     def begin(self, device):
         grads = [p.grad for p in self.params]
@@ -76,6 +92,7 @@ class GradSink:
         """End of the backward pass: p.grad (+)= accumulated gradient, then tell a gradient reducer."""
         if not self.active:
             return
+        self.join_chain()
         self.active, self.task = False, -1
         self.open_nodes = 0
         if self.flat is not None:
@@ -122,7 +139,7 @@ def _sink_of(host, params):
     return sink
 
 
-def _sink_views(ctx, params_need_grad, device):
+def _sink_views(ctx, params_need_grad, device, join=True):
     """The gradient accumulators of this backward pass (None when no stack parameter needs a gradient)."""
     if not params_need_grad:
         return None
@@ -131,6 +148,8 @@ def _sink_views(ctx, params_need_grad, device):
         sink.abort()                      # stale: its pass raised before the flush callback could run
     if not sink.active:
         sink.begin(device)
+    if join:
+        sink.join_chain()
     return sink.views
 
 
@@ -151,12 +170,32 @@ def _node_done(ctx, had_param_grads):
     sink.open_nodes -= 1
     ready = getattr(ctx.host, "_native_layer_ready", None)
     if sink.open_nodes == 0 and ready is not None and sink.flat is None:      # in-place mode: p.grad IS the reducer's bucket
+        sink.join_chain()
         ready(ctx.eng)
 
 
 def _CHAIN_ON():
     import os
     return os.environ.get("MST_CHAIN", "1") != "0"      # MST_CHAIN=0: every model call differentiates alone (A/B, tests)
+
+
+def _CHAIN_BWD_SIDE_ON():
+    import os
+    return os.environ.get("MST_CHAIN_BWD_SIDE", "1") != "0"     # MST_CHAIN_BWD_SIDE=0: the chain's ONE backward pass runs in line on the caller's stream
+
+
+def _chain_accumulators(host, params, device):
+    """Private gradient accumulators of the chain's backward pass (one flat fp32 buffer, views in parameter order), cached on the module."""
+    ent = host.__dict__.get("_mst_chain_acc")
+    ids = tuple(id(p) for p in params)
+    if ent is None or ent[0] != ids or ent[1].device != device:
+        flat = torch.empty(sum(p.numel() for p in params), dtype=torch.float32, device=device)
+        views, off = [], 0
+        for p in params:
+            views.append(flat[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+        ent = host.__dict__["_mst_chain_acc"] = (ids, flat, views)
+    return ent[1], ent[2]
 
 
 def _CHAIN_STREAM_ON():
@@ -264,8 +303,21 @@ class ChainedCalls:
         ctx = self.ctx0
         tape, self.tape = self.tape, None
         try:
-            views = _sink_views(ctx, True, self.dbuf.device)
-            if self.main is not None:
+            views = _sink_views(ctx, True, self.dbuf.device, join=False)
+            if self.side is not None and _CHAIN_BWD_SIDE_ON() and self.reported == self.k:      # (not through the end-of-pass callback: the sink may have been flushed)
+                # Round 5: the pass stays on the SIDE stream, beside the backward passes the caller's stream runs next (the frozen motion
+                # encoder, then the 64-clip call), and accumulates into buffers of its own; GradSink.join_chain adds them in before the
+                # next native node accumulates.  ~160 launch-bound kernels on six clips' token rows no longer sit in front of those passes.
+                sink = _sink_of(ctx.host, ctx.params)
+                cflat, cviews = _chain_accumulators(ctx.host, ctx.params, self.dbuf.device)
+                self.side.wait_stream(torch.cuda.current_stream(self.dbuf.device))     # (through the end-of-pass callback this runs on the caller's stream)
+                with torch.cuda.stream(self.side):
+                    cflat.zero_()
+                    ctx.eng.train_model_backward(tape, self.dbuf, ctx.p_drop, ctx.p_pe, self.seed, cviews, need_input_grad=False)
+                self.dbuf.record_stream(self.side)
+                tape.record_stream(self.side)
+                sink.pending = (self.side, cviews)
+            elif self.main is not None:
                 # autograd runs this node on the side stream (its forward's); the pass itself belongs on the caller's stream, behind
                 # the gradients the side stream has just copied in (report() ran there; through the end-of-pass callback this code is on
                 # the caller's stream already, so the side stream is named) and in line with the iteration's other backward passes
