@@ -444,6 +444,16 @@ def test_chain_and_side_stream_switches_give_the_same_gradients(monkeypatch):
             res[(chain_on, stream_on)] = (objective(), partial())
             side_taken[(chain_on, stream_on)] = any(taken)
             monkeypatch.setattr(native_stack.ChainedCalls, "__enter__", orig_enter)
+    # the chain's backward pass beside the others (side stream, accumulators of its own: GradSink.join_chain) against in line: same bits
+    monkeypatch.setenv("MST_CHAIN", "1")
+    monkeypatch.setenv("MST_CHAIN_STREAM", "1")
+    monkeypatch.setenv("MST_CHAIN_BWD_SIDE", "0")
+    inline = (objective(), partial())
+    monkeypatch.delenv("MST_CHAIN_BWD_SIDE")
+    for part in (0, 1):
+        la, ga = res[("1", "1")][part]
+        lb, gb = inline[part]
+        assert la == lb and all(torch.equal(a, b) for a, b in zip(ga, gb)), ("the side-stream backward pass changed the gradients", part)
     assert side_taken[("1", "1")] and not side_taken[("1", "0")]
     assert not side_taken[("0", "1")] and not side_taken[("0", "0")], "an unchained call must stay on the caller's stream"
     for part in (0, 1):
