@@ -693,6 +693,7 @@ static int launch_gemm_dma(dim3 grid, const SRC& xs, const f16* W, int ldw, int 
 // bound by the DMA round trip per slab, not by bandwidth, so small launches use 64-deep slabs (half as many round trips,
 // one workgroup per CU is plenty); large launches keep 32-deep slabs and two co-resident workgroups per CU.
 #define SMALL_M 2048
+#define LN_BWD_WIDE_M 4096        // k_ln_bwd: sixteen waves per block above this many rows (four below: a clip or a few, one row per wave)
 template <class SRC, class EPI>
 static int launch_wide(int M, int ny, const SRC& xs, const f16* W, int ldw, int K, const EPI& epi, hipStream_t st) {
     if (M <= SMALL_M && (K % 64) == 0 && K >= 128)
@@ -1907,7 +1908,11 @@ static int train_stack_backward(mst_engine* e, const Tape& t, int rows, int S, f
     const int M = rows * S, nl = e->cfg.num_layers;
     float* gA = w_.g0;      // dz buffers
     float* gB = w_.g1;      // gradient wrt the current layer output
-    const int ln_blocks = (M + 3) / 4 < 256 ? (M + 3) / 4 : 256;      // one per CU; their partial sums are added in block order (k_ln_bwd_finish)
+    // one block per CU at most; their partial sums are added in block order (k_ln_bwd_finish).  Sixteen waves per block above LN_BWD_WIDE_M rows
+    const bool ln_wide = M > LN_BWD_WIDE_M;
+    const int ln_wpb = ln_wide ? 16 : 4;
+    const int ln_blocks = (M + ln_wpb - 1) / ln_wpb < 256 ? (M + ln_wpb - 1) / ln_wpb : 256;
+    auto ln_bwd = ln_wide ? k_ln_bwd<16> : k_ln_bwd<4>;
     const bool small = e->small_m > 0 && M <= e->small_m;
     e->prof_now = 0;
     // The dgrad chain (LayerNorm / GELU / attention backward and the four dgrad GEMMs) is serial; the four wgrads of a
@@ -1934,7 +1939,7 @@ static int train_stack_backward(mst_engine* e, const Tape& t, int rows, int S, f
         for (int i = 0; i < 12; i++) if (!G[i]) return fail("mst_train_backward: null gradient buffer (layer %d, tensor %d)", l, i);
         if (two && side_used[par]) HIPCHECK(hipStreamWaitEvent(st, w_.ev_side[par], 0));
         // LayerNorm2 backward: gB -> dz2 (gA, fp32) and the branch gradient dbr2 (f16); dgamma2, dbeta2, db2
-        hipLaunchKernelGGL(k_ln_bwd, dim3(ln_blocks), dim3(256), 0, st, gB, a.z2h, a.z2l, w.g2, M, make_drop(seed, l, 3, p_drop), w_.gscale,
+        hipLaunchKernelGGL(ln_bwd, dim3(ln_blocks), dim3(64 * ln_wpb), 0, st, gB, a.z2h, a.z2l, w.g2, M, make_drop(seed, l, 3, p_drop), w_.gscale,
                            gA, dbr2, w_.ln_part);
         if (wg) hipLaunchKernelGGL(k_ln_bwd_finish, dim3(3 * MST_D / 64), dim3(256), 0, st, w_.ln_part, ln_blocks, w_.gscale, G[10], G[11], G[7]);
         HIPCHECK(hipGetLastError());
@@ -1955,7 +1960,7 @@ static int train_stack_backward(mst_engine* e, const Tape& t, int rows, int S, f
                         : launch_wide(M, MST_D / 256, RowsDirect{dpre, MST_FF}, w.w1T, MST_FF, MST_FF, epi, st));
         }
         // LayerNorm1 backward: gB -> dz1 (gA), dbr1 = d(out-proj output); dgamma1, dbeta1, db_out
-        hipLaunchKernelGGL(k_ln_bwd, dim3(ln_blocks), dim3(256), 0, st, gB, a.z1h, a.z1l, w.g1, M, make_drop(seed, l, 1, p_drop), w_.gscale,
+        hipLaunchKernelGGL(ln_bwd, dim3(ln_blocks), dim3(64 * ln_wpb), 0, st, gB, a.z1h, a.z1l, w.g1, M, make_drop(seed, l, 1, p_drop), w_.gscale,
                            gA, dbr1, w_.ln_part);
         if (wg) hipLaunchKernelGGL(k_ln_bwd_finish, dim3(3 * MST_D / 64), dim3(256), 0, st, w_.ln_part, ln_blocks, w_.gscale, G[8], G[9], G[3]);
         HIPCHECK(hipGetLastError());

@@ -472,19 +472,45 @@ __global__ void k_scale_f32(const float* __restrict__ in, size_t n, const float*
 //   dbr = dz * dropout-mask                                                            (f16, the branch gradient = GEMM operand)
 //   dgamma += sum_rows g xhat,  dbeta += sum_rows g,  dbias += sum_rows dbr            (unscaled, atomics)
 // One wave per row; lane owns features [4 lane, +4) and [256 + 4 lane, +4).
-__global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ g, const f16* __restrict__ z_hi, const f16* __restrict__ z_lo,
+// WPB waves per block: 4 for a clip or a few; 16 at batch size -- with 256 blocks of four waves every SIMD held ONE wave, and the row's
+// three shuffle ladders, the mask hash and the memory round trips ran in series (35 us per launch at 12 608 rows, 2.6 TB/s).
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_ln_bwd(const float* __restrict__ g, const f16* __restrict__ z_hi, const f16* __restrict__ z_lo,
                                                 const float* __restrict__ gamma, int M, Drop d, const float* __restrict__ gscale,
                                                 float* __restrict__ dz, f16* __restrict__ dbr, float* __restrict__ part) {
+    static_assert(WPB == 4 || WPB == 16, "partial sums: four LDS slots per block, each the ordered sum of WPB / 4 waves");
     __shared__ float red[3][4][MST_D];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fa = lane * 4, fb = 256 + lane * 4;
     const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + fa), gb = *reinterpret_cast<const f32x4*>(gamma + fb);
     f32x4 dga = {0.f, 0.f, 0.f, 0.f}, dgb = dga, dba = dga, dbb = dga, dca = dga, dcb = dga;
-    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    // RB rows of a wave per pass, every load of the pass issued before the first row is worked on: the rows of a wave were load -> three
+    // shuffle ladders -> store in series, twelve HBM round trips per launch at 12 608 rows with four waves on the CU (23 us).  The rows are
+    // still PROCESSED one after the other in the old order, so the partial sums come out bit for bit as before.
+    constexpr int RB = 4;
+    const int rstride = gridDim.x * WPB;
+    for (int row0 = blockIdx.x * WPB + wave; row0 < M; row0 += RB * rstride) {
+        uint2 zha[RB], zla[RB], zhb[RB], zlb[RB];
+        f32x4 gya[RB], gyb[RB];
+#pragma unroll
+        for (int k = 0; k < RB; k++) {
+            const int rr = row0 + k * rstride;
+            const size_t off = (size_t)(rr < M ? rr : row0) * MST_D;
+            zha[k] = *reinterpret_cast<const uint2*>(z_hi + off + fa);
+            zla[k] = *reinterpret_cast<const uint2*>(z_lo + off + fa);
+            zhb[k] = *reinterpret_cast<const uint2*>(z_hi + off + fb);
+            zlb[k] = *reinterpret_cast<const uint2*>(z_lo + off + fb);
+            gya[k] = *reinterpret_cast<const f32x4*>(g + off + fa);
+            gyb[k] = *reinterpret_cast<const f32x4*>(g + off + fb);
+        }
+#pragma unroll
+        for (int k = 0; k < RB; k++) {
+        const int row = row0 + k * rstride;
+        if (row >= M) break;                                 // wave-uniform
         const size_t off = (size_t)row * MST_D;
-        f32x4 xa = join4_f16(*reinterpret_cast<const uint2*>(z_hi + off + fa), *reinterpret_cast<const uint2*>(z_lo + off + fa));
-        f32x4 xb = join4_f16(*reinterpret_cast<const uint2*>(z_hi + off + fb), *reinterpret_cast<const uint2*>(z_lo + off + fb));
-        const f32x4 ya = *reinterpret_cast<const f32x4*>(g + off + fa), yb = *reinterpret_cast<const f32x4*>(g + off + fb);
+        f32x4 xa = join4_f16(zha[k], zla[k]);
+        f32x4 xb = join4_f16(zhb[k], zlb[k]);
+        const f32x4 ya = gya[k], yb = gyb[k];
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; i++) s += xa[i] + xb[i];
@@ -537,17 +563,31 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ g, con
         *reinterpret_cast<f32x4*>(dz + off + fb) = zb;
         *reinterpret_cast<uint2*>(dbr + off + fa) = pack4_f16(ra[0], ra[1], ra[2], ra[3]);
         *reinterpret_cast<uint2*>(dbr + off + fb) = pack4_f16(rb[0], rb[1], rb[2], rb[3]);
+        }
     }
+    // slot (wave & 3) = the sums of waves wave & 3, + 4, + 8, + 12, added in that order (a fixed order: the results are reproducible)
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        red[0][wave][fa + i] = dga[i]; red[0][wave][fb + i] = dgb[i];
-        red[1][wave][fa + i] = dba[i]; red[1][wave][fb + i] = dbb[i];
-        red[2][wave][fa + i] = dca[i]; red[2][wave][fb + i] = dcb[i];
+    for (int grp = 0; grp < WPB / 4; grp++) {
+        if ((wave >> 2) == grp) {
+            const int sl = wave & 3;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (grp == 0) {
+                    red[0][sl][fa + i] = dga[i]; red[0][sl][fb + i] = dgb[i];
+                    red[1][sl][fa + i] = dba[i]; red[1][sl][fb + i] = dbb[i];
+                    red[2][sl][fa + i] = dca[i]; red[2][sl][fb + i] = dcb[i];
+                } else {
+                    red[0][sl][fa + i] += dga[i]; red[0][sl][fb + i] += dgb[i];
+                    red[1][sl][fa + i] += dba[i]; red[1][sl][fb + i] += dbb[i];
+                    red[2][sl][fa + i] += dca[i]; red[2][sl][fb + i] += dcb[i];
+                }
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     // per-block partial sums; k_ln_bwd_finish adds them up in block order (float atomics here made dgamma / dbeta / dbias differ in the
     // last bits from run to run -- and between data-parallel replicas)
-    for (int i = threadIdx.x; i < 3 * MST_D; i += 256) {
+    for (int i = threadIdx.x; i < 3 * MST_D; i += 64 * WPB) {
         const int a = i / MST_D, f = i - a * MST_D;
         part[(size_t)blockIdx.x * (3 * MST_D) + i] = red[a][0][f] + red[a][1][f] + red[a][2][f] + red[a][3][f];
     }
