@@ -173,6 +173,7 @@ struct mst_engine {
     f16 *w_pose_in_pk = nullptr, *w_pose_out_pk = nullptr;      // the two projections as per-wave fragment streams (mst_embed.h, k_pack_wave_blocks)
     bool pose_in_dirty = true, pose_out_dirty = true;          // ... older than w_pose_in / w_pose_out: repacked by ensure_packed()
     int small_ln = 1, small_ln_m = 512;   // ... with the LayerNorms inside the consuming GEMMs, up to this many stream rows (MST_SMALL_LN, MST_SMALL_LN_M; tools/experiments/r4_small_sweep.sh: ahead through 2 clips x 197 rows, behind from 4)
+    int fuse_ln_bwd = 1;                  // training at batch size: LayerNorm1's backward in the epilogue of the dgrad GEMM in front of it (MST_FUSE_LN_BWD=0: two launches)
     int small_fast = 1;                   // small launches: the layer GEMMs as the kernels of mst_small.h (MST_SMALL_FAST=0: the slab ring)
     int fuse_embed = 1;                   // a sampling step's output projection also embeds the next step (MST_FUSE_EMBED=0: two launches)
     int embed_fast = 1;                   // K3 / K9 as the latency kernels of mst_embed.h; MST_EMBED_FAST=0: the ring GEMMs of rounds 1-3
@@ -384,6 +385,7 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     if (const char* v = getenv("MST_EMBED_FAST")) e->embed_fast = atoi(v) != 0;
     if (const char* v = getenv("MST_FUSE_EMBED")) e->fuse_embed = atoi(v) != 0;
     if (const char* v = getenv("MST_SMALL_FAST")) e->small_fast = atoi(v) != 0;
+    if (const char* v = getenv("MST_FUSE_LN_BWD")) e->fuse_ln_bwd = atoi(v) != 0;
     if (const char* v = getenv("MST_SMALL_LN")) e->small_ln = atoi(v) != 0;
     if (const char* v = getenv("MST_SMALL_LN_M")) e->small_ln_m = atoi(v);
     if (const char* v = getenv("MST_TAIL_NTB")) { int n = atoi(v); e->tail_ntb = (n >= 2 && n <= 4) ? n : 0; }
@@ -1914,6 +1916,9 @@ static int train_stack_backward(mst_engine* e, const Tape& t, int rows, int S, f
     const int ln_blocks = (M + ln_wpb - 1) / ln_wpb < 256 ? (M + ln_wpb - 1) / ln_wpb : 256;
     auto ln_bwd = ln_wide ? k_ln_bwd<16> : k_ln_bwd<4>;
     const bool small = e->small_m > 0 && M <= e->small_m;
+    // at batch size LayerNorm1's backward rides in the epilogue of the dgrad GEMM in front of it (DEpiLnBwd; MST_FUSE_LN_BWD=0: two launches)
+    const int ln_tiles = (M + 63) / 64;
+    const bool fuse_ln = e->fuse_ln_bwd && !small && ln_tiles <= 512;   // (512: the partial-sum buffer's rows)
     e->prof_now = 0;
     // The dgrad chain (LayerNorm / GELU / attention backward and the four dgrad GEMMs) is serial; the four wgrads of a
     // layer only consume its by-products, so they run on a second stream beside it.  Their f16 operands are
@@ -1953,6 +1958,13 @@ static int train_stack_backward(mst_engine* e, const Tape& t, int rows, int S, f
         }
         TO_SIDE()
         if (wg) CHECK(wgrad(e, dpre, MST_FF, a.x1h, MST_D, M, G[4], G[5], sw));                    // dW1 += dpre^T x1, db1
+        if (fuse_ln) {
+            // g(x1) = dpre W1 + dz2 and LayerNorm1's backward behind it in ONE launch (DEpiLnBwd): dz1 -> gA in place, dbr1, the tiles' sums
+            DEpiLnBwd epi{gA, a.z1h, a.z1l, w.g1, M, make_drop(seed, l, 1, p_drop), gA, dbr1, w_.ln_part};
+            CHECK((launch_gemm_dma<64, 512, 2, 2, LN_NS, 1, LN_BK>(dim3(ln_tiles, 1), RowsDirect{dpre, MST_FF}, w.w1T, MST_FF, MST_FF, epi, st)));
+            if (wg) hipLaunchKernelGGL(k_ln_bwd_finish, dim3(3 * MST_D / 64), dim3(256), 0, st, w_.ln_part, ln_tiles, w_.gscale, G[8], G[9], G[3]);
+            HIPCHECK(hipGetLastError());
+        } else {
         // g(x1) = dpre W1 + dz2  -> gB
         {
             DEpiF32 epi{gA, gB, MST_D, M};
@@ -1964,6 +1976,7 @@ static int train_stack_backward(mst_engine* e, const Tape& t, int rows, int S, f
                            gA, dbr1, w_.ln_part);
         if (wg) hipLaunchKernelGGL(k_ln_bwd_finish, dim3(3 * MST_D / 64), dim3(256), 0, st, w_.ln_part, ln_blocks, w_.gscale, G[8], G[9], G[3]);
         HIPCHECK(hipGetLastError());
+        }
         TO_SIDE()
         if (wg) CHECK(wgrad(e, dbr1, MST_D, a.att, MST_D, M, G[2], nullptr, sw));                  // dW_out += dbr1^T att
         // d att = dbr1 W_out

@@ -593,6 +593,136 @@ __global__ __launch_bounds__(64 * WPB) void k_ln_bwd(const float* __restrict__ g
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Epilogue: a dgrad GEMM whose result (+ the residual branch's gradient) is the gradient wrt a LayerNorm output, with that LayerNorm's
+// backward behind it in the same launch (k_ln_bwd's arithmetic, row for row): the fp32 gradient stream's round trip between the two
+// launches (51.6 MB at 12 608 rows) and one launch per LayerNorm less.  64 x 512 tiles (whole rows); the tile's [dgamma | dbeta | dbias]
+// sums go to part[blockIdx.x] and k_ln_bwd_finish adds the tiles up in block order.
+//   g = acc + resid;  dz = rstd (gamma g - mean(gamma g) - xhat mean(gamma g xhat)) -> dz (may alias resid: same lane, same addresses);
+//   dbr = dz * keep-mask -> f16
+// ------------------------------------------------------------------------------------------------------------
+struct DEpiLnBwd {
+    const float* resid; const f16* z_hi; const f16* z_lo; const float* gamma; int M; Drop d;
+    float* dz; f16* dbr; float* part;
+    __device__ __forceinline__ int rows() const { return M; }
+    template <int BT, int BF> static constexpr int smem_bytes() { return BT * (MST_D * 4 + 16); }
+    template <int BT, int BF, int MT, int NT>
+    __device__ __forceinline__ void run(f32x16 (&acc)[1][MT][NT], int tok0, int f0, char* smem) const {
+        static_assert(BF == MST_D && BT == 64, "whole rows, 64 per tile");
+        constexpr int LD = MST_D * 4 + 16;
+        DLane<BT, BF, MT, NT> lc;
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            char* trow = smem + lc.tok(m) * LD;
+#pragma unroll
+            for (int n = 0; n < NT; n++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    f32x4 v = {acc[0][m][n][4 * g], acc[0][m][n][4 * g + 1], acc[0][m][n][4 * g + 2], acc[0][m][n][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(trow + lc.feat(n, g) * 4) = v;
+                }
+        }
+        __syncthreads();
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int fa = lane * 4, fb = 256 + lane * 4;
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + fa), gb = *reinterpret_cast<const f32x4*>(gamma + fb);
+        f32x4 dga = {0.f, 0.f, 0.f, 0.f}, dgb = dga, dba = dga, dbb = dga, dca = dga, dcb = dga;
+        constexpr int RPW = BT / 8;
+        // every row's tape and residual loads first (one memory latency per tile)
+        uint2 zha[RPW], zla[RPW], zhb[RPW], zlb[RPW];
+        f32x4 ra_[RPW], rb_[RPW];
+#pragma unroll
+        for (int r = 0; r < RPW; r++) {
+            const int tok = tok0 + wave * RPW + r;
+            const size_t off = (size_t)(tok < M ? tok : M - 1) * MST_D;
+            zha[r] = *reinterpret_cast<const uint2*>(z_hi + off + fa);
+            zla[r] = *reinterpret_cast<const uint2*>(z_lo + off + fa);
+            zhb[r] = *reinterpret_cast<const uint2*>(z_hi + off + fb);
+            zlb[r] = *reinterpret_cast<const uint2*>(z_lo + off + fb);
+            ra_[r] = *reinterpret_cast<const f32x4*>(resid + off + fa);
+            rb_[r] = *reinterpret_cast<const f32x4*>(resid + off + fb);
+        }
+#pragma unroll
+        for (int r = 0; r < RPW; r++) {
+            const int row = wave * RPW + r, tok = tok0 + row;
+            if (tok >= M) break;                               // wave-uniform; rows ascend
+            const size_t off = (size_t)tok * MST_D;
+            f32x4 xa = join4_f16(zha[r], zla[r]);
+            f32x4 xb = join4_f16(zhb[r], zlb[r]);
+            f32x4 ya = *reinterpret_cast<const f32x4*>(smem + row * LD + fa * 4);
+            f32x4 yb = *reinterpret_cast<const f32x4*>(smem + row * LD + fb * 4);
+#pragma unroll
+            for (int i = 0; i < 4; i++) { ya[i] += ra_[r][i]; yb[i] += rb_[r][i]; }
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; i++) s += xa[i] + xb[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            const float mean = s * (1.0f / MST_D);
+            float s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                xa[i] -= mean;
+                xb[i] -= mean;
+                s2 += xa[i] * xa[i] + xb[i] * xb[i];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
+            const float rstd = ln_rstd(s2);
+            float c1 = 0.f, c2 = 0.f;
+            f32x4 aa, ab;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                xa[i] *= rstd;                                   // xhat
+                xb[i] *= rstd;
+                aa[i] = ga[i] * ya[i];
+                ab[i] = gb[i] * yb[i];
+                c1 += aa[i] + ab[i];
+                c2 += aa[i] * xa[i] + ab[i] * xb[i];
+                dga[i] += ya[i] * xa[i];
+                dgb[i] += yb[i] * xb[i];
+                dba[i] += ya[i];
+                dbb[i] += yb[i];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                c1 += __shfl_xor(c1, o);
+                c2 += __shfl_xor(c2, o);
+            }
+            c1 *= (1.0f / MST_D);
+            c2 *= (1.0f / MST_D);
+            f32x4 za, zb, qa, qb;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                za[i] = rstd * (aa[i] - c1 - xa[i] * c2);
+                zb[i] = rstd * (ab[i] - c1 - xb[i] * c2);
+                qa[i] = za[i] * drop_mul(d, (uint32_t)(off + fa + i));
+                qb[i] = zb[i] * drop_mul(d, (uint32_t)(off + fb + i));
+                dca[i] += qa[i];
+                dcb[i] += qb[i];
+            }
+            *reinterpret_cast<f32x4*>(dz + off + fa) = za;
+            *reinterpret_cast<f32x4*>(dz + off + fb) = zb;
+            *reinterpret_cast<uint2*>(dbr + off + fa) = pack4_f16(qa[0], qa[1], qa[2], qa[3]);
+            *reinterpret_cast<uint2*>(dbr + off + fb) = pack4_f16(qb[0], qb[1], qb[2], qb[3]);
+        }
+        __syncthreads();                                       // the tile rows are consumed: the waves' sums overlay them
+        float* red = reinterpret_cast<float*>(smem);           // [3][8][512]
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            red[(0 * 8 + wave) * MST_D + fa + i] = dga[i]; red[(0 * 8 + wave) * MST_D + fb + i] = dgb[i];
+            red[(1 * 8 + wave) * MST_D + fa + i] = dba[i]; red[(1 * 8 + wave) * MST_D + fb + i] = dbb[i];
+            red[(2 * 8 + wave) * MST_D + fa + i] = dca[i]; red[(2 * 8 + wave) * MST_D + fb + i] = dcb[i];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 3 * MST_D; i += 512) {
+            const int a = i / MST_D, f = i - a * MST_D;
+            const float* rr = red + (size_t)a * 8 * MST_D + f;
+            part[(size_t)blockIdx.x * (3 * MST_D) + i] = ((rr[0] + rr[MST_D]) + (rr[2 * MST_D] + rr[3 * MST_D])) + ((rr[4 * MST_D] + rr[5 * MST_D]) + (rr[6 * MST_D] + rr[7 * MST_D]));
+        }
+    }
+};
+
 // Ordered second stage of the partial-sum reductions: out[i] = sum_p part[p][i], p in a FIXED order -- 64 outputs per block, the
 // partials dealt to 4 thread slices (p = slice, slice + 4, ...) that are combined as (s0 + s1) + (s2 + s3).  Deterministic, and 16x
 // the parallelism of one thread per output (which took 28 us per call behind k_ln_bwd's 512 partials).

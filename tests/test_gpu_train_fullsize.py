@@ -98,6 +98,30 @@ def test_gradient_of_64_clips_is_the_sum_of_its_halves_and_bit_reproducible():
         assert rel_l2((a + b).cpu().numpy(), f.cpu().numpy()) < 2e-5, f"L{i // 12}.{LAYER_TENSORS[i % 12]}"
 
 
+def test_layernorm_backward_in_the_dgrad_epilogue_equals_the_two_launches(monkeypatch):
+    """DEpiLnBwd (csrc/mst_train.h): LayerNorm1's backward behind the FFN1 dgrad product in one launch against the GEMM + k_ln_bwd pair
+    (MST_FUSE_LN_BWD=0, read when the engine is created).  Same products and the same row arithmetic: dL/dh and every weight / bias
+    gradient bit-identical; the LayerNorm-parameter and branch-bias sums are added tile by tile instead of block by block (1e-6)."""
+    from mst_amd.engine import DenoiserEngine
+    eng, w = big_engine()
+    monkeypatch.setenv("MST_FUSE_LN_BWD", "0")
+    two = DenoiserEngine(FE, T, B, device=_dev())
+    two.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, layer_prefix="seqTransEncoder.layers.",
+                        pe=torch.from_numpy(syn.positional_table(5000, 512)))
+    h, r = stream(B)
+    for p in (0.0, 0.1):
+        out_a, d_a, g_a = engine_grads(eng, w, h, r, p, 77)
+        out_b, d_b, g_b = engine_grads(two, w, h, r, p, 77)
+        assert torch.equal(out_a, out_b) and torch.equal(d_a, d_b), p
+        for i, (a, b) in enumerate(zip(g_a, g_b)):
+            name = f"L{i // 12}.{LAYER_TENSORS[i % 12]}"
+            if LAYER_TENSORS[i % 12] in ("norm1.weight", "norm1.bias", "self_attn.out_proj.bias"):
+                assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-6, (name, p)
+            else:
+                assert torch.equal(a, b), (name, p)
+    del two
+
+
 def test_finetune_objective_at_64_clips_is_finite_and_seeded():
     """One fine-tune iteration exactly as bench.py --mode finetune / train/training_loop.py:249-263 issue it: the 64-clip
     text-to-motion call, the 6 chained single-clip DDIM steps, the frozen motion encoder, backward, fused AdamW."""

@@ -1,0 +1,6 @@
+# two keep-mask bits per dropout hash (drop_keep<N>): every test that touches dropout, then the fine-tune iteration against the previous library
+set -e
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+timeout -k 10 1000 python -m pytest tests/test_gpu_train.py tests/test_gpu_train_fullsize.py tests/test_gpu_boundary.py tests/test_gpu_training_loop.py tests/test_gpu_fused_ops.py -x -q > gpurun_out/ph_tests.txt 2>&1 || { tail -30 gpurun_out/ph_tests.txt; exit 1; }
+tail -2 gpurun_out/ph_tests.txt
+bash tools/ft_lib_ab.sh build/ab/prev.so default
