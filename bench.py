@@ -438,6 +438,17 @@ def finetune_roofline(B, world, s_per_iter, wgrad=None):
            "frac": round(achieved / (MFMA_PEAK_TFLOPS * world), 4), "traffic": None,
            "algorithmic_gflop_per_iteration_per_gpu": round(fl * 1e-9, 1),
            "kernel": None, "note": "whole iteration (objective + backward + AdamW) over the dense MFMA peak"}
+    # The other roofline: the activation tape.  Algorithmic HBM bytes per layer in units of rows x 512 bytes (every input read once, every
+    # output written once): forward 56 (QKV 8, attention 8, out-proj + LayerNorm 14, FFN1 10, FFN2 + LayerNorm 16),
+    # dgrad chain 76, weight / bias gradients 34 (frozen stacks: none).  One iteration = the B-clip call (all three), the frozen motion
+    # encoder on B clips (forward + dgrad) and the six chained single-clip calls (all three).
+    S, unit = 197, 512
+    tape = 8 * unit * (B * S * (56 + 76 + 34) + B * S * (56 + 76) + 6 * S * (56 + 76 + 34))
+    out["tape_traffic"] = {"algorithmic_gb_per_iteration_per_gpu": round(tape * 1e-9, 2),
+                           "achieved_tb_per_s": round(world * tape / s_per_iter * 1e-12, 3), "hbm_peak_tb_per_s": 8.0 * world,
+                           "frac": round(tape / s_per_iter * 1e-12 / 8.0, 4),
+                           "note": "the training launches sit on NEITHER roofline: each moves 52-103 MB of tape at 1.8-3.3 TB/s behind a serial "
+                                   "burst -> product -> epilogue per workgroup (docs/LAB_NOTES.md R5.7: rebuilding the GEMM main loops changed nothing)"}
     if wgrad and wgrad.get("launches"):
         n, iters = wgrad["launches"], wgrad["iterations"]
         avg_us = 1e3 * wgrad["total_ms"] / n - wgrad["event_pair_overhead_us"]
