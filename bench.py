@@ -493,6 +493,7 @@ def finetune_main(args):
     import torch
     import mst_amd  # noqa: F401
     from mst_amd import sharding, synthetic as syn
+    from mst_amd.diffusion.resample import host_to_device_async
     from mst_amd.finetune_dp import LayerBucketReducer
     from mst_amd.model.mdm_forstyledataset import StyleDiffusion
     from mst_amd.optim import FusedAdamW
@@ -525,7 +526,9 @@ def finetune_main(args):
     red = LayerBucketReducer(model)
 
     def iteration(reduce=True):
-        tt = torch.randint(0, 6, (B,), generator=gen).to(dev)                    # range((1000 - 700) / 1000 * 20), training_loop.py:247
+        # range((1000 - 700) / 1000 * 20), training_loop.py:247; onto the device as UniformSampler.sample does it (pinned staging, no
+        # blocking copy: the host is not tied to the GPU once per iteration -- diffusion/resample.py host_to_device_async)
+        tt = host_to_device_async(torch.randint(0, 6, (B,), generator=gen), dev)
         red.zero_grad()
         red.enabled = reduce
         terms = d_ddim.few_shot_style_finetune_losses(model, t2m, tt, content, style, skip_steps=700, model_kwargs=y1,

@@ -173,6 +173,7 @@ struct mst_engine {
     f16 *w_pose_in_pk = nullptr, *w_pose_out_pk = nullptr;      // the two projections as per-wave fragment streams (mst_embed.h, k_pack_wave_blocks)
     bool pose_in_dirty = true, pose_out_dirty = true;          // ... older than w_pose_in / w_pose_out: repacked by ensure_packed()
     int small_ln = 1, small_ln_m = 512;   // ... with the LayerNorms inside the consuming GEMMs, up to this many stream rows (MST_SMALL_LN, MST_SMALL_LN_M; tools/experiments/r4_small_sweep.sh: ahead through 2 clips x 197 rows, behind from 4)
+    int train_fuse_tail = 1;              // training forward at batch size: out-proj + LN1 + FFN + LN2 as k_layer_tail_train, writing the tape (MST_TRAIN_FUSE_TAIL=0: three ring GEMMs)
     int fuse_ln_bwd = 1;                  // training at batch size: LayerNorm1's backward in the epilogue of the dgrad GEMM in front of it (MST_FUSE_LN_BWD=0: two launches)
     int small_fast = 1;                   // small launches: the layer GEMMs as the kernels of mst_small.h (MST_SMALL_FAST=0: the slab ring)
     int fuse_embed = 1;                   // a sampling step's output projection also embeds the next step (MST_FUSE_EMBED=0: two launches)
@@ -200,6 +201,7 @@ struct mst_engine {
     int trunk_groups = 0;                 // MST_TRUNK=1: the encoder stack of a sampling step as ONE launch of resident workgroup groups (mst_trunk.h)
     unsigned* trunk_cnt = nullptr;        // [max_rows][32]: a clip's arrival counter (one 128-byte line each); every launch finds it at 0 and leaves it at 0
     unsigned* trunk_err = nullptr;        // pinned host word the kernel sets when a bounded spin gives up (mst_trunk_check)
+    bool trunk_used = false;              // a resident-group launch was enqueued since the last check: mst_forward / mst_sample_loop synchronise and read trunk_err
     void* trunk_layers = nullptr;         // TrunkLayer[num_layers] in device memory: the layers' pointers (fixed at creation), uploaded at the first such launch
     int fuse_frames = 1;                  // sampling loop: a step's epilogue writes the next step's f16 frame rows; MST_FUSE_FRAMES=0 runs k_frames_f16 every step
     int precise = 0;                      // mst_set_precise / MST_PRECISE=1: every layer GEMM of the sampling path multiplies its activation as hi + lo (the small-tile
@@ -386,6 +388,7 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     if (const char* v = getenv("MST_FUSE_EMBED")) e->fuse_embed = atoi(v) != 0;
     if (const char* v = getenv("MST_SMALL_FAST")) e->small_fast = atoi(v) != 0;
     if (const char* v = getenv("MST_FUSE_LN_BWD")) e->fuse_ln_bwd = atoi(v) != 0;
+    if (const char* v = getenv("MST_TRAIN_FUSE_TAIL")) e->train_fuse_tail = atoi(v) != 0;
     if (const char* v = getenv("MST_SMALL_LN")) e->small_ln = atoi(v) != 0;
     if (const char* v = getenv("MST_SMALL_LN_M")) e->small_ln_m = atoi(v);
     if (const char* v = getenv("MST_TAIL_NTB")) { int n = atoi(v); e->tail_ntb = (n >= 2 && n <= 4) ? n : 0; }
@@ -982,7 +985,20 @@ static int launch_trunk_groups(mst_engine* e, const WS& ws, int S, int rows, hip
     CHECK(ensure_dyn_lds((const void*)k_trunk_groups<13>, TT::SMEM));
     hipLaunchKernelGGL(k_trunk_groups<13>, dim3(4 * groups), dim3(512), TT::SMEM, st, a);
     HIPCHECK(hipGetLastError());
+    e->trunk_used = true;
     return 0;
+}
+// The error word is written by the kernel when it RUNS; a loop enqueues hundreds of steps ahead, so reading it at enqueue time is always
+// stale.  Every ABI call that may have used the resident launch therefore ends with a synchronisation of its stream and
+// this check: a give-up (the four blocks of a group not co-resident -- the launch rests on in-order dispatch of at most 256 one-per-CU
+// blocks, which another process or a busy foreign stream on the same GPU can break) is an ERROR of that call, never a wrong sample.
+static int trunk_settle(mst_engine* e, hipStream_t st, int rc) {
+    if (!e->trunk_used) return rc;
+    e->trunk_used = false;
+    if (hipStreamSynchronize(st) != hipSuccess) return rc ? rc : fail("resident-group trunk: synchronisation failed");
+    if (e->trunk_err[0]) return fail("resident-group trunk: a hand-off wait gave up (groups not co-resident?); the results of this call are invalid -- "
+                                     "mst_set_trunk_groups(e, 0) returns to one launch per kernel");
+    return rc;
 }
 extern "C" int mst_trunk_check(mst_engine* e) {          // after a synchronisation: did every hand-off of the resident-group launches arrive?
     if (!e) return fail("mst_trunk_check: null engine");
@@ -1306,7 +1322,7 @@ extern "C" int mst_forward(mst_engine* e, const float* x, const int64_t* t, cons
     CHECK(run_trunk(e, ws, x, batch, rows, frames, -1, batch, st, batch));
     StepArgs sa{};
     sa.scale = scale;
-    return launch_out_nt<0>(e, ws, cfg, batch, frames, out, sa, st, nullptr, nullptr, 1, false, true);
+    return trunk_settle(e, st, launch_out_nt<0>(e, ws, cfg, batch, frames, out, sa, st, nullptr, nullptr, 1, false, true));
 }
 
 // How many independent clip slices a loop over `batch` clips of `frames` frames runs as.  Measured, same box, interleaved
@@ -1527,7 +1543,7 @@ extern "C" int mst_sample_loop(mst_engine* e, const mst_schedule* s, const mst_l
     }
     e->prof_now = 0;
     if (hipEventRecord(e->ev_out, st) == hipSuccess) (void)hipStreamWaitEvent(caller, e->ev_out, 0);
-    return rc;
+    return trunk_settle(e, st, rc);
 }
 
 // ------------------------------------------------------------------------------------------ elementwise ABI
@@ -1766,6 +1782,19 @@ static int train_stack_forward(mst_engine* e, const Tape& t, int rows, int S, fl
             HIPCHECK(hipGetLastError());
         }
     }
+    // round 6: everything of a layer behind the attention as ONE launch (k_layer_tail_train, mst_tail.h) that writes the tape slots
+    // itself -- the sampling path's fused tail with dropout at the three sites, instead of three ring GEMMs moving 52-103 MB each
+    const bool fused_tail = !small && e->train_fuse_tail && e->fuse_tail;
+    if (fused_tail) {
+        for (int l = 0; l < nl; l++) {
+            LayerW& w = e->L[l];
+            if (!w.tail_dirty) continue;
+            hipLaunchKernelGGL(k_pack_tail, dim3(640), dim3(256), 0, st, w.w_out, w.w1, w.w2, w.wtail);
+            HIPCHECK(hipGetLastError());
+            w.tail_dirty = false;
+        }
+        CHECK(ensure_dyn_lds((const void*)k_layer_tail_train<4>, TailCfg::SMEM));
+    }
     for (int l = 0; !small && l < nl; l++) {
         const LayerW& w = e->L[l];
         const TapeL& a = t.L[l];
@@ -1774,6 +1803,14 @@ static int train_stack_forward(mst_engine* e, const Tape& t, int rows, int S, fl
             CHECK((launch_wide(M, 3 * MST_D / 256, RowsDirect{t.sh[l], MST_D}, w.w_in, MST_D, MST_D, epi, st)));
         }
         CHECK(launch_attn_train(a.qkv, a.att, S, rows, make_drop(seed, l, 0, p_drop, o0), key_keep, 0, a.lse, st));
+        if (fused_tail) {
+            auto td = [&](int site, uint32_t off) { const Drop d = make_drop(seed, l, site, p_drop, off); return TailDrop{d.key, d.thr, d.inv}; };
+            const TailTrain tt{t.sh[l], t.sl[l], a.z1h, a.z1l, a.x1h, a.x1l, a.pre, a.hid, a.z2h, a.z2l, td(1, o1), td(2, o2), td(3, o1)};
+            hipLaunchKernelGGL(k_layer_tail_train<4>, dim3((M + 63) / 64), dim3(512), TailCfg::SMEM, st, a.att, w.wtail, w.b_out, w.g1, w.be1,
+                               w.b1, w.b2, w.g2, w.be2, t.sh[l + 1], t.sl[l + 1], e->gelu_tab, M, tt);
+            HIPCHECK(hipGetLastError());
+            continue;
+        }
         {
             DEpiResidLNTrain epi{w.b_out, w.g1, w.be1, t.sh[l], t.sl[l], a.z1h, a.z1l, a.x1h, a.x1l, M, make_drop(seed, l, 1, p_drop, o1)};
             CHECK((launch_gemm_dma<64, 512, 2, 2, LN_NS, 1, LN_BK>(dim3((M + 63) / 64, 1), RowsDirect{a.att, MST_D}, w.w_out, MST_D, MST_D, epi, st)));

@@ -34,6 +34,9 @@
 #define MST_TAIL_OUT 0        // k_layer_tail's LayerNorm2 stores: 0 = 8 bytes per lane, plain; 1 = those write-through; 2 = 16 bytes per lane (a lane holds
                               // 8 consecutive features), plain; 3 = those write-through (tools/r5_tail_out_ab.sh)
 #endif
+#ifndef MST_TAIL_AWAIT_FLAT
+#define MST_TAIL_AWAIT_FLAT 0
+#endif
 #ifndef TAIL_MARK            // probes/tail_clock.hip defines it (with MST_PROBE_BUILD) to stamp the phases; the product build has none
 #define TAIL_MARK(i)
 #endif
@@ -53,10 +56,12 @@ struct TailCfg {
     // padded to 13 KB = 13 LDS-DMA pieces.  Linear interpolation error <= h^2 / 8 max|Phi''| = 1.9e-6, far below the f16 store (2^-11).
     static constexpr int GELU_N = 1536, GELU_TAB_BYTES = 13 * 1024;
     static constexpr int OFF_TAB = 69 * 1024;
+    static constexpr int OFF_EXCH_TR = 84 * 1024;        // TRAIN: LayerNorm1's 4 KB statistics exchange (the att image holds the residual's lo rows then)
     static constexpr int OFF_B1 = 92 * 1024;             // FFN1 bias (4 KB), staged at kernel start
     static constexpr int OFF_X1 = 96 * 1024;             // LayerNorm1 output, 64 x 1 KB; during phase P the residual rows (lo, then hi) are staged here
     static constexpr int SMEM = 160 * 1024;
-    static_assert(64 * 1024 <= OFF_CNT && OFF_CNT + 16 <= OFF_TAB && OFF_TAB + GELU_TAB_BYTES <= OFF_B1 && 64 * LN_LD <= SMEM && 2 * HBUF <= OFF_CNT, "LDS map");
+    static_assert(64 * 1024 <= OFF_CNT && OFF_CNT + 16 <= OFF_TAB && OFF_TAB + GELU_TAB_BYTES <= OFF_B1 && 64 * LN_LD <= SMEM && 2 * HBUF <= OFF_CNT &&
+                  OFF_TAB + GELU_TAB_BYTES <= OFF_EXCH_TR && OFF_EXCH_TR + 4096 <= OFF_B1, "LDS map");
     static_assert(P_FRAG % D == 0 && F1_FRAG % D == 0 && F2_FRAG % D == 0, "every phase starts on prefetch slot 0");
     static_assert(F1_FRAG == 32 && F2_FRAG == 32, "k_pack_tail's unit arithmetic");
 };
@@ -120,6 +125,38 @@ __device__ __forceinline__ float gelu_tab_lds(float x, const char* tab) {
     return x * fmaf(e.y, __builtin_amdgcn_fractf(u), e.x);
 }
 
+// TRAIN instantiation (round 6: the training forward of a 64-clip call / the frozen motion encoder on the fused kernel).  Same tiling,
+// same weight stream; what changes:
+//   * dropout at the layer's three sites behind the attention (out-proj output, hidden, FFN2 output: counter-based keep masks, mst_train.h
+//     `Drop`, the very counters the unfused epilogues and the backward kernels use), so the residuals can no longer ride in the
+//     accumulators: LayerNorm1's residual is added behind the out-proj loop (hi rows staged during the loop as before, lo rows into the
+//     dead att image behind it), LayerNorm2's is re-read from the x1 tape slot;
+//   * the layer's tape slots are written from where the values are: z1 / x1 (hi + lo) from the accumulator layout, pre / hid from the
+//     GELU stage (8 bytes per lane, inside the FFN2 passes: stores count in vmcnt IN ISSUE ORDER with the weight fragments, so every
+//     hand-counted wait of the stream stays sufficient -- it waits for a few stores more than it needs), z2 and the layer output as rows;
+//   * input and output streams are different buffers (tape slots l and l + 1).
+// Dropout needs mst_train.h's Drop; the struct is repeated here as a POD so that this header does not depend on the training header.
+struct TailDrop { uint32_t key, thr; float inv; };
+__device__ __forceinline__ uint32_t tail_mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+#if MST_TT_NOHASH          // A/B probe builds only (never the product): what the keep-mask hash costs inside the fused training tail
+__device__ __forceinline__ float tail_drop_mul(const TailDrop& d, uint32_t idx) { return d.inv; }
+#else
+__device__ __forceinline__ float tail_drop_mul(const TailDrop& d, uint32_t idx) { return tail_mix32(idx * 0x9E3779B9u + d.key) >= d.thr ? d.inv : 0.f; }
+#endif
+#if MST_TT_NOSTORE         // A/B probe builds only: the tape stores of the accumulator-layout stages dropped (wrong gradients; timing only)
+#define TT_STORE(stmt) do { } while (0)
+#else
+#define TT_STORE(stmt) do { stmt; } while (0)
+#endif
+struct TailTrain {
+    const f16 *xin_h, *xin_l;                                     // the layer's input stream (tape slot l): LayerNorm1's residual
+    f16 *z1h, *z1l, *x1h, *x1l, *pre, *hid, *z2h, *z2l;           // tape slots of the layer
+    TailDrop d1, d2, d3;                                          // keep masks: out-proj output [tok][512], hidden [tok][1024], FFN2 output [tok][512]
+};
+
 __device__ __forceinline__ void tail_glds1(unsigned voff, unsigned long long sbase, unsigned lds_dst) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
@@ -134,14 +171,17 @@ __device__ __forceinline__ void tail_glds1(unsigned voff, unsigned long long sba
 // workgroup; the resident-group trunk (mst_trunk.h) calls it once per layer with PERSIST = true: the tables, the FFN1 bias and the first D
 // weight fragments are requested, THEN the workgroup waits for its clip's four attention heads (group_wait) and only then requests its
 // att rows; LayerNorm2's rows leave as write-through stores.
-template <int NTB, bool PERSIST>
+template <int NTB, bool PERSIST, bool TRAIN = false>
 __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ att, const f16* __restrict__ wt,
                                           const float* __restrict__ b_out, const float* __restrict__ g1, const float* __restrict__ be1,
                                           const float* __restrict__ b1, const float* __restrict__ b2,
                                           const float* __restrict__ g2, const float* __restrict__ be2,
                                           f16* __restrict__ hx, f16* __restrict__ hl, const float* __restrict__ gelu_tab, int M, int tok0,
-                                          const GroupSync sync, int wave_in) {
+                                          const GroupSync sync, int wave_in, const TailTrain& tt = TailTrain{}) {
     using C = TailCfg;
+    static_assert(!(TRAIN && PERSIST), "the training forward is one launch per layer");
+    const f16* const rin_h = TRAIN ? tt.xin_h : hx;                // LayerNorm1's residual rows (TRAIN: hx / hl are the OUTPUT stream)
+    const f16* const rin_l = TRAIN ? tt.xin_l : hl;
     constexpr int D = C::D;
     // (PERSIST: the lane index is recomputed in every phase and the wave index arrives in a scalar register, so that no per-lane
     // constant stays alive across the other phases' bodies)
@@ -171,14 +211,14 @@ __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ at
     unsigned* const arrived = reinterpret_cast<unsigned*>(smem + C::OFF_CNT);      // [chunk]: waves whose GELU output of that chunk is in the H image
     if (tid < 4) arrived[tid] = 0;                                                  // published by the barriers in front of the out-proj loop
     // residual rows of the tile -> [OFF_X1, +64 KB) in the att / x1 image layout; wave w fills rows [8 w, 8 w + 8)
-    auto stage_rows = [&](const f16* src) {
+    auto stage_rows = [&](const f16* src, int dst_off = C::OFF_X1) {
 #pragma unroll
         for (int j = 0; j < RPW; j++) {
             const int r = RPW * wave + j;
             int tok = tok0 + r;
             if (tok >= M) tok = M - 1;                                // last tile: clamp (rows beyond M are never stored)
             const unsigned voff = (unsigned)tok * (unsigned)(MST_D * 2) + (unsigned)((lane ^ (r & 15)) << 4);
-            tail_glds1(voff, (unsigned long long)src, __builtin_amdgcn_readfirstlane(smem_base + C::OFF_X1 + r * 1024));
+            tail_glds1(voff, (unsigned long long)src, __builtin_amdgcn_readfirstlane(smem_base + dst_off + r * 1024));
         }
     };
     constexpr int ROW_OPS = RPW;
@@ -310,7 +350,12 @@ __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ at
         static_assert(NPP == 4, "passes 0 | 1: the lo rows land, 2 | 3: the hi rows");
         // Neither half of the residual is part of the kernel-start burst: there, 64 KB more in front of (or behind) the att image
         // delay the first MFMA by 1.5 us (measured both ways).  Requested in front of a pass, the rows travel beside the weight stream.
-        stage_rows(hl);
+        if constexpr (TRAIN) {
+            // the residual joins BEHIND the dropout of (acc + bias): nothing is added inside the loop
+            pass(img, RB1K(), RA4(), LD1(), 0, true, [](int) {});
+            pass(img, RB1K(), RA4(), LD1(), D / 4, true, [](int) {});
+        } else {
+        stage_rows(rin_l);
         pass(img, RB1K(), RA4(), std::integral_constant<int, 1 + 2 * ROW_OPS>(), 0, true, [](int) {});
         pass(img, RB1K(), RA4(), LD1(), D / 4, true, [](int) {});
         // the lo rows are older than the fragments requested by pass 0, which pass 1 has consumed: landed
@@ -330,7 +375,8 @@ __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ at
                     }
         }
         tail_barrier();                                                // everybody has read lo: hi may overwrite it
-        stage_rows(hx);
+        }
+        stage_rows(rin_h);
         pass(img, RB1K(), RA4(), std::integral_constant<int, 1 + 2 * ROW_OPS>(), 2 * (D / 4), true, [](int) {});
         pass(img, RB1K(), RA4(), LD1(), 3 * (D / 4), false, [](int) {});
     }
@@ -345,8 +391,51 @@ __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ at
     tail_barrier();                                                    // every wave's hi rows are in place (each waited for its own fragments behind them); att is dead
     {
         char* x1img = smem + C::OFF_X1;
-        float2* exch = reinterpret_cast<float2*>(smem + C::OFF_ATT);   // [wave][token]: a 16-lane group writes / reads 128 contiguous bytes (no bank conflict)
+        // [wave][token]: a 16-lane group writes / reads 128 contiguous bytes (no bank conflict).  TRAIN: the dead att image receives the
+        // residual's lo rows, so the exchange moves into the free 10 KB between the Phi table and the FFN1 bias
+        float2* exch = reinterpret_cast<float2*>(smem + (TRAIN ? C::OFF_EXCH_TR : C::OFF_ATT));
         float mw[NTB], m2[NTB];
+        if constexpr (TRAIN) {
+            stage_rows(rin_l, C::OFF_ATT);                             // behind the barrier above: nobody reads att any more
+            tail_acc_settle();                                         // (the adds below are inline asm reading MFMA results)
+#pragma unroll
+            for (int nh = 0; nh < 2; nh++)
+#pragma unroll
+                for (int rb = 0; rb < 2; rb++) {
+                    const int f = 256 * nh + 32 * wave + 16 * rb + 4 * q4;
+                    const f32x4 bo = *reinterpret_cast<const f32x4*>(b_out + f);
+#pragma unroll
+                    for (int tb = 0; tb < NTB; tb++) {
+                        const uint32_t idx = (uint32_t)(tok0 + 16 * tb + t16) * (uint32_t)MST_D + (uint32_t)f;
+                        const uint2 h = *reinterpret_cast<const uint2*>(x1img + slot1k(nh, rb, tb));
+                        f32x4 a = acc[nh][rb][tb] + bo;
+                        a = f32x4{a[0] * tail_drop_mul(tt.d1, idx), a[1] * tail_drop_mul(tt.d1, idx + 1), a[2] * tail_drop_mul(tt.d1, idx + 2),
+                                  a[3] * tail_drop_mul(tt.d1, idx + 3)};
+                        acc[nh][rb][tb] = f32x4{add_half<0>(h.x, a[0]), add_half<1>(h.x, a[1]), add_half<0>(h.y, a[2]), add_half<1>(h.y, a[3])};
+                    }
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's lo rows (the youngest operations; the fragments in flight are older)
+            tail_barrier();                                            // ... and everybody's
+            const char* lo = smem + C::OFF_ATT;
+#pragma unroll
+            for (int nh = 0; nh < 2; nh++)
+#pragma unroll
+                for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+                    for (int tb = 0; tb < NTB; tb++) {
+                        const uint2 l = *reinterpret_cast<const uint2*>(lo + slot1k(nh, rb, tb));
+                        f32x4& a = acc[nh][rb][tb];
+                        a = f32x4{add_half<0>(l.x, a[0]), add_half<1>(l.x, a[1]), add_half<0>(l.y, a[2]), add_half<1>(l.y, a[3])};
+                        const int tok = tok0 + 16 * tb + t16;
+                        if (tok < M) {                                 // z1 = x + dropout(att W_out^T + b_out): LayerNorm1's input, hi / lo
+                            const size_t o = (size_t)tok * MST_D + (256 * nh + 32 * wave + 16 * rb + 4 * q4);
+                            uint2 zh, zl;
+                            split4_f16(a, zh, zl);
+                            TT_STORE(*reinterpret_cast<uint2*>(tt.z1h + o) = zh);
+                            TT_STORE(*reinterpret_cast<uint2*>(tt.z1l + o) = zl);
+                        }
+                    }
+        } else {
 #pragma unroll
         for (int nh = 0; nh < 2; nh++)
 #pragma unroll
@@ -359,6 +448,7 @@ __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ at
                     acc[nh][rb][tb] = f32x4{add_half<0>(h.x, a[0]), add_half<1>(h.x, a[1]), add_half<0>(h.y, a[2]), add_half<1>(h.y, a[3])};
                 }
             }
+        }
         auto quad_sum = [](float v) {                                  // over the four q4 groups (lanes l, l ^ 16, l ^ 32, l ^ 48)
             if constexpr (PERSIST) return xor32_add(xor16_add(v));     // (the same two additions: a + b is commutative bit for bit)
             v += __shfl_xor(v, 16);
@@ -407,8 +497,22 @@ __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ at
 #pragma unroll
                 for (int tb = 0; tb < NTB; tb++) {
                     const f32x4 y = __builtin_elementwise_fma(acc[nh][rb][tb] - mean[tb], g * rstd[tb], be);
+                    if constexpr (TRAIN) {
+                        // x1 -> the image (FFN1's operand) and the tape (hi: wgrad operand, hi + lo: LayerNorm2's residual); FFN2 starts from 0
+                        uint2 yh, yl;
+                        split4_f16(y, yh, yl);
+                        *reinterpret_cast<uint2*>(x1img + slot1k(nh, rb, tb)) = yh;
+                        const int tok = tok0 + 16 * tb + t16;
+                        if (tok < M) {
+                            const size_t o = (size_t)tok * MST_D + f;
+                            TT_STORE(*reinterpret_cast<uint2*>(tt.x1h + o) = yh);
+                            TT_STORE(*reinterpret_cast<uint2*>(tt.x1l + o) = yl);
+                        }
+                        acc[nh][rb][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    } else {
                     acc[nh][rb][tb] = y;
                     *reinterpret_cast<uint2*>(x1img + slot1k(nh, rb, tb)) = pack4_f16(y[0], y[1], y[2], y[3]);
+                    }
                 }
             }
         TAIL_MARK(7)
@@ -447,6 +551,20 @@ __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ at
         auto gelu_group = [&](int hc, int rb, int tb) {
             const unsigned coff = (unsigned)(((4 * wave + 2 * rb + (q4 >> 1)) ^ t16) << 4) + 8u * (q4 & 1);
             const f32x4 v = acch[rb][tb];
+            if constexpr (TRAIN) {
+                // pre (the f16 the backward's GELU' reads) and hid = dropout(GELU(pre)) -> the tape; hid -> the H image
+                const uint2 p16 = pack4_f16(v[0], v[1], v[2], v[3]);
+                const f16x4 ph = __builtin_bit_cast(f16x4, p16);
+                const int tok = tok0 + 16 * tb + t16;
+                const uint32_t o = (uint32_t)tok * (uint32_t)MST_FF + (uint32_t)(256 * hc + 32 * wave + 16 * rb + 4 * q4);
+                const uint2 h16 = pack4_f16(gelu_tab_lds((float)ph[0], gtab) * tail_drop_mul(tt.d2, o), gelu_tab_lds((float)ph[1], gtab) * tail_drop_mul(tt.d2, o + 1),
+                                            gelu_tab_lds((float)ph[2], gtab) * tail_drop_mul(tt.d2, o + 2), gelu_tab_lds((float)ph[3], gtab) * tail_drop_mul(tt.d2, o + 3));
+                *reinterpret_cast<uint2*>(smem + C::OFF_H + (hc & 1) * C::HBUF + (16 * tb + t16) * 512 + coff) = h16;
+                if (tok < M) {
+                    TT_STORE(*reinterpret_cast<uint2*>(tt.pre + o) = p16);
+                    TT_STORE(*reinterpret_cast<uint2*>(tt.hid + o) = h16);
+                }
+            } else
             *reinterpret_cast<uint2*>(smem + C::OFF_H + (hc & 1) * C::HBUF + (16 * tb + t16) * 512 + coff) =
                 pack4_f16(gelu_tab_lds(v[0], gtab), gelu_tab_lds(v[1], gtab), gelu_tab_lds(v[2], gtab), gelu_tab_lds(v[3], gtab));
         };
@@ -455,9 +573,22 @@ __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ at
             if (lane == 0) __hip_atomic_fetch_add(arrived + hc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             tail_fence();
         };
+        // The poll is a ds_read_b32 written out: through a `volatile unsigned*` hipcc loses the address space (the pointer is a generic one
+        // by then) and emits flat_load_dword + s_waitcnt vmcnt(0) lgkmcnt(0) -- every await DRAINED the weight stream (found in round 6 in
+        // the ISA of the shipped kernel: four full drains per tile).  MST_TAIL_AWAIT_FLAT=1 brings the old poll back (A/B builds).
         auto await = [&](int hc) {
             tail_fence();
+#if MST_TAIL_AWAIT_FLAT
             while (__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile unsigned*>(arrived + hc)) < 8u) __builtin_amdgcn_s_sleep(1);
+#else
+            const unsigned caddr = smem_base + C::OFF_CNT + 4u * (unsigned)hc;
+            for (;;) {
+                unsigned v;
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(caddr) : "memory");
+                if (__builtin_amdgcn_readfirstlane(v) >= 8u) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+#endif
             tail_fence();
         };
         static_assert(C::F2_FRAG / 4 == 8 && 2 * NTB <= 8, "FFN2 of a chunk = eight k-steps: at most one GELU group (rb, tb) per k-step");
@@ -520,6 +651,45 @@ __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ at
         const f32x4 ea = *reinterpret_cast<const f32x4*>(be2 + fa), eb = *reinterpret_cast<const f32x4*>(be2 + fb);
         f32x4 xa[RPW], xb[RPW];
         float mean[RPW], rstd[RPW];
+        if constexpr (TRAIN) {
+            // z2 = x1 + dropout(hid W2^T + b2): x1 (hi + lo) comes back from the tape slot LayerNorm1 wrote (every wave has since consumed
+            // weight fragments requested behind those stores, and operations complete in issue order: the stores are in L2; this CU never
+            // read the lines, so its L1 holds no older copy)
+            uint2 r1[RPW][4];
+#pragma unroll
+            for (int r = 0; r < RPW; r++) {
+                int tok = tok0 + RPW * wave + r;
+                if (tok >= M) tok = M - 1;
+                const size_t off = (size_t)tok * MST_D;
+                r1[r][0] = *reinterpret_cast<const uint2*>(tt.x1h + off + fa);
+                r1[r][1] = *reinterpret_cast<const uint2*>(tt.x1l + off + fa);
+                r1[r][2] = *reinterpret_cast<const uint2*>(tt.x1h + off + fb);
+                r1[r][3] = *reinterpret_cast<const uint2*>(tt.x1l + off + fb);
+            }
+#pragma unroll
+            for (int r = 0; r < RPW; r++) {
+                const char* srow = smem + (RPW * wave + r) * C::LN_LD;
+                const int tok = tok0 + RPW * wave + r;
+                const uint32_t ia = (uint32_t)tok * (uint32_t)MST_D + (uint32_t)fa, ib = (uint32_t)tok * (uint32_t)MST_D + (uint32_t)fb;
+                f32x4 a = *reinterpret_cast<const f32x4*>(srow + fa * 4) + ba, b = *reinterpret_cast<const f32x4*>(srow + fb * 4) + bb;
+                a = f32x4{a[0] * tail_drop_mul(tt.d3, ia), a[1] * tail_drop_mul(tt.d3, ia + 1), a[2] * tail_drop_mul(tt.d3, ia + 2), a[3] * tail_drop_mul(tt.d3, ia + 3)};
+                b = f32x4{b[0] * tail_drop_mul(tt.d3, ib), b[1] * tail_drop_mul(tt.d3, ib + 1), b[2] * tail_drop_mul(tt.d3, ib + 2), b[3] * tail_drop_mul(tt.d3, ib + 3)};
+                xa[r] = add4_f16(r1[r][0], r1[r][1], a);
+                xb[r] = add4_f16(r1[r][2], r1[r][3], b);
+                if (tok < M) {
+                    const size_t off = (size_t)tok * MST_D;
+                    uint2 zh, zl;
+                    split4_f16(xa[r], zh, zl);
+                    *reinterpret_cast<uint2*>(tt.z2h + off + fa) = zh;
+                    *reinterpret_cast<uint2*>(tt.z2l + off + fa) = zl;
+                    split4_f16(xb[r], zh, zl);
+                    *reinterpret_cast<uint2*>(tt.z2h + off + fb) = zh;
+                    *reinterpret_cast<uint2*>(tt.z2l + off + fb) = zl;
+                }
+                const f32x4 t = xa[r] + xb[r];
+                mean[r] = wave_sum((t[0] + t[1]) + (t[2] + t[3])) * (1.0f / MST_D);
+            }
+        } else {
 #pragma unroll
         for (int r = 0; r < RPW; r++) {
             const char* srow = smem + (RPW * wave + r) * C::LN_LD;
@@ -527,6 +697,7 @@ __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ at
             xb[r] = *reinterpret_cast<const f32x4*>(srow + fb * 4) + bb;
             const f32x4 t = xa[r] + xb[r];
             mean[r] = wave_sum((t[0] + t[1]) + (t[2] + t[3])) * (1.0f / MST_D);
+        }
         }
 #pragma unroll
         for (int r = 0; r < RPW; r++) {
@@ -576,6 +747,18 @@ __global__ __launch_bounds__(512) void k_layer_tail(const f16* __restrict__ att,
                                                     f16* __restrict__ hx, f16* __restrict__ hl, const float* __restrict__ gelu_tab, int M) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     tail_body<NTB, false>(smem, att, wt, b_out, g1, be1, b1, b2, g2, be2, hx, hl, gelu_tab, M, blockIdx.x * (16 * NTB), GroupSync{nullptr, 0u, nullptr}, 0);
+}
+
+// The training forward's launch: tape slots of layer l in `tt`, the layer's output stream (slot l + 1) in hx / hl.
+template <int NTB>
+__global__ __launch_bounds__(512) void k_layer_tail_train(const f16* __restrict__ att, const f16* __restrict__ wt,
+                                                          const float* __restrict__ b_out, const float* __restrict__ g1, const float* __restrict__ be1,
+                                                          const float* __restrict__ b1, const float* __restrict__ b2,
+                                                          const float* __restrict__ g2, const float* __restrict__ be2,
+                                                          f16* __restrict__ hx, f16* __restrict__ hl, const float* __restrict__ gelu_tab, int M,
+                                                          const TailTrain tt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    tail_body<NTB, false, true>(smem, att, wt, b_out, g1, be1, b1, b2, g2, be2, hx, hl, gelu_tab, M, blockIdx.x * (16 * NTB), GroupSync{nullptr, 0u, nullptr}, 0, tt);
 }
 
 }  // namespace mst

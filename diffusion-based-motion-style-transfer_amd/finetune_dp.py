@@ -83,11 +83,14 @@ class LayerBucketReducer:
         self.launch_order.append(b["layer"])
         self.launched_in.append(where)
 
-    def _native_layer_ready(self, eng):
+    def _native_layer_ready(self, eng, after=None):
         """Called by the LAST native node of a backward pass right after its backward call returned (GPU work enqueued, not
-        finished): start every layer's exchange behind that layer's gradient event."""
+        finished): start every layer's exchange behind that layer's gradient event.  after: a CUDA event behind gradient sums that
+        were added OUTSIDE the engine's own streams (GradSink.join_chain on the caller's stream); the exchange waits for it too."""
         if all(b["launched"] for b in self.buckets):
             raise RuntimeError(self._TWICE)
+        if after is not None:
+            self.comm.wait_event(after)
         for b in self.buckets:
             if b["launched"]:
                 continue

@@ -51,7 +51,7 @@ class GradSink:
         self.ids = tuple(id(p) for p in params)
         self.flat, self.views, self.active, self.task = None, None, False, -1
         self.open_nodes = 0            # native nodes with parameter gradients created since the last backward pass ended
-        self.pending = None            # (side stream, private accumulators) of a chained backward pass still running beside this one
+        self.pending = None            # (side stream, private accumulators, caller's stream) of a chained backward pass still running beside this one
 
     def abort(self):
         """A backward pass died (the autograd engine drops queued callbacks when a node raises): forget its partial sums."""
@@ -61,18 +61,30 @@ class GradSink:
         self.pending = None
 
     def join_chain(self):
-        """The chained single-clip calls were differentiated on a side stream into accumulators of their own (ChainedCalls.finish): wait
-        for that pass on the CURRENT stream and add its sums into this pass's accumulators.  Called before the next native node of the
-        pass accumulates (in the fine-tune objective: the 64-clip call, ~2 ms after the chain's pass started, so nothing waits), before
-        a gradient reducer is told that layers are ready, and at the end of the pass.  x + 0 is exact, so the gradients are bit for bit
-        those of the in-line pass."""
+        """The chained single-clip calls were differentiated on a side stream into accumulators of their own (ChainedCalls.finish): make
+        the CALLER's stream (the one the chain was opened on; named explicitly: this runs from inside the chain node's own backward too,
+        where the current stream IS the side stream -- ADVICE round 5) wait for that pass and add its sums into this pass's accumulators
+        there.  Called before the next native node of the pass accumulates (in the fine-tune objective: the 64-clip call, ~2 ms after
+        the chain's pass started, so nothing waits), before a gradient reducer is told that layers are ready, and at the end of the
+        pass.  x + 0 is exact, so the gradients are bit for bit those of the in-line pass."""
         if self.pending is None:
-            return
-        side, cviews = self.pending
+            return None
+        side, cviews, main = self.pending
         self.pending = None
-        torch.cuda.current_stream(cviews[0].device).wait_stream(side)
-        if self.views is not None:
-            torch._foreach_add_(list(self.views), list(cviews))
+        if main is None:
+            main = torch.cuda.current_stream(cviews[0].device)
+        main.wait_stream(side)
+        with torch.cuda.stream(main):
+            if self.views is not None:
+                torch._foreach_add_(list(self.views), list(cviews))
+            # the private accumulators may be zeroed (on the side stream) only behind this add
+            free = torch.cuda.Event()
+            free.record(main)
+        self.host.__dict__["_mst_chain_acc_free"] = free
+        cur = torch.cuda.current_stream(cviews[0].device)
+        if cur != main:
+            cur.wait_stream(main)          # whoever asked for the join reads the sums on ITS stream
+        return free                        # recorded on the caller's stream behind the add (a reducer told "ready" right now waits for it)
 
     def begin(self, device):
         grads = [p.grad for p in self.params]
@@ -170,8 +182,10 @@ def _node_done(ctx, had_param_grads):
     sink.open_nodes -= 1
     ready = getattr(ctx.host, "_native_layer_ready", None)
     if sink.open_nodes == 0 and ready is not None and sink.flat is None:      # in-place mode: p.grad IS the reducer's bucket
-        sink.join_chain()
-        ready(ctx.eng)
+        # (the chain as the pass's LAST node: its sums are added on the caller's stream HERE, behind everything the earlier nodes
+        # accumulated there; the engine's per-layer events do not cover that add, so the reducer also waits for `after`)
+        after = sink.join_chain()
+        ready(ctx.eng, after)
 
 
 def _CHAIN_ON():
@@ -310,13 +324,24 @@ class ChainedCalls:
                 # next native node accumulates.  ~160 launch-bound kernels on six clips' token rows no longer sit in front of those passes.
                 sink = _sink_of(ctx.host, ctx.params)
                 cflat, cviews = _chain_accumulators(ctx.host, ctx.params, self.dbuf.device)
-                self.side.wait_stream(torch.cuda.current_stream(self.dbuf.device))     # (through the end-of-pass callback this runs on the caller's stream)
+                cur = torch.cuda.current_stream(self.dbuf.device)
+                if cur != self.side:
+                    self.side.wait_stream(cur)       # (through the end-of-pass callback this runs on the caller's stream: the copies into dbuf)
+                # A second chain of the SAME backward pass (two objective evaluations summed into one loss): the first
+                # chain's sums are still waiting in the private accumulators for join_chain -- keep adding on the same side stream.
+                again = sink.pending is not None and sink.pending[0] is self.side and sink.pending[1] is cviews
+                if sink.pending is not None and not again:
+                    sink.join_chain()
                 with torch.cuda.stream(self.side):
-                    cflat.zero_()
+                    if not again:
+                        free = ctx.host.__dict__.get("_mst_chain_acc_free")
+                        if free is not None:
+                            self.side.wait_event(free)       # the previous join's add (on the caller's stream) has read them
+                        cflat.zero_()
                     ctx.eng.train_model_backward(tape, self.dbuf, ctx.p_drop, ctx.p_pe, self.seed, cviews, need_input_grad=False)
                 self.dbuf.record_stream(self.side)
                 tape.record_stream(self.side)
-                sink.pending = (self.side, cviews)
+                sink.pending = (self.side, cviews, self.main)
             elif self.main is not None:
                 # autograd runs this node on the side stream (its forward's); the pass itself belongs on the caller's stream, behind
                 # the gradients the side stream has just copied in (report() ran there; through the end-of-pass callback this code is on
