@@ -1919,7 +1919,7 @@ static int wgrad(mst_engine* e, const f16* dY, int n_out, const f16* X, int k_in
         hipLaunchKernelGGL(k_colsum_f16, dim3(n_out / 256, nrb), dim3(256), 0, st, dY, n_out, M, rpb, t.gscale, db, t.cs_part);
         HIPCHECK(hipGetLastError());
         if (nrb > 1) {
-            hipLaunchKernelGGL(k_sum_partials, dim3((n_out + 63) / 64), dim3(256), 0, st, t.cs_part, nrb, n_out, t.gscale, db);
+            hipLaunchKernelGGL(k_sum_partials, dim3((n_out + kFinOut - 1) / kFinOut), dim3(256), 0, st, t.cs_part, nrb, n_out, t.gscale, db);
             HIPCHECK(hipGetLastError());
         }
     }
@@ -1983,7 +1983,7 @@ static int train_stack_backward(mst_engine* e, const Tape& t, int rows, int S, f
         // LayerNorm2 backward: gB -> dz2 (gA, fp32) and the branch gradient dbr2 (f16); dgamma2, dbeta2, db2
         hipLaunchKernelGGL(ln_bwd, dim3(ln_blocks), dim3(64 * ln_wpb), 0, st, gB, a.z2h, a.z2l, w.g2, M, make_drop(seed, l, 3, p_drop), w_.gscale,
                            gA, dbr2, w_.ln_part);
-        if (wg) hipLaunchKernelGGL(k_ln_bwd_finish, dim3(3 * MST_D / 64), dim3(256), 0, st, w_.ln_part, ln_blocks, w_.gscale, G[10], G[11], G[7]);
+        if (wg) hipLaunchKernelGGL(k_ln_bwd_finish, dim3(3 * MST_D / kFinOut), dim3(256), 0, st, w_.ln_part, ln_blocks, w_.gscale, G[10], G[11], G[7]);
         HIPCHECK(hipGetLastError());
         TO_SIDE()
         if (wg) CHECK(wgrad(e, dbr2, MST_D, a.hid, MST_FF, M, G[6], nullptr, sw));                 // dW2 += dbr2^T hid
@@ -1999,7 +1999,7 @@ static int train_stack_backward(mst_engine* e, const Tape& t, int rows, int S, f
             // g(x1) = dpre W1 + dz2 and LayerNorm1's backward behind it in ONE launch (DEpiLnBwd): dz1 -> gA in place, dbr1, the tiles' sums
             DEpiLnBwd epi{gA, a.z1h, a.z1l, w.g1, M, make_drop(seed, l, 1, p_drop), gA, dbr1, w_.ln_part};
             CHECK((launch_gemm_dma<64, 512, 2, 2, LN_NS, 1, LN_BK>(dim3(ln_tiles, 1), RowsDirect{dpre, MST_FF}, w.w1T, MST_FF, MST_FF, epi, st)));
-            if (wg) hipLaunchKernelGGL(k_ln_bwd_finish, dim3(3 * MST_D / 64), dim3(256), 0, st, w_.ln_part, ln_tiles, w_.gscale, G[8], G[9], G[3]);
+            if (wg) hipLaunchKernelGGL(k_ln_bwd_finish, dim3(3 * MST_D / kFinOut), dim3(256), 0, st, w_.ln_part, ln_tiles, w_.gscale, G[8], G[9], G[3]);
             HIPCHECK(hipGetLastError());
         } else {
         // g(x1) = dpre W1 + dz2  -> gB
@@ -2011,7 +2011,7 @@ static int train_stack_backward(mst_engine* e, const Tape& t, int rows, int S, f
         // LayerNorm1 backward: gB -> dz1 (gA), dbr1 = d(out-proj output); dgamma1, dbeta1, db_out
         hipLaunchKernelGGL(ln_bwd, dim3(ln_blocks), dim3(64 * ln_wpb), 0, st, gB, a.z1h, a.z1l, w.g1, M, make_drop(seed, l, 1, p_drop), w_.gscale,
                            gA, dbr1, w_.ln_part);
-        if (wg) hipLaunchKernelGGL(k_ln_bwd_finish, dim3(3 * MST_D / 64), dim3(256), 0, st, w_.ln_part, ln_blocks, w_.gscale, G[8], G[9], G[3]);
+        if (wg) hipLaunchKernelGGL(k_ln_bwd_finish, dim3(3 * MST_D / kFinOut), dim3(256), 0, st, w_.ln_part, ln_blocks, w_.gscale, G[8], G[9], G[3]);
         HIPCHECK(hipGetLastError());
         }
         TO_SIDE()

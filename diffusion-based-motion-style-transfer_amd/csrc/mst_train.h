@@ -723,35 +723,48 @@ struct DEpiLnBwd {
     }
 };
 
-// Ordered second stage of the partial-sum reductions: out[i] = sum_p part[p][i], p in a FIXED order -- 64 outputs per block, the
-// partials dealt to 4 thread slices (p = slice, slice + 4, ...) that are combined as (s0 + s1) + (s2 + s3).  Deterministic, and 16x
-// the parallelism of one thread per output (which took 28 us per call behind k_ln_bwd's 512 partials).
-__device__ __forceinline__ float ordered_partial_sum(const float* __restrict__ part, int nparts, int n, int i_local, int i, float (&red)[4][64]) {
-    const int slice = threadIdx.x >> 6;
+// Ordered second stage of the partial-sum reductions: out[i] = sum_p part[p][i], p in a FIXED order -- kFinOut outputs per block, the
+// partials dealt to kFinSlices thread slices (p = slice, slice + kFinSlices, ...) whose sums meet in a fixed binary tree.  Deterministic.
+// Round 6: 16 slices x 16 outputs (96 blocks for LayerNorm's 1536 sums) instead of 4 x 64 (24 blocks): with 197 .. 256 partials a thread
+// walked 50 .. 64 of them in series, 12 us per call behind every LayerNorm backward -- on the dgrad chain, 32 calls per iteration.
+constexpr int kFinSlices = 16, kFinOut = 16;
+__device__ __forceinline__ float ordered_partial_sum(const float* __restrict__ part, int nparts, int n, int i_local, int i, float (&red)[kFinSlices][kFinOut]) {
+    const int slice = threadIdx.x / kFinOut;
     float s = 0.f;
     if (i < n) {
         int p = slice;
-        for (; p + 28 < nparts; p += 32) {                 // eight loads in flight, added in the same order as one at a time
+        for (; p + 7 * kFinSlices < nparts; p += 8 * kFinSlices) {                 // eight loads in flight, added in the same order as one at a time
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = part[(size_t)(p + 4 * u) * n + i];
+            for (int u = 0; u < 8; u++) v[u] = part[(size_t)(p + kFinSlices * u) * n + i];
 #pragma unroll
             for (int u = 0; u < 8; u++) s += v[u];
         }
-        for (; p < nparts; p += 4) s += part[(size_t)p * n + i];
+        for (; p < nparts; p += kFinSlices) s += part[(size_t)p * n + i];
     }
     red[slice][i_local] = s;
     __syncthreads();
-    return (red[0][i_local] + red[1][i_local]) + (red[2][i_local] + red[3][i_local]);
+    float t = 0.f;
+    if (threadIdx.x < kFinOut) {
+        float a[kFinSlices];
+#pragma unroll
+        for (int k = 0; k < kFinSlices; k++) a[k] = red[k][i_local];
+#pragma unroll
+        for (int w = 1; w < kFinSlices; w *= 2)
+#pragma unroll
+            for (int k = 0; k < kFinSlices; k += 2 * w) a[k] += a[k + w];
+        t = a[0];
+    }
+    return t;
 }
 
-// dgamma / dbeta / dbias += unscale * sum over the blocks of k_ln_bwd (grid = 3 * 512 / 64 blocks of 256 threads)
+// dgamma / dbeta / dbias += unscale * sum over the blocks of k_ln_bwd (grid = 3 * 512 / kFinOut blocks of 256 threads)
 __global__ __launch_bounds__(256) void k_ln_bwd_finish(const float* __restrict__ part, int nblocks, const float* __restrict__ gscale,
                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias) {
-    __shared__ float red[4][64];
-    const int il = threadIdx.x & 63, i = blockIdx.x * 64 + il;
+    __shared__ float red[kFinSlices][kFinOut];
+    const int il = threadIdx.x % kFinOut, i = blockIdx.x * kFinOut + il;
     const float s = ordered_partial_sum(part, nblocks, 3 * MST_D, il, i, red);
-    if (threadIdx.x < 64) {
+    if (threadIdx.x < kFinOut) {
         const int a = i / MST_D, f = i - a * MST_D;
         float* dst = a == 0 ? dgamma : (a == 1 ? dbeta : dbias);
         dst[f] += s * gscale[1];
@@ -1290,13 +1303,13 @@ __global__ __launch_bounds__(256) void k_colsum_f16(const f16* __restrict__ in, 
     else part[(size_t)blockIdx.y * N + blockIdx.x * 256 + threadIdx.x] = t;
 }
 
-// dst[i] += scale * sum_p part[p][i], p in a fixed order (the second stage of the bias-gradient reductions; grid = ceil(n / 64))
+// dst[i] += scale * sum_p part[p][i], p in a fixed order (the second stage of the bias-gradient reductions; grid = ceil(n / kFinOut))
 __global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ part, int nparts, int n, const float* __restrict__ gscale,
                                                       float* __restrict__ dst) {
-    __shared__ float red[4][64];
-    const int il = threadIdx.x & 63, i = blockIdx.x * 64 + il;
+    __shared__ float red[kFinSlices][kFinOut];
+    const int il = threadIdx.x % kFinOut, i = blockIdx.x * kFinOut + il;
     const float s = ordered_partial_sum(part, nparts, n, il, i, red);
-    if (threadIdx.x < 64 && i < n) dst[i] += gscale ? s * gscale[1] : s;
+    if (threadIdx.x < kFinOut && i < n) dst[i] += gscale ? s * gscale[1] : s;
 }
 
 

@@ -471,6 +471,57 @@ def test_chain_and_side_stream_switches_give_the_same_gradients(monkeypatch):
     model.zero_grad()
 
 
+@pytest.mark.parametrize("semantic", [0, 1])
+def test_two_objective_evaluations_in_one_backward_pass(semantic):
+    """two evaluations of the objective summed into ONE backward pass = two chains of single-clip calls differentiated in the
+    same pass.  Every chain's backward runs on the side stream into the module's ONE private accumulator; the second used to zero it
+    before GradSink.join_chain had added the first chain's sums in (with semantic_guidance=0 the 64-clip node gets no gradient, so nothing
+    joined in between).  The summed pass must give the gradients of the two passes run one after the other."""
+    c = build()
+    model, dd = c["m"], c["ddim"]
+    x, t, y, mask, motion = inputs()
+    shp = (1, F, 1, T)
+    y1 = {"y": {"text": PROMPTS[:1], "mask": torch.ones(1, 1, 1, T, device=dev()), "inpainting_mask": mask[:1], "inpainted_motion": motion[:1]}}
+    t2m = cu(syn.normal(SEED, "xia/t2m", (2, F, 1, T)))
+    fm = torch.ones(2, 1, 1, T, device=dev())
+    fm[1, ..., T - 9:] = 0
+    y_t2m = {"y": {"text": PROMPTS, "mask": fm, "inpainting_mask": mask.double(), "inpainted_motion": t2m}}
+    style = cu(syn.normal(SEED, "xia/style", shp))
+    names = [n for n, p in model.named_parameters() if not n.startswith("motion_enc.")]
+    for p_ in model.parameters_wo_enc():
+        p_.requires_grad_(True)
+
+    def loss_of(tag):
+        with recorded_noise(tag):
+            return dd.few_shot_style_finetune_losses(model, t2m, torch.tensor([2, 4], device=dev()), motion[:1], style, skip_steps=700,
+                                                     model_kwargs=y1, model_t2m_kwargs=y_t2m, semantic_guidance=semantic, use_ddim=1, Ls=10)["loss"]
+
+    def grads():
+        torch.cuda.synchronize()
+        g = dict(model.named_parameters())
+        return [g[n].grad.clone() for n in names]
+
+    model.zero_grad()
+    la = loss_of("xia/ft1")
+    la.backward()
+    ga = grads()
+    model.zero_grad()
+    lb = loss_of("xia/ft1p")
+    lb.backward()
+    gb = grads()
+    model.zero_grad()
+    (loss_of("xia/ft1") + loss_of("xia/ft1p")).backward()
+    gboth = grads()
+    worst = 0.0
+    for a, b, ab in zip(ga, gb, gboth):
+        want = (a + b).cpu().numpy()
+        worst = max(worst, rel_l2(ab.cpu().numpy(), want))
+    print("two chains in one pass vs one after the other, worst of", len(names), "tensors:", worst)
+    assert worst < 1e-5, worst
+    assert all(float(a.abs().max()) > 0 for a in ga)
+    model.zero_grad()
+
+
 def test_neutralisation_prepass_all_100_xstarts_vs_reference():
     """SURVEY 8 f-2, exactly as train/finetune_style_diffusion.py:195-212 issues it: the frozen prior as the denoiser,
     `stop_timesteps=900`, `dump_all_xstart=True` -> 100 x0-hat tensors.  The fixture (tests/golden/make_golden_gen.py, the
