@@ -173,6 +173,7 @@ struct mst_engine {
     f16 *w_pose_in_pk = nullptr, *w_pose_out_pk = nullptr;      // the two projections as per-wave fragment streams (mst_embed.h, k_pack_wave_blocks)
     bool pose_in_dirty = true, pose_out_dirty = true;          // ... older than w_pose_in / w_pose_out: repacked by ensure_packed()
     int small_ln = 1, small_ln_m = 512;   // ... with the LayerNorms inside the consuming GEMMs, up to this many stream rows (MST_SMALL_LN, MST_SMALL_LN_M; tools/experiments/r4_small_sweep.sh: ahead through 2 clips x 197 rows, behind from 4)
+    int train_small_ln = 1;               // training at a clip or two: the LayerNorms inside the GEMMs behind them (MST_TRAIN_SMALL_LN=0: k_ln_rows_train launches)
     int train_fuse_tail = 1;              // training forward at batch size: out-proj + LN1 + FFN + LN2 as k_layer_tail_train, writing the tape (MST_TRAIN_FUSE_TAIL=0: three ring GEMMs)
     int fuse_ln_bwd = 1;                  // training at batch size: LayerNorm1's backward in the epilogue of the dgrad GEMM in front of it (MST_FUSE_LN_BWD=0: two launches)
     int small_fast = 1;                   // small launches: the layer GEMMs as the kernels of mst_small.h (MST_SMALL_FAST=0: the slab ring)
@@ -389,6 +390,7 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     if (const char* v = getenv("MST_SMALL_FAST")) e->small_fast = atoi(v) != 0;
     if (const char* v = getenv("MST_FUSE_LN_BWD")) e->fuse_ln_bwd = atoi(v) != 0;
     if (const char* v = getenv("MST_TRAIN_FUSE_TAIL")) e->train_fuse_tail = atoi(v) != 0;
+    if (const char* v = getenv("MST_TRAIN_SMALL_LN")) e->train_small_ln = atoi(v) != 0;
     if (const char* v = getenv("MST_SMALL_LN")) e->small_ln = atoi(v) != 0;
     if (const char* v = getenv("MST_SMALL_LN_M")) e->small_ln_m = atoi(v);
     if (const char* v = getenv("MST_TAIL_NTB")) { int n = atoi(v); e->tail_ntb = (n >= 2 && n <= 4) ? n : 0; }
@@ -721,9 +723,9 @@ template <int KS, int MODE>
 static int launch_rows_gemm(int M, int N, const f16* X, const f16* wpk, const float* bias, void* out, int ldo, hipStream_t st, const LnRows* ln = nullptr,
                             const FfnTrain* ft = nullptr) {
     constexpr int smem = 64 * (KS / 16) * 1024;
-    if constexpr (KS == 16 && (MODE == 0 || MODE == 1)) {
+    if constexpr (KS == 16 && (MODE == 0 || MODE == 1 || MODE == 3)) {
         if (ln) {                                                  // 16-token tiles (mst_small.h)
-            hipLaunchKernelGGL((k_rows_gemm<KS, MODE, 1, 1>), dim3((M + 15) / 16, N / 128), dim3(512), 16 * 1024, st, X, wpk, bias, out, ldo, M, *ln);
+            hipLaunchKernelGGL((k_rows_gemm<KS, MODE, 1, 1>), dim3((M + 15) / 16, N / 128), dim3(512), 16 * 1024, st, X, wpk, bias, out, ldo, M, *ln, ft ? *ft : FfnTrain{});
             HIPCHECK(hipGetLastError());
             return 0;
         }
@@ -1603,7 +1605,7 @@ extern "C" int mst_masked_l2(const float* a, int64_t a_stride, const float* b, c
                              int32_t feats, int32_t frames, const float* g, float* out, void* stream) {
     if (!a || !b || !mask || !out || n < 1 || feats < 1 || frames < 1) return fail("mst_masked_l2: bad arguments");
     if (!g)
-        hipLaunchKernelGGL(k_masked_l2_fwd, dim3(n), dim3(256), 0, (hipStream_t)stream, a, (long long)a_stride, b, mask, (long long)mask_stride,
+        hipLaunchKernelGGL(k_masked_l2_fwd, dim3(n), dim3(1024), 0, (hipStream_t)stream, a, (long long)a_stride, b, mask, (long long)mask_stride,
                            feats, frames, out);
     else {
         int gx = (feats * frames + 255) / 256;
@@ -1617,7 +1619,7 @@ extern "C" int mst_masked_l2(const float* a, int64_t a_stride, const float* b, c
 
 extern "C" int mst_text_cosine(const float* f, const float* m, int32_t batch, int32_t dim, const float* g, float* out, void* stream) {
     if (!f || !m || !out || batch < 1 || batch > 1024 || dim < 1) return fail("mst_text_cosine: bad arguments (batch 1..1024)");
-    hipLaunchKernelGGL(k_text_cosine, dim3(1), dim3(256), 0, (hipStream_t)stream, f, m, batch, dim, g ? 1 : 0, g, out);
+    hipLaunchKernelGGL(k_text_cosine, dim3(1), dim3(1024), 0, (hipStream_t)stream, f, m, batch, dim, g ? 1 : 0, g, out);
     HIPCHECK(hipGetLastError());
     return 0;
 }
@@ -1745,10 +1747,20 @@ static int train_stack_forward(mst_engine* e, const Tape& t, int rows, int S, fl
     const bool small = e->small_m > 0 && M <= e->small_m;
     const bool fast = small && e->small_fast;            // the four GEMMs as resident-tile kernels (mst_small.h), as in the sampling path
     if (fast) CHECK(ensure_small_packed_all(e, st));
+    // round 6: at a clip or two (the objective's chained single-clip calls) the two LayerNorms of a layer ride in the GEMM behind them
+    // (k_rows_gemm LNF = 1 with LnRows' training fields: dropout, z -> tape), as on the sampling path: 16 launches fewer per call.
+    // LayerNorm1 in FFN1; LayerNorm2 in the NEXT layer's QKV GEMM, the last one as the rows kernel.  MST_TRAIN_SMALL_LN=0: every LayerNorm a launch.
+    const bool lnf = fast && e->train_small_ln && M <= e->small_ln_m;
     for (int l = 0; small && l < nl; l++) {              // few token rows: 64 x 128 tiles, row-wise LayerNorm, query-split attention
         const LayerW& w = e->L[l];
         const TapeL& a = t.L[l];
-        if (fast) CHECK((launch_rows_gemm<16, 0>(M, 3 * MST_D, t.sh[l], w.wsm_in, w.b_in, a.qkv, 3 * MST_D, st)));
+        if (lnf && l > 0) {
+            const LayerW& p = e->L[l - 1];
+            const TapeL& pa = t.L[l - 1];
+            LnRows ln{e->zacc, p.b2, p.g2, p.be2, pa.x1h, pa.x1l, t.sh[l], t.sl[l]};
+            ln.z_hi = pa.z2h; ln.z_lo = pa.z2l; ln.d = make_drop(seed, l - 1, 3, p_drop, o1);
+            CHECK((launch_rows_gemm<16, 0>(M, 3 * MST_D, nullptr, w.wsm_in, w.b_in, a.qkv, 3 * MST_D, st, &ln)));
+        } else if (fast) CHECK((launch_rows_gemm<16, 0>(M, 3 * MST_D, t.sh[l], w.wsm_in, w.b_in, a.qkv, 3 * MST_D, st)));
         else {
             DEpiBiasF16<false> epi{w.b_in, a.qkv, 3 * MST_D, M};
             CHECK(launch_small(M, 3 * MST_D, RowsDirect{t.sh[l], MST_D}, w.w_in, MST_D, MST_D, epi, st));
@@ -1760,11 +1772,18 @@ static int train_stack_forward(mst_engine* e, const Tape& t, int rows, int S, fl
                 DEpiPlainF32 epi{e->zacc, MST_D, M};
                 CHECK(launch_small(M, MST_D, RowsDirect{a.att, MST_D}, w.w_out, MST_D, MST_D, epi, st));
             }
-            hipLaunchKernelGGL(k_ln_rows_train, dim3((M + 3) / 4), dim3(256), 0, st, e->zacc, w.b_out, w.g1, w.be1, t.sh[l], t.sl[l],
-                               a.z1h, a.z1l, a.x1h, a.x1l, M, make_drop(seed, l, 1, p_drop, o1));
-            HIPCHECK(hipGetLastError());
+            if (!lnf) {
+                hipLaunchKernelGGL(k_ln_rows_train, dim3((M + 3) / 4), dim3(256), 0, st, e->zacc, w.b_out, w.g1, w.be1, t.sh[l], t.sl[l],
+                                   a.z1h, a.z1l, a.x1h, a.x1l, M, make_drop(seed, l, 1, p_drop, o1));
+                HIPCHECK(hipGetLastError());
+            }
         }
-        if (fast) {
+        if (lnf) {
+            const FfnTrain ft{a.pre, make_drop(seed, l, 2, p_drop, o2)};
+            LnRows ln{e->zacc, w.b_out, w.g1, w.be1, t.sh[l], t.sl[l], a.x1h, a.x1l};
+            ln.z_hi = a.z1h; ln.z_lo = a.z1l; ln.d = make_drop(seed, l, 1, p_drop, o1);
+            CHECK((launch_rows_gemm<16, 3>(M, MST_FF, nullptr, w.wsm_1, w.b1, a.hid, MST_FF, st, &ln, &ft)));
+        } else if (fast) {
             const FfnTrain ft{a.pre, make_drop(seed, l, 2, p_drop, o2)};
             CHECK((launch_rows_gemm<16, 3>(M, MST_FF, a.x1h, w.wsm_1, w.b1, a.hid, MST_FF, st, nullptr, &ft)));
         } else {
@@ -1777,9 +1796,11 @@ static int train_stack_forward(mst_engine* e, const Tape& t, int rows, int S, fl
                 DEpiPlainF32 epi{e->zacc, MST_D, M};
                 CHECK(launch_small(M, MST_D, RowsDirect{a.hid, MST_FF}, w.w2, MST_FF, MST_FF, epi, st));
             }
-            hipLaunchKernelGGL(k_ln_rows_train, dim3((M + 3) / 4), dim3(256), 0, st, e->zacc, w.b2, w.g2, w.be2, a.x1h, a.x1l,
-                               a.z2h, a.z2l, t.sh[l + 1], t.sl[l + 1], M, make_drop(seed, l, 3, p_drop, o1));
-            HIPCHECK(hipGetLastError());
+            if (!lnf || l == nl - 1) {
+                hipLaunchKernelGGL(k_ln_rows_train, dim3((M + 3) / 4), dim3(256), 0, st, e->zacc, w.b2, w.g2, w.be2, a.x1h, a.x1l,
+                                   a.z2h, a.z2l, t.sh[l + 1], t.sl[l + 1], M, make_drop(seed, l, 3, p_drop, o1));
+                HIPCHECK(hipGetLastError());
+            }
         }
     }
     // round 6: everything of a layer behind the attention as ONE launch (k_layer_tail_train, mst_tail.h) that writes the tape slots

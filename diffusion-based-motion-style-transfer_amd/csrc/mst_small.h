@@ -38,6 +38,11 @@ struct LnRows {
     const float *acc, *bias, *gamma, *beta;     // fp32 GEMM result [M][512]; bias of that GEMM; LayerNorm weight, bias
     const f16 *res_hi, *res_lo;                 // the residual stream in front of the GEMM
     f16 *out_hi, *out_lo;                       // the stream behind the LayerNorm
+    // training (round 6: the chained single-clip calls of the fine-tune objective, 16 LayerNorm launches fewer per call): the GEMM result
+    // passes the site's dropout before the residual joins -- z = res + dropout(acc + bias), k_ln_rows_train's arithmetic -- and z goes to
+    // its tape slot (column 0 writes it, like the rows).  z_hi == nullptr: inference.
+    f16 *z_hi = nullptr, *z_lo = nullptr;
+    Drop d = Drop{0u, 0u, 1.0f};
 };
 
 // The same re-layout for up to 32 matrices in one launch (blockIdx.y = job): the training path re-uploads every layer each iteration.
@@ -123,10 +128,29 @@ __global__ __launch_bounds__(512) void k_rows_gemm(const f16* __restrict__ X, co
 #pragma unroll
                         for (int i = 0; i < LB; i++) {
                             const int r = RPW * wave + LB * h + i, tok = tok0 + r;
+                            if (ln.z_hi) {                                     // (uniform) training: dropout, then the residual; z -> tape
+                                const uint32_t ia = (uint32_t)tok * (uint32_t)MST_D + (uint32_t)fa, ib = (uint32_t)tok * (uint32_t)MST_D + (uint32_t)fb;
+#pragma unroll
+                                for (int c = 0; c < 4; c++) {
+                                    xa[i][c] += (ta[i][c] + ba[c]) * drop_mul(ln.d, ia + c);
+                                    xb[i][c] += (tb[i][c] + bb[c]) * drop_mul(ln.d, ib + c);
+                                }
+                                if (blockIdx.y == 0 && tok < M) {
+                                    const size_t off = (size_t)tok * MST_D;
+                                    uint2 zh, zl;
+                                    split4_f16(xa[i], zh, zl);
+                                    *reinterpret_cast<uint2*>(ln.z_hi + off + fa) = zh;
+                                    *reinterpret_cast<uint2*>(ln.z_lo + off + fa) = zl;
+                                    split4_f16(xb[i], zh, zl);
+                                    *reinterpret_cast<uint2*>(ln.z_hi + off + fb) = zh;
+                                    *reinterpret_cast<uint2*>(ln.z_lo + off + fb) = zl;
+                                }
+                            } else {
 #pragma unroll
                             for (int c = 0; c < 4; c++) {
                                 xa[i][c] = ta[i][c] + ba[c] + xa[i][c];
                                 xb[i][c] = tb[i][c] + bb[c] + xb[i][c];
+                            }
                             }
                             ln_row_wave(xa[i], xb[i], ga, gb, ea, eb);
                             const f32x4 ya = xa[i], yb = xb[i];

@@ -532,8 +532,13 @@ class GaussianDiffusion:
             chain_start = (chain_start, x_start.device)
         x_t = self.q_sample(x_start, t, noise=noise_t2m, model_kwargs=model_t2m_kwargs)
         model_output = model(x_t, self._scale_timesteps(t), **model_t2m_kwargs)
+        text_cosine = None
         if semantic_guidance:
             mu, text_features = motion_enc(model_output, **model_t2m_kwargs)
+            # (evaluated HERE, not behind the sampling loop as the reference writes it at :1384-1389: it reads nothing of the loop, draws no
+            # random number, and on the caller's stream it would otherwise sit behind the wait for the chained steps' side stream)
+            from .fused_ops import TextCosineFn           # normalise both, cosine_similarity, 1 -, mean: one launch each way
+            text_cosine = TextCosineFn.apply(text_features.detach(), mu)
         if use_ddim:
             sample_fn, skip_steps = self.ddim_sample_loop, int(skip_steps / 1000 * 20)
         else:
@@ -554,8 +559,7 @@ class GaussianDiffusion:
         terms = {"rot_mse": self.masked_l2(x_style_start.expand(num_step, -1, -1, -1), sample,
                                            mask.expand(num_step, -1, -1, -1))}
         if semantic_guidance:
-            from .fused_ops import TextCosineFn           # normalise both, cosine_similarity, 1 -, mean: one launch each way
-            terms["text_cosine"] = TextCosineFn.apply(text_features.detach(), mu)
+            terms["text_cosine"] = text_cosine
             terms["loss"] = terms["rot_mse"].mean() + terms["text_cosine"] * Ls
         else:
             terms["loss"] = terms["rot_mse"].mean()

@@ -1,0 +1,11 @@
+# Round 6: boundary + training tests, then the fine-tune line (three runs) -- a quick check behind a training-path change
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout -k 10 900 python -m pytest tests/test_gpu_boundary.py tests/test_gpu_fused_ops.py tests/test_gpu_train.py tests/test_gpu_train_fullsize.py tests/test_gpu_training_loop.py -x -q -m gpu > gpurun_out/r6_gpu_tests2.log 2>&1; rc=$?
+tail -4 gpurun_out/r6_gpu_tests2.log
+[ $rc = 0 ] || exit $rc
+for r in 1 2 3; do
+timeout -k 10 300 python bench.py --mode finetune --steps 50 --warmup 5 --no-cpu-baseline > gpurun_out/r6_ft.log 2>&1 || { tail -5 gpurun_out/r6_ft.log; exit 1; }
+tail -1 gpurun_out/r6_ft.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], 'ms/iteration', 'loss', d.get('final_loss'))"
+done
+timeout -k 10 300 python tools/ft_events.py 2>&1 | grep -v "it/s" | tail -16
