@@ -146,10 +146,24 @@ __device__ __forceinline__ float tail_drop_mul(const TailDrop& d, uint32_t idx) 
 #else
 __device__ __forceinline__ float tail_drop_mul(const TailDrop& d, uint32_t idx) { return tail_mix32(idx * 0x9E3779B9u + d.key) >= d.thr ? d.inv : 0.f; }
 #endif
-#if MST_TT_NOSTORE         // A/B probe builds only: the tape stores of the accumulator-layout stages dropped (wrong gradients; timing only)
-#define TT_STORE(stmt) do { } while (0)
+// Tape stores.  Non-temporal stores (the slots are written once and read once, by the backward pass, behind a gigabyte of other traffic)
+// were measured and LOSE: same box, three alternating runs of 50 fine-tune iterations, 10.03 / 10.09 / 10.13 ms with plain stores against
+// 10.51 / 10.60 / 10.61 ms with `nt` ones (64-clip call 1.79 -> 2.01 ms, motion encoder 1.49 -> 1.72 ms; the chained calls beside them
+// slower too).  MST_TT_NT=1 builds that variant.
+#ifndef MST_TT_NT
+#define MST_TT_NT 0
+#endif
+__device__ __forceinline__ void tape_store8(f16* dst, uint2 v) {
+#if MST_TT_NT
+    __builtin_nontemporal_store(__builtin_bit_cast(unsigned long long, v), reinterpret_cast<unsigned long long*>(dst));
 #else
-#define TT_STORE(stmt) do { stmt; } while (0)
+    *reinterpret_cast<uint2*>(dst) = v;
+#endif
+}
+#if MST_TT_NOSTORE         // A/B probe builds only: the tape stores of the accumulator-layout stages dropped (wrong gradients; timing only)
+#define TT_STORE(dst, v) do { } while (0)
+#else
+#define TT_STORE(dst, v) tape_store8(dst, v)
 #endif
 struct TailTrain {
     const f16 *xin_h, *xin_l;                                     // the layer's input stream (tape slot l): LayerNorm1's residual
@@ -431,8 +445,8 @@ __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ at
                             const size_t o = (size_t)tok * MST_D + (256 * nh + 32 * wave + 16 * rb + 4 * q4);
                             uint2 zh, zl;
                             split4_f16(a, zh, zl);
-                            TT_STORE(*reinterpret_cast<uint2*>(tt.z1h + o) = zh);
-                            TT_STORE(*reinterpret_cast<uint2*>(tt.z1l + o) = zl);
+                            TT_STORE(tt.z1h + o, zh);
+                            TT_STORE(tt.z1l + o, zl);
                         }
                     }
         } else {
@@ -505,8 +519,9 @@ __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ at
                         const int tok = tok0 + 16 * tb + t16;
                         if (tok < M) {
                             const size_t o = (size_t)tok * MST_D + f;
-                            TT_STORE(*reinterpret_cast<uint2*>(tt.x1h + o) = yh);
-                            TT_STORE(*reinterpret_cast<uint2*>(tt.x1l + o) = yl);
+                            // (plain stores: LayerNorm2 of this very workgroup reads the rows back)
+                            *reinterpret_cast<uint2*>(tt.x1h + o) = yh;
+                            *reinterpret_cast<uint2*>(tt.x1l + o) = yl;
                         }
                         acc[nh][rb][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
                     } else {
@@ -561,8 +576,8 @@ __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ at
                                             gelu_tab_lds((float)ph[2], gtab) * tail_drop_mul(tt.d2, o + 2), gelu_tab_lds((float)ph[3], gtab) * tail_drop_mul(tt.d2, o + 3));
                 *reinterpret_cast<uint2*>(smem + C::OFF_H + (hc & 1) * C::HBUF + (16 * tb + t16) * 512 + coff) = h16;
                 if (tok < M) {
-                    TT_STORE(*reinterpret_cast<uint2*>(tt.pre + o) = p16);
-                    TT_STORE(*reinterpret_cast<uint2*>(tt.hid + o) = h16);
+                    TT_STORE(tt.pre + o, p16);
+                    TT_STORE(tt.hid + o, h16);
                 }
             } else
             *reinterpret_cast<uint2*>(smem + C::OFF_H + (hc & 1) * C::HBUF + (16 * tb + t16) * 512 + coff) =
@@ -680,11 +695,11 @@ __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ at
                     const size_t off = (size_t)tok * MST_D;
                     uint2 zh, zl;
                     split4_f16(xa[r], zh, zl);
-                    *reinterpret_cast<uint2*>(tt.z2h + off + fa) = zh;
-                    *reinterpret_cast<uint2*>(tt.z2l + off + fa) = zl;
+                    tape_store8(tt.z2h + off + fa, zh);
+                    tape_store8(tt.z2l + off + fa, zl);
                     split4_f16(xb[r], zh, zl);
-                    *reinterpret_cast<uint2*>(tt.z2h + off + fb) = zh;
-                    *reinterpret_cast<uint2*>(tt.z2l + off + fb) = zl;
+                    tape_store8(tt.z2h + off + fb, zh);
+                    tape_store8(tt.z2l + off + fb, zl);
                 }
                 const f32x4 t = xa[r] + xb[r];
                 mean[r] = wave_sum((t[0] + t[1]) + (t[2] + t[3])) * (1.0f / MST_D);

@@ -45,6 +45,22 @@ def mef(*a, **k):
 me.forward = mef
 
 
+# the chained single-clip steps on their side stream: an event where a step's block starts and one where it ends (both on the side stream)
+from mst_amd.model import native_stack as _ns
+chain_marks = []
+_enter, _exit = _ns.ChainedCalls.__enter__, _ns.ChainedCalls.__exit__
+def _en(self):
+    r = _enter(self)
+    if collecting[0] and self._depth == 1 and self.side is not None:
+        e = torch.cuda.Event(enable_timing=True); e.record(self.side); chain_marks.append(("in", e))
+    return r
+def _ex(self, *exc):
+    if collecting[0] and self._depth == 1 and self.side is not None:
+        e = torch.cuda.Event(enable_timing=True); e.record(self.side); chain_marks.append(("out", e))
+    return _exit(self, *exc)
+_ns.ChainedCalls.__enter__, _ns.ChainedCalls.__exit__ = _en, _ex
+
+
 def iteration(h2d):
     mark("start")
     tt = torch.randint(0, 6, (B,), generator=gen).to(dev) if h2d else tt_dev
@@ -90,5 +106,22 @@ for h2d in (True, False):
     print(f"caller's stream, {'with' if h2d else 'without'} the per-iteration copy (events, no synchronisation; ms per iteration):")
     for k, v in acc.items():
         print(f"  {k:55s} {v / 10:7.2f}")
+    # side stream: per iteration 7 blocks (loop set-up + six steps)
+    starts = [e for k, e in chain_marks if k == "in"]
+    ends = [e for k, e in chain_marks if k == "out"]
+    n_it = 10
+    per = len(starts) // n_it
+    its = [m for m in marks if m[0] == "start"]
+    if per:
+        dur = [0.0] * per
+        gap = [0.0] * per
+        for it in range(n_it):
+            for j in range(per):
+                dur[j] += starts[it * per + j].elapsed_time(ends[it * per + j])
+                gap[j] += (its[it][1].elapsed_time(starts[it * per + j]) if j == 0 else ends[it * per + j - 1].elapsed_time(starts[it * per + j]))
+        print("  side stream blocks (ms): " + ", ".join(f"{d / n_it:.2f}" for d in dur) + f"   sum {sum(dur) / n_it:.2f}")
+        print("  gaps in front of them (first: from the iteration's start): " + ", ".join(f"{g_ / n_it:.2f}" for g_ in gap))
+        print(f"  iteration start -> last block's end: {sum(its[it][1].elapsed_time(ends[it * per + per - 1]) for it in range(n_it)) / n_it:.2f}")
+    chain_marks.clear()
     tot = marks[0][1].elapsed_time(marks[-1][1]) / 10
     print(f"  {'first start -> last optimizer step, per iteration':55s} {tot:7.2f}")
