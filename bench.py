@@ -248,6 +248,7 @@ def sample_main(args):
         eng.profile(False)
     assert torch.isfinite(last).all()
     assert torch.equal(last[:, :3], motion[:, :3]), "inpainted rows must equal the content clip exactly"
+    group = sharding.group_report(dt, B * args.steps, dev if args.backend == "nccl" else "cpu")      # before the max: every rank's OWN time
     dt = sharding.max_over_ranks(dt, dev if args.backend == "nccl" else "cpu")
 
     boundary = None
@@ -282,6 +283,7 @@ def sample_main(args):
                        (f", called through diffusion.p_sample_loop ({args.via_boundary} noise)" if args.via_boundary else ""),
                        "global_batch": world * B, "denoise_steps": NS, "parallelism": f"clip-sharded x{world}, no collective"},
         }
+        line["distributed"] = group
         if eng is not None:
             line["roofline"] = roofline(prof, rows, B, T, F, value, flops_per_clip, eng.loop_slices(B, args.cfg), ev_us)
         else:
@@ -549,6 +551,7 @@ def finetune_main(args):
     for _ in range(max(1, args.warmup)):
         iteration()
     dt, loss = timed(args.steps)
+    group = sharding.group_report(dt, B * args.steps, dev if args.backend == "nccl" else "cpu")
     dt = sharding.max_over_ranks(dt, dev if args.backend == "nccl" else "cpu")
     comm = None
     if world > 1:
@@ -597,7 +600,7 @@ def finetune_main(args):
                 "config": {"workload": f"configs[3]: data-parallel fine-tune, {B} clips/GPU x (263,1,196), one 64-clip objective call + "
                            "6 chained single-clip steps + frozen motion encoder + backward + AdamW per iteration",
                            "global_batch": world * B, "parallelism": f"dp{world}, 8 per-layer gradient buckets, all-reduce overlapped with backward"},
-                "iterations_per_s": round(args.steps / dt, 3), "final_loss": round(loss, 5), "allreduce": comm}
+                "iterations_per_s": round(args.steps / dt, 3), "final_loss": round(loss, 5), "allreduce": comm, "distributed": group}
         line["roofline"] = finetune_roofline(B, world, dt / args.steps, wgrad)
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -39,6 +39,20 @@ def max_over_ranks(seconds, device="cpu"):
     return float(t.item())
 
 
+def group_report(own_seconds, units, device="cpu"):
+    """What the PROCESS GROUP says about a timed region (bench.py puts it into its JSON line, so that a multi-GPU record proves the
+    collective backend saw N ranks -- `n_gpus` alone is read from the launcher's WORLD_SIZE): world size and backend from
+    torch.distributed, every rank's own rate (units / its own wall time) through an all_gather."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"initialized": False, "world_size": 1, "backend": None, "per_rank_units_per_s": [round(units / own_seconds, 3)]}
+    ws = dist.get_world_size()
+    t = torch.tensor([own_seconds], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(ws)]
+    dist.all_gather(out, t)
+    return {"initialized": True, "world_size": ws, "backend": str(dist.get_backend()), "rank": dist.get_rank(),
+            "per_rank_units_per_s": [round(units / float(o.item()), 3) for o in out]}
+
+
 def gather_clips(local, global_batch):
     """All ranks' finished clips in global order ([global_batch, F, 1, T]); ragged shards are padded
     to the largest shard for the collective and trimmed afterwards."""

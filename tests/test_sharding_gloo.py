@@ -26,7 +26,8 @@ def _worker(rank, ws, port, gb, q):
         sharding.barrier()
         t = sharding.max_over_ranks(1.0 + rank)
         full = sharding.gather_clips(local, gb)
-        q.put((rank, lo, hi, t, full[:, 0, 0, 0].tolist(), sharding.rank_seed(7, rank), sharding.world()))
+        rep = sharding.group_report(1.0 + rank, 10.0)          # every rank's own rate, world size and backend from the process group
+        q.put((rank, lo, hi, t, full[:, 0, 0, 0].tolist(), sharding.rank_seed(7, rank), sharding.world(), rep))
     finally:
         dist.destroy_process_group()
 
@@ -43,7 +44,10 @@ def test_two_rank_sharding_timing_and_gather():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, lo0, hi0, t0, full0, s0, w0), (r1, lo1, hi1, t1, full1, s1, w1) = res
+    (r0, lo0, hi0, t0, full0, s0, w0, g0), (r1, lo1, hi1, t1, full1, s1, w1, g1) = res
+    for g, r in ((g0, 0), (g1, 1)):
+        assert g["initialized"] and g["world_size"] == 2 and g["backend"] == "gloo" and g["rank"] == r
+        assert g["per_rank_units_per_s"] == [10.0, 5.0]
     assert (lo0, hi0, lo1, hi1) == (0, 4, 4, 7)          # disjoint, contiguous, covers the batch
     assert t0 == t1 == 2.0                                # max over ranks
     assert full0 == full1 == [float(i) for i in range(gb)]
@@ -55,5 +59,6 @@ def test_single_process_defaults():
     assert sharding.shard_range(64, 0, 1) == (0, 64)
     assert [sharding.shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
     assert sharding.max_over_ranks(1.5) == 1.5
+    assert sharding.group_report(2.0, 8.0) == {"initialized": False, "world_size": 1, "backend": None, "per_rank_units_per_s": [4.0]}
     x = torch.zeros(2, 3, 1, 4)
     assert sharding.gather_clips(x, 2) is x
