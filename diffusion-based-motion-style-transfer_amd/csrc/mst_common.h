@@ -324,17 +324,24 @@ __device__ __forceinline__ StepCoef step_coef(const float* __restrict__ tab, int
 }
 
 // returns the next sample; x0-hat (after blend / clip) is written to *pred.
-template <int SAMPLER>
+// MEAN: what the model predicts (reference :398-412, in the reference's order: the inpainting blend acts on the RAW model output, :341-349,
+// the conversion to x0-hat follows): 0 = x_start (every model the factories build, utils/model_util.py:172), 1 = epsilon
+// (_predict_xstart_from_eps, :426-431), 2 = x_{t-1} (_predict_xstart_from_xprev, :433-441; the posterior mean then IS the model output,
+// :399-403).  A template parameter: the fused output-projection kernels instantiate 0 and compile to what they were.
+template <int SAMPLER, int MEAN = 0>
 __device__ __forceinline__ float step_update(const StepCoef& c, float model_out, float x, float noise,
                                              bool has_blend, float mask, float motion, bool mask_noise,
                                              bool clip, float* pred) {
     float out = model_out;
     if (has_blend) out = out * (1.0f - mask) + motion * mask;
+    const float raw = out;
+    if (MEAN == 1) out = c.srac * x - c.srm1ac * out;
+    if (MEAN == 2) out = (1.0f / c.c1) * out - (c.c2 / c.c1) * x;
     if (clip) out = fminf(fmaxf(out, -1.0f), 1.0f);
     *pred = out;
     if (mask_noise) noise = noise * (1.0f - mask);
     if (SAMPLER == 0) {
-        float mean = c.c1 * out + c.c2 * x;
+        float mean = MEAN == 2 ? raw : c.c1 * out + c.c2 * x;
         return mean + c.sigma_ddpm * noise;
     } else {
         float eps = (c.srac * x - out) / c.srm1ac;

@@ -184,7 +184,7 @@ __global__ void k_q_sample(const float* __restrict__ tab, int nsteps, const floa
 }
 
 // K10 / K10' stand-alone (model output produced elsewhere)
-template <int SAMPLER>
+template <int SAMPLER, int MEAN = 0>
 __global__ void k_step_epilogue(const float* __restrict__ tab, int nsteps, float eta,
                                 const float* __restrict__ model_out, const float* __restrict__ x,
                                 const float* __restrict__ noise, const float* __restrict__ mask,
@@ -200,8 +200,8 @@ __global__ void k_step_epilogue(const float* __restrict__ tab, int nsteps, float
         float m = mask ? mask[idx] : 0.f;
         float mot = blend ? motion[idx] : 0.f;
         float pred;
-        float nx = step_update<SAMPLER>(sc, model_out[idx], x[idx], noise ? noise[idx] : 0.f, blend, m, mot,
-                                        mask_noise && mask, clip_denoised, &pred);
+        float nx = step_update<SAMPLER, MEAN>(sc, model_out[idx], x[idx], noise ? noise[idx] : 0.f, blend, m, mot,
+                                              mask_noise && mask, clip_denoised, &pred);
         if (sample) sample[idx] = nx;
         if (xstart) xstart[idx] = pred;
     }

@@ -15,7 +15,7 @@
 #include "mst_common.h"
 #include "mst_gemm_dma.h"
 
-#ifndef EMB_MARK            // diagnostic builds (tools/r4_embed_stamps.sh) stamp the phases; the product build has none
+#ifndef EMB_MARK            // diagnostic builds (tools/experiments/r4_embed_stamps.py) stamp the phases; the product build has none
 #define EMB_MARK(i)
 #endif
 

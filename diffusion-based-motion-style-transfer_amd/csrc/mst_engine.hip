@@ -20,7 +20,7 @@
 #include "mst_gemm_dma.h"
 #include "mst_tail.h"
 #include "mst_trunk.h"
-#ifdef EMB_PROBE            // diagnostic build only (tools/r4_embed_stamps.sh): wave 0..7 of every workgroup stamp the 100 MHz clock at the phase marks
+#ifdef EMB_PROBE            // diagnostic build only (tools/experiments/r4_embed_stamps.py): wave 0..7 of every workgroup stamp the 100 MHz clock at the phase marks
 __device__ unsigned long long g_emb_stamp[512][8][8];
 #define EMB_MARK(i) if ((threadIdx.x & 63) == 0 && blockIdx.x < 512) g_emb_stamp[blockIdx.x][threadIdx.x >> 6][i] = __builtin_amdgcn_s_memrealtime();
 extern "C" int mst_probe_read(void* dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_emb_stamp), sizeof(g_emb_stamp)) == hipSuccess ? 0 : 1; }
@@ -31,7 +31,7 @@ extern "C" int mst_probe_read(void* dst) { return hipMemcpyFromSymbol(dst, HIP_S
 using namespace mst;
 
 // wide (QKV / FFN1) tile: WIDE_BT tokens x 256 features, 8 waves of (WIDE_BT/64) x 2 MFMA tiles
-#define WIDE_BT 128   // same-box A/B (tools/ab.sh): 128/3-slot/XCD 52.4 clips/s, 128/4-slot 47.2, 256/4-slot 47.5
+#define WIDE_BT 128   // same-box A/B (round 1, script since removed): 128/3-slot/XCD 52.4 clips/s, 128/4-slot 47.2, 256/4-slot 47.5
 #define WIDE_NS 3     // 3 x 24 KB ring: two blocks share a CU
 #define FFN1_BF 256   // same-box A/B: 128x512 tiles (one 8-wave block per CU) 40 us vs 35 us for two co-resident 128x256 blocks
 #define WIDE_XCD 1
@@ -1561,24 +1561,35 @@ extern "C" int mst_q_sample(const mst_schedule* s, const float* x0, const float*
     return 0;
 }
 
+extern "C" int mst_step_epilogue_mt(const mst_schedule* s, const float* model_out, const float* x, const float* noise,
+                                    const float* mask, const float* motion, const int64_t* t, int32_t batch, int64_t per_clip,
+                                    int32_t sampler, int32_t mean_type, float eta, int32_t mask_noise, int32_t clip_denoised, float* sample,
+                                    float* xstart, void* stream) {
+    if (!s || !model_out || !x || !t || batch < 1 || per_clip < 1) return fail("mst_step_epilogue: bad arguments");
+    if (sampler != MST_SAMPLER_DDPM && sampler != MST_SAMPLER_DDIM) return fail("mst_step_epilogue: bad sampler %d", sampler);
+    if (mean_type < 0 || mean_type > 2) return fail("mst_step_epilogue: bad mean type %d (0 = x_start, 1 = epsilon, 2 = previous x)", mean_type);
+    ON_DEVICE(s->device);
+    int gx = (int)((per_clip + 255) / 256);
+    if (gx > 2048) gx = 2048;
+#define STEP_LAUNCH(S_, M_)                                                                                                              \
+    hipLaunchKernelGGL((k_step_epilogue<S_, M_>), dim3(gx, batch), dim3(256), 0, (hipStream_t)stream, s->tab, s->n, eta, model_out, x,   \
+                       noise, mask, motion, (const long long*)t, (long long)per_clip, mask_noise, clip_denoised, sample, xstart)
+    const bool ddim = sampler == MST_SAMPLER_DDIM;
+    switch (mean_type) {
+        case 0: if (ddim) STEP_LAUNCH(1, 0); else STEP_LAUNCH(0, 0); break;
+        case 1: if (ddim) STEP_LAUNCH(1, 1); else STEP_LAUNCH(0, 1); break;
+        default: if (ddim) STEP_LAUNCH(1, 2); else STEP_LAUNCH(0, 2); break;
+    }
+#undef STEP_LAUNCH
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
 extern "C" int mst_step_epilogue(const mst_schedule* s, const float* model_out, const float* x, const float* noise,
                                  const float* mask, const float* motion, const int64_t* t, int32_t batch, int64_t per_clip,
                                  int32_t sampler, float eta, int32_t mask_noise, int32_t clip_denoised, float* sample,
                                  float* xstart, void* stream) {
-    if (!s || !model_out || !x || !t || batch < 1 || per_clip < 1) return fail("mst_step_epilogue: bad arguments");
-    ON_DEVICE(s->device);
-    int gx = (int)((per_clip + 255) / 256);
-    if (gx > 2048) gx = 2048;
-    if (sampler == MST_SAMPLER_DDPM)
-        hipLaunchKernelGGL(k_step_epilogue<0>, dim3(gx, batch), dim3(256), 0, (hipStream_t)stream, s->tab, s->n, eta, model_out, x,
-                           noise, mask, motion, (const long long*)t, (long long)per_clip, mask_noise, clip_denoised, sample, xstart);
-    else if (sampler == MST_SAMPLER_DDIM)
-        hipLaunchKernelGGL(k_step_epilogue<1>, dim3(gx, batch), dim3(256), 0, (hipStream_t)stream, s->tab, s->n, eta, model_out, x,
-                           noise, mask, motion, (const long long*)t, (long long)per_clip, mask_noise, clip_denoised, sample, xstart);
-    else
-        return fail("mst_step_epilogue: bad sampler %d", sampler);
-    HIPCHECK(hipGetLastError());
-    return 0;
+    return mst_step_epilogue_mt(s, model_out, x, noise, mask, motion, t, batch, per_clip, sampler, 0, eta, mask_noise, clip_denoised, sample,
+                                xstart, stream);
 }
 
 extern "C" int mst_step_backward(const mst_schedule* s, const float* g_sample, const float* g_pred, const float* mask,

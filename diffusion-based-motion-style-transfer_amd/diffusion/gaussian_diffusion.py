@@ -227,9 +227,9 @@ class GaussianDiffusion:
                 - _extract_into_tensor(self.posterior_mean_coef2 / self.posterior_mean_coef1, t, x_t.shape) * x_t)
 
     def _xstart_from_output(self, out, x, t):
-        """What the model predicts -> x0-hat (reference :398-412).  The shipped factories only build START_X models
-        (utils/model_util.py:172); the other two parameterisations are converted with the reference's formulas in front of
-        the fused step kernel, which works on x0-hat."""
+        """What the model predicts -> x0-hat (reference :398-412), torch ops: the differentiable `p_mean_variance` form.  The no-grad
+        samplers convert inside the step kernel (`Schedule.step(mean_type=...)`).  The shipped factories only build START_X models
+        (utils/model_util.py:172)."""
         if self.model_mean_type == ModelMeanType.START_X:
             return out
         if self.model_mean_type == ModelMeanType.EPSILON:
@@ -282,13 +282,16 @@ class GaussianDiffusion:
         if cond_fn is not None or denoised_fn is not None:
             raise NotImplementedError("cond_fn / denoised_fn are never set by this code base (SURVEY.md section 9)")
         with th.no_grad():
-            out = self._xstart_from_output(self._model_output(model, x, t, model_kwargs), x, t)
+            out = self._model_output(model, x, t, model_kwargs)
         noise = self._draw(x, const_noise)
         mask, motion = self._inpaint_pair(model_kwargs)
         nmask = self._noise_mask(model_kwargs)
+        # epsilon / previous-x models: converted to x0-hat INSIDE the step kernel (MODEs of k_step_epilogue), behind the inpainting blend
+        # as the reference orders them (:341-349 then :398-412)
+        mean_type = {ModelMeanType.START_X: 0, ModelMeanType.EPSILON: 1, ModelMeanType.PREVIOUS_X: 2}[self.model_mean_type]
         sample, pred = self._schedule(x.device).step(
             out, x, t, noise, sampler, eta, mask=mask if mask is not None else nmask, motion=motion,
-            mask_noise=nmask is not None, clip_denoised=clip_denoised)
+            mask_noise=nmask is not None, clip_denoised=clip_denoised, mean_type=mean_type)
         return {"sample": sample, "pred_xstart": pred}
 
     def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,

@@ -84,8 +84,9 @@ class Schedule:
         return out
 
     def step(self, model_output, x, t, noise, sampler=SAMPLER_DDPM, eta=0.0, mask=None, motion=None,
-             mask_noise=False, clip_denoised=False):
-        """(sample, pred_xstart) of one p_sample / ddim_sample step given the model output."""
+             mask_noise=False, clip_denoised=False, mean_type=0):
+        """(sample, pred_xstart) of one p_sample / ddim_sample step given the model output.
+        mean_type: what the model predicts -- 0 x_start, 1 epsilon, 2 previous x (converted inside the kernel, reference :398-412)."""
         dev = x.device
         mo = _f32c(model_output, dev, "model_output")
         x = _f32c(x, dev, "x")
@@ -95,9 +96,9 @@ class Schedule:
         t = t.to(device=dev, dtype=torch.int64).contiguous()
         sample, xstart = torch.empty_like(x), torch.empty_like(x)
         B = x.shape[0]
-        N.check(N.lib().mst_step_epilogue(self.handle, N.ptr(mo), N.ptr(x), N.ptr(noise), N.ptr(mask), N.ptr(motion),
-                                          N.ptr(t), B, x.numel() // B, int(sampler), float(eta), int(bool(mask_noise)),
-                                          int(bool(clip_denoised)), N.ptr(sample), N.ptr(xstart), N.stream_ptr(dev)))
+        N.check(N.lib().mst_step_epilogue_mt(self.handle, N.ptr(mo), N.ptr(x), N.ptr(noise), N.ptr(mask), N.ptr(motion),
+                                             N.ptr(t), B, x.numel() // B, int(sampler), int(mean_type), float(eta), int(bool(mask_noise)),
+                                             int(bool(clip_denoised)), N.ptr(sample), N.ptr(xstart), N.stream_ptr(dev)))
         return sample, xstart
 
 
@@ -182,28 +183,30 @@ class DenoiserEngine:
     GAIN_OUTLIER, WEIGHT_SCALE = 8.0, 2.0
 
     def _diagnose(self, layer_tensors):
-        """One stacked reduction per tensor kind and ONE host synchronisation (the tensors may live on the GPU: this runs inside the first
-        call of a freshly loaded model)."""
+        """Per-tensor reductions (amax / median of the LayerNorm gains, rms of the matrices: no stacked copy of the 96 tensors) gathered
+        into ONE small vector and ONE host synchronisation -- this runs inside the first call of a freshly loaded model.
+        Both criteria are validated on the synthetic stress checkpoints only (tests/test_gpu_parity.py: x20 gain outliers 1.1e-3, x3
+        weight scale 1.2e-3 on the default path).  The weight-scale ratio is relative to torch's INITIALISATION rms, which trained
+        checkpoints may exceed without leaving the bar (not calibrated against a real trained checkpoint -- none is
+        available offline), so `weight_diagnostics` says WHICH criterion fired (`gain_outlier`, `weight_scale_above_threshold`) and a
+        caller who knows the checkpoint can tell the two apart."""
         init_rms = {"self_attn.in_proj_weight": (2.0 / (4 * self.latent_dim)) ** 0.5}            # xavier_uniform over [3d, d]
-        by_kind = {}
+        stats, index = [], []
         for name, t in layer_tensors.items():
             layer, kind = name.split(".", 1)
-            by_kind.setdefault(kind, []).append((int(layer), t.detach().float()))
-        stats, index = [], []
-        for kind, items in by_kind.items():
-            v = torch.stack([t for _, t in items])
+            v = t.detach().float()
             if kind in ("norm1.weight", "norm2.weight"):
                 a = v.abs()
-                r = a.amax(dim=1) / a.median(dim=1).values.clamp_min(1e-12)
+                r = a.amax() / a.median().clamp_min(1e-12)
                 what = "gain"
-            elif kind.endswith("weight") and v.dim() == 3:
-                ref = init_rms.get(kind, (1.0 / (3.0 * v.shape[2])) ** 0.5)                          # nn.Linear default: U(-1/sqrt(in), 1/sqrt(in))
-                r = v.pow(2).mean(dim=(1, 2)).sqrt() / ref
+            elif kind.endswith("weight") and v.dim() == 2:
+                ref = init_rms.get(kind, (1.0 / (3.0 * v.shape[1])) ** 0.5)                          # nn.Linear default: U(-1/sqrt(in), 1/sqrt(in))
+                r = v.pow(2).mean().sqrt() / ref
                 what = "scale"
             else:
                 continue
-            stats.append(r.reshape(-1).cpu() if not r.is_cuda else r.reshape(-1))
-            index += [(what, f"{layer}.{kind}") for layer, _ in items]
+            stats.append(r.reshape(1))
+            index.append((what, f"{layer}.{kind}"))
         vals = torch.cat([x.to(stats[0].device) for x in stats]).tolist() if stats else []
         worst_gain, worst_w, where_g, where_w = 1.0, 1.0, "", ""
         for (what, name), r in zip(index, vals):
@@ -217,6 +220,7 @@ class DenoiserEngine:
         if worst_w >= self.WEIGHT_SCALE:
             why.append(f"weight scale x{worst_w:.1f} of the initialisation scale (layers.{where_w})")
         return {"max_layernorm_gain_over_median": worst_gain, "max_weight_scale_over_init": worst_w,
+                "gain_outlier": worst_gain >= self.GAIN_OUTLIER, "weight_scale_above_threshold": worst_w >= self.WEIGHT_SCALE,
                 "recommend_precise": bool(why), "why": "; ".join(why)}
 
     # ------------------------------------------------------------------------------ conditioning

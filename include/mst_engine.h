@@ -189,6 +189,16 @@ int mst_step_epilogue(const mst_schedule* s, const float* model_out_dev, const f
                       float eta, int32_t mask_noise, int32_t clip_denoised,
                       float* sample_out_dev, float* xstart_out_dev, void* stream);
 
+/* The same step for a model that predicts something else than x_start (enum ModelMeanType, gaussian_diffusion.py:69-76; branch
+ * :398-412): mean_type 0 = x_start, 1 = epsilon (x0-hat = sqrt_recip_alphas_cumprod x - sqrt_recipm1_alphas_cumprod out, :426-431),
+ * 2 = previous x (x0-hat = out / coef1 - coef2 / coef1 x, :433-441; the posterior mean is then the model output itself, :399-403).
+ * As in the reference the inpainting blend (:341-349) acts on the raw model output, in front of the conversion. */
+int mst_step_epilogue_mt(const mst_schedule* s, const float* model_out_dev, const float* x_dev,
+                         const float* noise_dev, const float* mask_dev, const float* motion_dev,
+                         const int64_t* t_dev, int32_t batch, int64_t per_clip, int32_t sampler, int32_t mean_type,
+                         float eta, int32_t mask_noise, int32_t clip_denoised,
+                         float* sample_out_dev, float* xstart_out_dev, void* stream);
+
 /* Standard-normal fill with the engine's Philox stream (the generator MST_NOISE_PHILOX uses
  * inside the fused step), so a caller can reproduce in-loop noise: element (clip, f, t) of step
  * `step`.  Replaces th.randn / th.randn_like draws (gaussian_diffusion.py:754, :569). */

@@ -1,7 +1,7 @@
 """k_tok_gemm (csrc/mst_tokgemm.h) against the slab-ring GEMMs it replaces in the training path at batch size: two engines in one
 process (MST_TOK_GEMM=0 / 1 at creation), the same weights and inputs; forward output, dL/dh and all 96 parameter gradients must be
 BIT-identical (same MFMA, same k order, same epilogue code), then both are timed (forward, backward; events on the launch stream).
-    python tools/r5_tok_gemm_check.py [clips]"""
+    python tools/experiments/r5_tok_gemm/r5_tok_gemm_check.py [clips]"""
 import os
 import sys
 import time

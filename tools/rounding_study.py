@@ -38,8 +38,8 @@ def layer(x, w, p, on, keep):
     return F.layer_norm(x + h, (d,), t("norm2.weight"), t("norm2.bias"), 1e-5)
 
 
-def forward(w, pe, x, t, txt, on, keep_fn=None):
-    xs = denoiser.token_stream(w, pe, x, t, txt, dt=H)                       # [B, S, d]; embedding GEMMs rounded as always
+def forward(w, pe, x, t, txt, on, keep_fn=None, uncond=False):
+    xs = denoiser.token_stream(w, pe, x, t, txt, uncond=uncond, dt=H)        # [B, S, d]; embedding GEMMs rounded as always
     for i in range(8):
         p = f"seqTransEncoder.layers.{i}."
         keep = keep_fn(w, i) if keep_fn else {}
@@ -77,7 +77,42 @@ def outlier_cols(w, i):
     return keep
 
 
+def guided(w, pe, x, t, txt, on, scale=2.5):
+    """cfg_sampler.py:36-43: u + scale (c - u), both halves through the same rounding switches"""
+    c = forward(w, pe, x, t, txt, on)
+    u = forward(w, pe, x, t, txt, on, uncond=True)
+    return u + scale * (c - u)
+
+
+def cfg_study():
+    """which operand sites carry the classifier-free-guidance error (scale 2.5 amplifies c - u)?  One guided
+    forward at the HumanML shape, seeded weights: every site alone, all but it, and the cheapest candidates for a split (hi + lo)."""
+    F_, T, B = 263, 196, 2
+    x = syn.normal(SEED, "x/hml", (B, F_, 1, T)); txt = syn.normal(SEED, "txt/hml", (B, 512)); t = np.array([10, 900])
+    pe = syn.positional_table(5000, 512)
+    w = stress("seeded", F_)
+    all_on = {k: True for k in OPS}; all_off = {k: False for k in OPS}
+    ref = guided(w, pe, x, t, txt, all_off)
+    one = rel(forward(w, pe, x, t, txt, all_on), forward(w, pe, x, t, txt, all_off))
+    print(f"== classifier-free guidance (scale 2.5), HumanML shape: single forward all rounded {one:.2e}, guided all rounded {rel(guided(w, pe, x, t, txt, all_on), ref):.2e}")
+    for k in OPS:
+        only = dict(all_off); only[k] = True
+        but = dict(all_on); but[k] = False
+        print(f"   {k:7s} alone rounded {rel(guided(w, pe, x, t, txt, only), ref):.2e}    all but it {rel(guided(w, pe, x, t, txt, but), ref):.2e}")
+    for name, sites in (("every weight exact (4 GEMMs' weights split: + 100 % of the layer MFMA work)", ["qkv.w", "out.w", "ffn1.w", "ffn2.w"]),
+                        ("every GEMM activation exact (+ 100 %)", ["qkv.x", "out.x", "ffn1.x", "ffn2.x"]),
+                        ("attention operands exact (+ 9 %)", ["qk.q", "qk.k", "pv.p", "pv.v"]),
+                        ("out-proj both operands exact (+ 23 %)", ["out.x", "out.w"])):
+        sw = dict(all_on)
+        for k in sites:
+            sw[k] = False
+        print(f"   {name}: {rel(guided(w, pe, x, t, txt, sw), ref):.2e}")
+
+
 if __name__ == "__main__":
+    if "--cfg" in sys.argv:
+        cfg_study()
+        sys.exit(0)
     torch.manual_seed(0)
     F_, T, B = 181, 76, 2
     x = syn.normal(SEED, "x/xia", (B, F_, 1, T)); txt = syn.normal(SEED, "txt/xia", (B, 512)); t = np.array([10, 900])
