@@ -370,7 +370,7 @@ def pmc_traffic(families, rows):
     # file from another build (any csrc/ change since) reads as "no traffic figure", never as a stale number.
     from mst_amd import _native
     have = _native.built_hash()
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json"):
         try:
             doc = json.load(open(os.path.join(prof_dir, name)))
             kernels = doc["kernels"]
@@ -441,16 +441,17 @@ def finetune_roofline(B, world, s_per_iter, wgrad=None):
            "algorithmic_gflop_per_iteration_per_gpu": round(fl * 1e-9, 1),
            "kernel": None, "note": "whole iteration (objective + backward + AdamW) over the dense MFMA peak"}
     # The other roofline: the activation tape.  Algorithmic HBM bytes per layer in units of rows x 512 bytes (every input read once, every
-    # output written once): forward 56 (QKV 8, attention 8, out-proj + LayerNorm 14, FFN1 10, FFN2 + LayerNorm 16),
-    # dgrad chain 76, weight / bias gradients 34 (frozen stacks: none).  One iteration = the B-clip call (all three), the frozen motion
-    # encoder on B clips (forward + dgrad) and the six chained single-clip calls (all three).
+    # output written once): forward 50 at batch size (QKV 8, attention 8, the fused tail 34: att 2 + the stream's hi / lo
+    # 4 + x1 read back 4 in, z1 / x1 / pre / hid / z2 / the stream out 24) and 56 on the small path (out-proj + LayerNorm 14, FFN1 10, FFN2
+    # + LayerNorm 16 instead of the tail), dgrad chain 76, weight / bias gradients 34 (frozen stacks: none).  One iteration = the B-clip
+    # call (all three), the frozen motion encoder on B clips (forward + dgrad) and the six chained single-clip calls (all three).
     S, unit = 197, 512
-    tape = 8 * unit * (B * S * (56 + 76 + 34) + B * S * (56 + 76) + 6 * S * (56 + 76 + 34))
+    tape = 8 * unit * (B * S * (50 + 76 + 34) + B * S * (50 + 76) + 6 * S * (56 + 76 + 34))
     out["tape_traffic"] = {"algorithmic_gb_per_iteration_per_gpu": round(tape * 1e-9, 2),
                            "achieved_tb_per_s": round(world * tape / s_per_iter * 1e-12, 3), "hbm_peak_tb_per_s": 8.0 * world,
                            "frac": round(tape / s_per_iter * 1e-12 / 8.0, 4),
-                           "note": "the training launches sit on NEITHER roofline: each moves 52-103 MB of tape at 1.8-3.3 TB/s behind a serial "
-                                   "burst -> product -> epilogue per workgroup (docs/LAB_NOTES.md R5.7: rebuilding the GEMM main loops changed nothing)"}
+                           "note": "the training launches sit on NEITHER roofline: each moves 52-150 MB of tape at 1.5-3.3 TB/s (docs/LAB_NOTES.md R5.7, "
+                                   "R6.2); what bounds the iteration is the dependent chain on the caller's stream (R6.3)"}
     if wgrad and wgrad.get("launches"):
         n, iters = wgrad["launches"], wgrad["iterations"]
         avg_us = 1e3 * wgrad["total_ms"] / n - wgrad["event_pair_overhead_us"]
@@ -465,7 +466,7 @@ def finetune_roofline(B, world, s_per_iter, wgrad=None):
             "frac_of_mfma_peak": round(tflops / MFMA_PEAK_TFLOPS, 4)}
     # A committed rocprofv3 summary of the same command from an earlier run (possibly another build), with the file's hash: the share of
     # device time that names the dominant kernel comes from there.
-    for name in ("r05_finetune_kernel_stats_streams1.csv", "r04_finetune_kernel_stats_streams1.csv", "r03_finetune_kernel_stats_streams1.csv"):
+    for name in ("r06_finetune_kernel_stats_streams1.csv", "r05_finetune_kernel_stats_streams1.csv", "r04_finetune_kernel_stats_streams1.csv"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             import csv

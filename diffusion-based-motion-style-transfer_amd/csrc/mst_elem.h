@@ -373,6 +373,23 @@ __global__ void k_scatter_token0(const float* __restrict__ d, const float* __res
     g[(size_t)(i / MST_D) * S * MST_D + (i % MST_D)] = d[i] * scale[0];
 }
 
+// the same seed with the zero fill inside (round 6: the 26 MB hipMemsetAsync in front of it was a launch of its own on the backward pass's
+// dependent chain): g[clip][s][:] = s == 0 ? scale[0] * d_mu[clip][:] : 0, one float4 per thread
+__global__ void k_seed_token0(const float* __restrict__ d, const float* __restrict__ scale, int S, int rows, float* __restrict__ g) {
+    const size_t n4 = (size_t)rows * S * (MST_D / 4);
+    const float sc = scale[0];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / (MST_D / 4);
+        const int c4 = (int)(i % (MST_D / 4));
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row % S == 0) {
+            const f32x4 dv = *reinterpret_cast<const f32x4*>(d + (row / S) * MST_D + c4 * 4);
+            v = f32x4{dv[0] * sc, dv[1] * sc, dv[2] * sc, dv[3] * sc};
+        }
+        reinterpret_cast<f32x4*>(g)[i] = v;
+    }
+}
+
 // one wave per (clip, feature) row of a [rows][T] 0/1 mask: 0 = all zeros, 1 = all ones, 2 = anything else
 __global__ __launch_bounds__(256) void k_mask_rowflags(const float* __restrict__ mask, int rows, int T, unsigned char* __restrict__ flags) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;

@@ -1912,6 +1912,8 @@ static int wgrad(mst_engine* e, const f16* dY, int n_out, const f16* X, int k_in
     // whole number of 32-token slabs
     const int tiles = (n_out / 128) * (k_in / 256);
     static const int wg_target = [] { const char* v = getenv("MST_WGRAD_WGS"); return v ? atoi(v) : 128; }();
+    // (round 6, measured and removed: twice the workgroups for layer 0's weight gradients -- they run when the dgrad chain beside them has
+    // ended -- 10.11 / 10.15 / 10.20 ms per iteration without, 10.15 / 10.18 / 10.22 ms with: the wgrad stream's tail is not short of CUs)
     int nsplit = (wg_target + tiles - 1) / tiles;
     const int slabs = (M + 31) / 32;
     if (nsplit > slabs) nsplit = slabs;
@@ -2257,8 +2259,7 @@ extern "C" int mst_motion_encoder_backward(mst_engine* e, const void* tape, cons
     const size_t n = (size_t)M * MST_D, n_out = (size_t)batch * F * frames;
     e->prof_now = 0;
     CHECK(grad_scale_from(e, d_mu, (size_t)batch * MST_D, st));
-    HIPCHECK(hipMemsetAsync(w_.g1, 0, n * sizeof(float), st));                  // only token 0 of every clip carries a gradient
-    hipLaunchKernelGGL(k_scatter_token0, dim3((batch * MST_D + 255) / 256), dim3(256), 0, st, d_mu, (const float*)w_.gscale, S, batch, w_.g1);
+    hipLaunchKernelGGL(k_seed_token0, dim3(2048), dim3(256), 0, st, d_mu, (const float*)w_.gscale, S, batch, w_.g1);   // only token 0 of every clip carries a gradient
     HIPCHECK(hipGetLastError());
     CHECK(train_stack_backward(e, t, batch, S, p_drop, seed, key_keep, nullptr, st));      // frozen stack: input gradient only
     if (p_pe > 0.f) {
