@@ -143,6 +143,7 @@ struct TrainWS {
     // operands the wgrad stream reads while the dgrad chain moves on: double-buffered by layer parity
     f16 *dbr2[2] = {nullptr, nullptr}, *dbr1[2] = {nullptr, nullptr}, *dpre[2] = {nullptr, nullptr}, *dqkv[2] = {nullptr, nullptr};
     f16* datt = nullptr;
+    f16* hidr[2] = {nullptr, nullptr};                  // hid = dropout(GELU(pre)) regenerated by the FFN2 dgrad epilogue: the operand of dW2 (by layer parity)
     hipEvent_t ev_ready = nullptr, ev_side[2] = {nullptr, nullptr};
     hipEvent_t ev_layer[16] = {nullptr};                // recorded when layer l's parameter gradients of the LAST backward call are enqueued
     bool layer_done[16] = {false};
@@ -427,7 +428,7 @@ extern "C" void mst_engine_destroy(mst_engine* e) {
     {
         TrainWS& t = e->tw;
         void* p[] = {t.g0, t.g1, t.dbr2[0], t.dbr2[1], t.dbr1[0], t.dbr1[1], t.dpre[0], t.dpre[1], t.dqkv[0], t.dqkv[1],
-                     t.datt, t.part, t.zeros, t.gscale, t.amax, t.ln_part, t.cs_part};
+                     t.datt, t.part, t.zeros, t.gscale, t.amax, t.ln_part, t.cs_part, t.hidr[0], t.hidr[1]};
         if (t.ev_ready) (void)hipEventDestroy(t.ev_ready);
         for (int i = 0; i < 16; i++) if (t.ev_layer[i]) (void)hipEventDestroy(t.ev_layer[i]);
         for (int i = 0; i < 2; i++) if (t.ev_side[i]) (void)hipEventDestroy(t.ev_side[i]);
@@ -1888,6 +1889,7 @@ static int train_ws(mst_engine* e) {
         CHECK(dmalloc(&t.dbr2[i], Mp * MST_D));
         CHECK(dmalloc(&t.dbr1[i], Mp * MST_D));
         CHECK(dmalloc(&t.dpre[i], Mp * MST_FF));
+        CHECK(dmalloc(&t.hidr[i], Mp * MST_FF));
         CHECK(dmalloc(&t.dqkv[i], Mp * 3 * MST_D));
         HIPCHECK(hipEventCreateWithFlags(&t.ev_side[i], hipEventDisableTiming));
     }
@@ -2019,15 +2021,17 @@ static int train_stack_backward(mst_engine* e, const Tape& t, int rows, int S, f
                            gA, dbr2, w_.ln_part);
         if (wg) hipLaunchKernelGGL(k_ln_bwd_finish, dim3(3 * MST_D / kFinOut), dim3(256), 0, st, w_.ln_part, ln_blocks, w_.gscale, G[10], G[11], G[7]);
         HIPCHECK(hipGetLastError());
-        TO_SIDE()
-        if (wg) CHECK(wgrad(e, dbr2, MST_D, a.hid, MST_FF, M, G[6], nullptr, sw));                 // dW2 += dbr2^T hid
-        // d pre = (dbr2 W2) * mask * gelu'(pre)
+        // d pre = (dbr2 W2) * mask * gelu'(pre); the same epilogue regenerates hid = dropout(GELU(pre)), dW2's operand, from the pre it reads
+        // anyway (round 6: the fused training forward no longer writes hid to the tape -- 2 KB per token and layer less, and a frozen stack
+        // never needs it)
+        f16* hidr = wg ? w_.hidr[par] : nullptr;
         {
-            DEpiRowOp<OpGeluBwd> epi{nullptr, M, OpGeluBwd{a.pre, dpre, MST_FF, make_drop(seed, l, 2, p_drop)}};
+            DEpiRowOp<OpGeluBwd> epi{nullptr, M, OpGeluBwd{a.pre, dpre, MST_FF, make_drop(seed, l, 2, p_drop), hidr}};
             CHECK(small ? launch_small(M, MST_FF, RowsDirect{dbr2, MST_D}, w.w2T, MST_D, MST_D, epi, st)
                         : launch_wide(M, MST_FF / 256, RowsDirect{dbr2, MST_D}, w.w2T, MST_D, MST_D, epi, st));
         }
         TO_SIDE()
+        if (wg) CHECK(wgrad(e, dbr2, MST_D, hidr, MST_FF, M, G[6], nullptr, sw));                  // dW2 += dbr2^T hid
         if (wg) CHECK(wgrad(e, dpre, MST_FF, a.x1h, MST_D, M, G[4], G[5], sw));                    // dW1 += dpre^T x1, db1
         if (fuse_ln) {
             // g(x1) = dpre W1 + dz2 and LayerNorm1's backward behind it in ONE launch (DEpiLnBwd): dz1 -> gA in place, dbr1, the tiles' sums

@@ -56,12 +56,14 @@ struct TailCfg {
     // padded to 13 KB = 13 LDS-DMA pieces.  Linear interpolation error <= h^2 / 8 max|Phi''| = 1.9e-6, far below the f16 store (2^-11).
     static constexpr int GELU_N = 1536, GELU_TAB_BYTES = 13 * 1024;
     static constexpr int OFF_TAB = 69 * 1024;
+    static constexpr int OFF_BO_TR = 82 * 1024, OFF_G1_TR = 88 * 1024, OFF_BE1_TR = 90 * 1024;   // TRAIN: b_out | LayerNorm1 weight | bias, 2 KB each, staged at kernel start
     static constexpr int OFF_EXCH_TR = 84 * 1024;        // TRAIN: LayerNorm1's 4 KB statistics exchange (the att image holds the residual's lo rows then)
     static constexpr int OFF_B1 = 92 * 1024;             // FFN1 bias (4 KB), staged at kernel start
     static constexpr int OFF_X1 = 96 * 1024;             // LayerNorm1 output, 64 x 1 KB; during phase P the residual rows (lo, then hi) are staged here
     static constexpr int SMEM = 160 * 1024;
     static_assert(64 * 1024 <= OFF_CNT && OFF_CNT + 16 <= OFF_TAB && OFF_TAB + GELU_TAB_BYTES <= OFF_B1 && 64 * LN_LD <= SMEM && 2 * HBUF <= OFF_CNT &&
-                  OFF_TAB + GELU_TAB_BYTES <= OFF_EXCH_TR && OFF_EXCH_TR + 4096 <= OFF_B1, "LDS map");
+                  OFF_TAB + GELU_TAB_BYTES <= OFF_BO_TR && OFF_BO_TR + 2048 <= OFF_EXCH_TR && OFF_EXCH_TR + 4096 <= OFF_G1_TR &&
+                  OFF_G1_TR + 2048 <= OFF_BE1_TR && OFF_BE1_TR + 2048 <= OFF_B1, "LDS map");
     static_assert(P_FRAG % D == 0 && F1_FRAG % D == 0 && F2_FRAG % D == 0, "every phase starts on prefetch slot 0");
     static_assert(F1_FRAG == 32 && F2_FRAG == 32, "k_pack_tail's unit arithmetic");
 };
@@ -165,6 +167,7 @@ __device__ __forceinline__ void tape_store8(f16* dst, uint2 v) {
 #else
 #define TT_STORE(dst, v) tape_store8(dst, v)
 #endif
+__device__ __forceinline__ uint32_t tail_keep_bit(const TailDrop& d, uint32_t idx) { return tail_mix32(idx * 0x9E3779B9u + d.key) >= d.thr ? 1u : 0u; }
 struct TailTrain {
     const f16 *xin_h, *xin_l;                                     // the layer's input stream (tape slot l): LayerNorm1's residual
     f16 *z1h, *z1l, *x1h, *x1l, *pre, *hid, *z2h, *z2l;           // tape slots of the layer
@@ -196,7 +199,11 @@ __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ at
     static_assert(!(TRAIN && PERSIST), "the training forward is one launch per layer");
     const f16* const rin_h = TRAIN ? tt.xin_h : hx;                // LayerNorm1's residual rows (TRAIN: hx / hl are the OUTPUT stream)
     const f16* const rin_l = TRAIN ? tt.xin_l : hl;
-    constexpr int D = C::D;
+    // Fragments in flight per wave.  TRAIN: 8 -- the inference kernel measures the same at 8 and 16, and the 32 registers pay for the
+    // training stages' addresses and masks: at 16 hipcc spilled five values, and every scratch reload is a vmcnt(0) that drains the
+    // weight stream AND the tape stores in flight (found in the ISA: four such drains in the GELU(0) stage alone).
+    constexpr int D = TRAIN ? 8 : C::D;
+    static_assert(C::P_FRAG % D == 0 && C::F1_FRAG % D == 0 && C::F2_FRAG % D == 0, "every phase starts on prefetch slot 0");
     // (PERSIST: the lane index is recomputed in every phase and the wave index arrives in a scalar register, so that no per-lane
     // constant stays alive across the other phases' bodies)
     int lane, wave;
@@ -250,6 +257,15 @@ __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ at
     if (wave < 4) tail_glds1((unsigned)lane * 16u, (unsigned long long)(b1 + 256 * wave), __builtin_amdgcn_readfirstlane(smem_base + C::OFF_B1 + 1024 * wave));
     tail_glds1((unsigned)lane * 16u, (unsigned long long)(gelu_tab + 256 * wave), __builtin_amdgcn_readfirstlane(smem_base + C::OFF_TAB + 1024 * wave));
     if (wave < 5) tail_glds1((unsigned)lane * 16u, (unsigned long long)(gelu_tab + 256 * (8 + wave)), __builtin_amdgcn_readfirstlane(smem_base + C::OFF_TAB + 1024 * (8 + wave)));
+    if constexpr (TRAIN) {
+        // LayerNorm1's vectors -> LDS too (waves 0 .. 5, one 1-KB piece each): read with plain global loads in the LayerNorm1 stage, hipcc
+        // waits vmcnt(0) for each of them -- with this kernel's tape stores in flight every such wait drained the store queue
+        if (wave < 6) {
+            const float* src = wave < 2 ? b_out : wave < 4 ? g1 : be1;
+            const int off = wave < 2 ? C::OFF_BO_TR : wave < 4 ? C::OFF_G1_TR : C::OFF_BE1_TR;
+            tail_glds1((unsigned)lane * 16u, (unsigned long long)(src + 256 * (wave & 1)), __builtin_amdgcn_readfirstlane(smem_base + off + 1024 * (wave & 1)));
+        }
+    }
 
     // ---- the weight stream of this wave
     const unsigned w_voff = (unsigned)lane * 16u;
@@ -342,6 +358,28 @@ __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ at
     auto slot1k = [&](int nh, int rb, int tb) {
         return (unsigned)((16 * tb + t16) * 1024 + (((32 * nh + 4 * wave + 2 * rb + (q4 >> 1)) ^ t16) << 4) + 8 * (q4 & 1));
     };
+    // TRAIN: keep masks of sites 1 and 3 as bit sets, filled in the shadow of matrix steps (see phase P / the last FFN2 chunk)
+    uint32_t keep1[2] = {0u, 0u}, keep3[2] = {0u, 0u};
+    auto keep1_step = [&](int k) {                                     // accumulator slot k = (nh, rb, tb): bits 4 k .. 4 k + 3
+        if constexpr (TRAIN) {
+            const int nh = k >> 3, rb = (k >> 2) & 1, tb = k & 3;
+            const uint32_t idx = (uint32_t)(tok0 + 16 * tb + t16) * (uint32_t)MST_D + (uint32_t)(256 * nh + 32 * wave + 16 * rb + 4 * q4);
+            const uint32_t b = tail_keep_bit(tt.d1, idx) | (tail_keep_bit(tt.d1, idx + 1) << 1) | (tail_keep_bit(tt.d1, idx + 2) << 2) |
+                               (tail_keep_bit(tt.d1, idx + 3) << 3);
+            keep1[k >> 3] |= b << (4 * (k & 7));
+        }
+    };
+    auto keep3_step = [&](int r) {                                     // LayerNorm2's row r of this wave: bits 8 r .. (features fa .. + 3 | fb .. + 3)
+        if constexpr (TRAIN) {
+            constexpr bool WIDE_ = MST_TAIL_OUT >= 2;
+            const int fa_ = WIDE_ ? lane * 8 : lane * 4, fb_ = WIDE_ ? lane * 8 + 4 : 256 + lane * 4;
+            const uint32_t base = (uint32_t)(tok0 + RPW * wave + r) * (uint32_t)MST_D;
+            uint32_t b = 0u;
+#pragma unroll
+            for (int i = 0; i < 4; i++) b |= (tail_keep_bit(tt.d3, base + fa_ + i) << i) | (tail_keep_bit(tt.d3, base + fb_ + i) << (4 + i));
+            keep3[r >> 2] |= b << (8 * (r & 3));
+        }
+    };
 #pragma unroll
     for (int nh = 0; nh < 2; nh++)
 #pragma unroll
@@ -361,13 +399,25 @@ __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ at
         const char* img = smem + C::OFF_ATT;
         xread(img, RB1K(), 0, xs[0]);
         constexpr int NPP = C::P_FRAG / D;
-        static_assert(NPP == 4, "passes 0 | 1: the lo rows land, 2 | 3: the hi rows");
+        static_assert(TRAIN || NPP == 4, "passes 0 | 1: the lo rows land, 2 | 3: the hi rows");
         // Neither half of the residual is part of the kernel-start burst: there, 64 KB more in front of (or behind) the att image
         // delay the first MFMA by 1.5 us (measured both ways).  Requested in front of a pass, the rows travel beside the weight stream.
         if constexpr (TRAIN) {
-            // the residual joins BEHIND the dropout of (acc + bias): nothing is added inside the loop
-            pass(img, RB1K(), RA4(), LD1(), 0, true, [](int) {});
-            pass(img, RB1K(), RA4(), LD1(), D / 4, true, [](int) {});
+            // the residual joins BEHIND the dropout of (acc + bias): nothing is added inside the loop.  What the loop's matrix steps DO
+            // carry in their shadow is the keep mask of site 1 (out-proj output): k-step k = 4 pass + s hashes the four elements of
+            // accumulator slot (nh, rb, tb) = (k >> 3, (k >> 2) & 1, k & 3) into bit 4 k + i of (keep1[0], keep1[1]) -- alone in front of
+            // LayerNorm1 the 64 hashes per lane were ~5 us of exposed VALU time.
+            constexpr int STP = D / 4;                                 // k-steps per pass
+            static_assert(NTB == 4 && NPP * STP == 16, "mask bookkeeping: 16 k-steps = 16 accumulator slots");
+#pragma unroll
+            for (int pp = 0; pp < NPP; pp++) {
+                if (pp == NPP / 2) {                                   // the hi rows travel beside the second half of the loop (as in the inference kernel)
+                    stage_rows(rin_h);
+                    pass(img, RB1K(), RA4(), std::integral_constant<int, 1 + 2 * ROW_OPS>(), pp * STP, pp + 1 < NPP, [&](int s_) { keep1_step(pp * STP + s_); });
+                } else {
+                    pass(img, RB1K(), RA4(), LD1(), pp * STP, pp + 1 < NPP, [&](int s_) { keep1_step(pp * STP + s_); });
+                }
+            }
         } else {
         stage_rows(rin_l);
         pass(img, RB1K(), RA4(), std::integral_constant<int, 1 + 2 * ROW_OPS>(), 0, true, [](int) {});
@@ -389,10 +439,10 @@ __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ at
                     }
         }
         tail_barrier();                                                // everybody has read lo: hi may overwrite it
-        }
         stage_rows(rin_h);
         pass(img, RB1K(), RA4(), std::integral_constant<int, 1 + 2 * ROW_OPS>(), 2 * (D / 4), true, [](int) {});
         pass(img, RB1K(), RA4(), LD1(), 3 * (D / 4), false, [](int) {});
+        }
     }
     TAIL_MARK(2)
 
@@ -417,14 +467,15 @@ __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ at
 #pragma unroll
                 for (int rb = 0; rb < 2; rb++) {
                     const int f = 256 * nh + 32 * wave + 16 * rb + 4 * q4;
-                    const f32x4 bo = *reinterpret_cast<const f32x4*>(b_out + f);
+                    const f32x4 bo = *reinterpret_cast<const f32x4*>(smem + C::OFF_BO_TR + f * 4);
 #pragma unroll
                     for (int tb = 0; tb < NTB; tb++) {
-                        const uint32_t idx = (uint32_t)(tok0 + 16 * tb + t16) * (uint32_t)MST_D + (uint32_t)f;
+                        const int k = 8 * nh + 4 * rb + tb;
+                        const uint32_t kb = keep1[k >> 3] >> (4 * (k & 7));
                         const uint2 h = *reinterpret_cast<const uint2*>(x1img + slot1k(nh, rb, tb));
                         f32x4 a = acc[nh][rb][tb] + bo;
-                        a = f32x4{a[0] * tail_drop_mul(tt.d1, idx), a[1] * tail_drop_mul(tt.d1, idx + 1), a[2] * tail_drop_mul(tt.d1, idx + 2),
-                                  a[3] * tail_drop_mul(tt.d1, idx + 3)};
+                        a = f32x4{(kb & 1u) ? a[0] * tt.d1.inv : 0.f, (kb & 2u) ? a[1] * tt.d1.inv : 0.f, (kb & 4u) ? a[2] * tt.d1.inv : 0.f,
+                                  (kb & 8u) ? a[3] * tt.d1.inv : 0.f};
                         acc[nh][rb][tb] = f32x4{add_half<0>(h.x, a[0]), add_half<1>(h.x, a[1]), add_half<0>(h.y, a[2]), add_half<1>(h.y, a[3])};
                     }
                 }
@@ -507,22 +558,24 @@ __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ at
 #pragma unroll
             for (int rb = 0; rb < 2; rb++) {
                 const int f = 256 * nh + 32 * wave + 16 * rb + 4 * q4;
-                const f32x4 g = *reinterpret_cast<const f32x4*>(g1 + f), be = *reinterpret_cast<const f32x4*>(be1 + f);
+                f32x4 g, be;
+                if constexpr (TRAIN) {
+                    g = *reinterpret_cast<const f32x4*>(smem + C::OFF_G1_TR + f * 4);
+                    be = *reinterpret_cast<const f32x4*>(smem + C::OFF_BE1_TR + f * 4);
+                } else {
+                    g = *reinterpret_cast<const f32x4*>(g1 + f);
+                    be = *reinterpret_cast<const f32x4*>(be1 + f);
+                }
 #pragma unroll
                 for (int tb = 0; tb < NTB; tb++) {
                     const f32x4 y = __builtin_elementwise_fma(acc[nh][rb][tb] - mean[tb], g * rstd[tb], be);
                     if constexpr (TRAIN) {
-                        // x1 -> the image (FFN1's operand) and the tape (hi: wgrad operand, hi + lo: LayerNorm2's residual); FFN2 starts from 0
-                        uint2 yh, yl;
-                        split4_f16(y, yh, yl);
+                        // x1 -> the image (FFN1's operand) and its hi half to the tape (dW1's operand).  No lo half: LayerNorm2's residual is
+                        // LayerNorm1 evaluated again, row-wise, from the z1 rows this workgroup has just stored.  FFN2 starts from 0.
+                        const uint2 yh = pack4_f16(y[0], y[1], y[2], y[3]);
                         *reinterpret_cast<uint2*>(x1img + slot1k(nh, rb, tb)) = yh;
                         const int tok = tok0 + 16 * tb + t16;
-                        if (tok < M) {
-                            const size_t o = (size_t)tok * MST_D + f;
-                            // (plain stores: LayerNorm2 of this very workgroup reads the rows back)
-                            *reinterpret_cast<uint2*>(tt.x1h + o) = yh;
-                            *reinterpret_cast<uint2*>(tt.x1l + o) = yl;
-                        }
+                        if (tok < M) TT_STORE(tt.x1h + (size_t)tok * MST_D + f, yh);
                         acc[nh][rb][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
                     } else {
                     acc[nh][rb][tb] = y;
@@ -576,8 +629,7 @@ __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ at
                                             gelu_tab_lds((float)ph[2], gtab) * tail_drop_mul(tt.d2, o + 2), gelu_tab_lds((float)ph[3], gtab) * tail_drop_mul(tt.d2, o + 3));
                 *reinterpret_cast<uint2*>(smem + C::OFF_H + (hc & 1) * C::HBUF + (16 * tb + t16) * 512 + coff) = h16;
                 if (tok < M) {
-                    TT_STORE(tt.pre + o, p16);
-                    TT_STORE(tt.hid + o, h16);
+                    TT_STORE(tt.pre + o, p16);         // (hid is not stored: the backward regenerates it from pre, OpGeluBwd)
                 }
             } else
             *reinterpret_cast<uint2*>(smem + C::OFF_H + (hc & 1) * C::HBUF + (16 * tb + t16) * 512 + coff) =
@@ -636,9 +688,11 @@ __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ at
             TAIL_MARK(23)
             const char* himg = smem + C::OFF_H + C::HBUF;              // chunk 3
             xread(himg, RB512(), 0, xs[0]);
+            // (TRAIN: the keep mask of site 3, the FFN2 output, one LayerNorm2 row per k-step -- this chunk's steps carry no GELU)
+            static_assert(!TRAIN || (NP2 * ST2 == RPW), "one k-step of the last chunk per LayerNorm2 row of a wave");
 #pragma unroll
-            for (int ps = 0; ps + 1 < NP2; ps++) pass(himg, RB512(), RA4(), LD1(), ps * ST2, true, [](int) {});
-            pass(himg, RB512(), RA4(), LD0(), (NP2 - 1) * ST2, false, [](int) {});
+            for (int ps = 0; ps + 1 < NP2; ps++) pass(himg, RB512(), RA4(), LD1(), ps * ST2, true, [&](int s_) { keep3_step(ps * ST2 + s_); });
+            pass(himg, RB512(), RA4(), LD0(), (NP2 - 1) * ST2, false, [&](int s_) { keep3_step((NP2 - 1) * ST2 + s_); });
         }
     }
     tail_fence();
@@ -667,30 +721,43 @@ __device__ __forceinline__ void tail_body(char* smem, const f16* __restrict__ at
         f32x4 xa[RPW], xb[RPW];
         float mean[RPW], rstd[RPW];
         if constexpr (TRAIN) {
-            // z2 = x1 + dropout(hid W2^T + b2): x1 (hi + lo) comes back from the tape slot LayerNorm1 wrote (every wave has since consumed
-            // weight fragments requested behind those stores, and operations complete in issue order: the stores are in L2; this CU never
-            // read the lines, so its L1 holds no older copy)
+            // z2 = x1 + dropout(hid W2^T + b2).  x1 = LayerNorm1(z1) evaluated AGAIN here, row-wise, from the z1 rows (hi + lo) the
+            // LayerNorm1 stage stored (every wave has since consumed weight fragments requested behind those stores, and operations complete
+            // in issue order: the rows are in L2; this CU never read the lines, so its L1 holds no older copy) -- fp32, what the accumulators
+            // held there to ~1e-7; the tape carries no lo half of x1.
             uint2 r1[RPW][4];
 #pragma unroll
             for (int r = 0; r < RPW; r++) {
                 int tok = tok0 + RPW * wave + r;
                 if (tok >= M) tok = M - 1;
                 const size_t off = (size_t)tok * MST_D;
-                r1[r][0] = *reinterpret_cast<const uint2*>(tt.x1h + off + fa);
-                r1[r][1] = *reinterpret_cast<const uint2*>(tt.x1l + off + fa);
-                r1[r][2] = *reinterpret_cast<const uint2*>(tt.x1h + off + fb);
-                r1[r][3] = *reinterpret_cast<const uint2*>(tt.x1l + off + fb);
+                r1[r][0] = *reinterpret_cast<const uint2*>(tt.z1h + off + fa);
+                r1[r][1] = *reinterpret_cast<const uint2*>(tt.z1l + off + fa);
+                r1[r][2] = *reinterpret_cast<const uint2*>(tt.z1h + off + fb);
+                r1[r][3] = *reinterpret_cast<const uint2*>(tt.z1l + off + fb);
             }
+            const f32x4 g1a = *reinterpret_cast<const f32x4*>(g1 + fa), g1b = *reinterpret_cast<const f32x4*>(g1 + fb);
+            const f32x4 e1a = *reinterpret_cast<const f32x4*>(be1 + fa), e1b = *reinterpret_cast<const f32x4*>(be1 + fb);
 #pragma unroll
             for (int r = 0; r < RPW; r++) {
                 const char* srow = smem + (RPW * wave + r) * C::LN_LD;
                 const int tok = tok0 + RPW * wave + r;
-                const uint32_t ia = (uint32_t)tok * (uint32_t)MST_D + (uint32_t)fa, ib = (uint32_t)tok * (uint32_t)MST_D + (uint32_t)fb;
+                const uint32_t kb = keep3[r >> 2] >> (8 * (r & 3));
                 f32x4 a = *reinterpret_cast<const f32x4*>(srow + fa * 4) + ba, b = *reinterpret_cast<const f32x4*>(srow + fb * 4) + bb;
-                a = f32x4{a[0] * tail_drop_mul(tt.d3, ia), a[1] * tail_drop_mul(tt.d3, ia + 1), a[2] * tail_drop_mul(tt.d3, ia + 2), a[3] * tail_drop_mul(tt.d3, ia + 3)};
-                b = f32x4{b[0] * tail_drop_mul(tt.d3, ib), b[1] * tail_drop_mul(tt.d3, ib + 1), b[2] * tail_drop_mul(tt.d3, ib + 2), b[3] * tail_drop_mul(tt.d3, ib + 3)};
-                xa[r] = add4_f16(r1[r][0], r1[r][1], a);
-                xb[r] = add4_f16(r1[r][2], r1[r][3], b);
+                a = f32x4{(kb & 1u) ? a[0] * tt.d3.inv : 0.f, (kb & 2u) ? a[1] * tt.d3.inv : 0.f, (kb & 4u) ? a[2] * tt.d3.inv : 0.f, (kb & 8u) ? a[3] * tt.d3.inv : 0.f};
+                b = f32x4{(kb & 16u) ? b[0] * tt.d3.inv : 0.f, (kb & 32u) ? b[1] * tt.d3.inv : 0.f, (kb & 64u) ? b[2] * tt.d3.inv : 0.f, (kb & 128u) ? b[3] * tt.d3.inv : 0.f};
+                {
+                    f32x4 za = join4_f16(r1[r][0], r1[r][1]), zb = join4_f16(r1[r][2], r1[r][3]);
+                    const f32x4 t1 = za + zb;
+                    const float m1 = wave_sum((t1[0] + t1[1]) + (t1[2] + t1[3])) * (1.0f / MST_D);
+                    za -= m1;
+                    zb -= m1;
+                    const f32x4 q1 = {fmaf(za[0], za[0], zb[0] * zb[0]), fmaf(za[1], za[1], zb[1] * zb[1]), fmaf(za[2], za[2], zb[2] * zb[2]),
+                                      fmaf(za[3], za[3], zb[3] * zb[3])};
+                    const float rs1 = ln_rstd(wave_sum((q1[0] + q1[1]) + (q1[2] + q1[3])));
+                    xa[r] = __builtin_elementwise_fma(za, g1a * rs1, e1a) + a;
+                    xb[r] = __builtin_elementwise_fma(zb, g1b * rs1, e1b) + b;
+                }
                 if (tok < M) {
                     const size_t off = (size_t)tok * MST_D;
                     uint2 zh, zl;

@@ -99,14 +99,20 @@ struct OpFfn1Train {
 // FFN2 dgrad: tile = d hid.  out = tile * dropout-mask * gelu'(pre).
 struct OpGeluBwd {
     const f16* pre; f16* out; int ld; Drop d;
+    f16* hid = nullptr;          // non-null: also hid = dropout(GELU(pre)) (OpFfn1Train's arithmetic) -> the operand of dW2
     __device__ __forceinline__ void operator()(int tok, int c, uint4 v) const {
         const size_t o = (size_t)tok * ld + c;
         const f16x8 g = __builtin_bit_cast(f16x8, v);
         const f16x8 p = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(pre + o));
-        f16x8 r;
+        f16x8 r, h;
 #pragma unroll
-        for (int j = 0; j < 8; j++) r[j] = (f16)((float)g[j] * drop_mul(d, (uint32_t)o + j) * gelu_grad((float)p[j]));
+        for (int j = 0; j < 8; j++) {
+            const float m = drop_mul(d, (uint32_t)o + j);
+            r[j] = (f16)((float)g[j] * m * gelu_grad((float)p[j]));
+            h[j] = (f16)(gelu_erf((float)p[j]) * m);
+        }
         *reinterpret_cast<uint4*>(out + o) = __builtin_bit_cast(uint4, r);
+        if (hid) *reinterpret_cast<uint4*>(hid + o) = __builtin_bit_cast(uint4, h);
     }
 };
 

@@ -18,7 +18,11 @@ using namespace mst;
 #ifndef TAIL_NTB
 #define TAIL_NTB 4           // -DTAIL_NTB=3 / 2: 48- / 32-token tiles
 #endif
+#ifdef TAIL_TRAIN            // -DTAIL_TRAIN: the training instantiation (dropout 0.1 at the three sites, every tape slot written)
+#define KTAIL k_layer_tail_train<TAIL_NTB>
+#else
 #define KTAIL k_layer_tail<TAIL_NTB>
+#endif
 
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 64, M = argc > 2 ? atoi(argv[2]) : B * 197;   // [batch] or [_ tokens]
@@ -35,14 +39,25 @@ int main(int argc, char** argv) {
     hipMemcpy(wt, h.data(), nw * 2, hipMemcpyHostToDevice);
     std::vector<float> ones(4096, 1.0f);
     hipMemcpy(v, ones.data(), 4096 * 4, hipMemcpyHostToDevice);
+#ifdef TAIL_TRAIN
+    f16* tp[8];
+    for (int i = 0; i < 8; i++) hipMalloc(&tp[i], (size_t)(M + 64) * MST_FF * 2);
+    f16 *oh, *ol; hipMalloc(&oh, nx * 2); hipMalloc(&ol, nx * 2);
+    const TailDrop dd{0x1234567u, (uint32_t)(0.1 * 4294967296.0), 1.0f / 0.9f};
+    const TailTrain tt{hx, hl, tp[0], tp[1], tp[2], tp[3], tp[4], tp[5], tp[6], tp[7], dd, dd, dd};
+#endif
     if (hipFuncSetAttribute((const void*)KTAIL, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM) != hipSuccess) { printf("LDS attribute failed\n"); return 1; }
     const int grid = (M + 16 * TAIL_NTB - 1) / (16 * TAIL_NTB);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; rep++) {
-        const int iters = rep == 0 ? 100 : 20000;
+        const int iters = rep == 0 ? 100 : 5000;
         hipEventRecord(e0);
         for (int i = 0; i < iters; i++)
+#ifdef TAIL_TRAIN
+            hipLaunchKernelGGL(KTAIL, dim3(grid), dim3(512), C::SMEM, 0, att, wt, v, v, v, v, v, v, v, oh, ol, v, M, tt);
+#else
             hipLaunchKernelGGL(KTAIL, dim3(grid), dim3(512), C::SMEM, 0, att, wt, v, v, v, v, v, v, v, hx, hl, v, M);
+#endif
         hipEventRecord(e1);
         if (hipEventSynchronize(e1) != hipSuccess) { printf("kernel failed: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
         float ms; hipEventElapsedTime(&ms, e0, e1);
