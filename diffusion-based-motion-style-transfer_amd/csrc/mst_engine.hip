@@ -20,6 +20,7 @@
 #include "mst_gemm_dma.h"
 #include "mst_tail.h"
 #include "mst_trunk.h"
+#include "mst_tail_bwd.h"
 #ifdef EMB_PROBE            // diagnostic build only (tools/experiments/r4_embed_stamps.py): wave 0..7 of every workgroup stamp the 100 MHz clock at the phase marks
 __device__ unsigned long long g_emb_stamp[512][8][8];
 #define EMB_MARK(i) if ((threadIdx.x & 63) == 0 && blockIdx.x < 512) g_emb_stamp[blockIdx.x][threadIdx.x >> 6][i] = __builtin_amdgcn_s_memrealtime();
@@ -129,6 +130,8 @@ struct LayerW {
     // [in][out] f16 copies: the "weights" operand of the dgrad GEMMs (training path)
     f16 *w_inT = nullptr, *w_outT = nullptr, *w1T = nullptr, *w2T = nullptr;
     f16* wtail = nullptr;           // W_out | W1 | W2 as the fused layer tail's slab stream (mst_tail.h, k_pack_tail)
+    f16* wtail_bwd = nullptr;       // W2^T | W1^T | W_out^T as the fused BACKWARD tail's stream (mst_tail_bwd.h, k_pack_tail_bwd): allocated and packed on first use
+    bool tailb_dirty = true;
     f16 *w_in_lo = nullptr, *w_out_lo = nullptr, *w1_lo = nullptr, *w2_lo = nullptr;   // f16(w - f16(w)): the weights' lo halves (precise mode)
     bool tail_dirty = true, qkv_dirty = true;   // wtail / wqkv are older than w_out | w1 | w2 / w_in: repacked by ensure_packed() before the next sampling launch
     f16* wqkv = nullptr;            // W_in as the fused QKV+attention kernel's per-(head, wave) fragment streams (mst_attn.h, k_pack_qkv)
@@ -174,6 +177,7 @@ struct mst_engine {
     f16 *w_pose_in_pk = nullptr, *w_pose_out_pk = nullptr;      // the two projections as per-wave fragment streams (mst_embed.h, k_pack_wave_blocks)
     bool pose_in_dirty = true, pose_out_dirty = true;          // ... older than w_pose_in / w_pose_out: repacked by ensure_packed()
     int small_ln = 1, small_ln_m = 512;   // ... with the LayerNorms inside the consuming GEMMs, up to this many stream rows (MST_SMALL_LN, MST_SMALL_LN_M; tools/experiments/r4_small_sweep.sh: ahead through 2 clips x 197 rows, behind from 4)
+    int train_fuse_bwd_tail = 0;          // training backward at batch size: FFN2 dgrad + GELU' + FFN1 dgrad + LayerNorm1 backward + out-proj dgrad as k_layer_tail_bwd (MST_TRAIN_FUSE_BWD_TAIL)
     int train_small_ln = 1;               // training at a clip or two: the LayerNorms inside the GEMMs behind them (MST_TRAIN_SMALL_LN=0: k_ln_rows_train launches)
     int train_fuse_tail = 1;              // training forward at batch size: out-proj + LN1 + FFN + LN2 as k_layer_tail_train, writing the tape (MST_TRAIN_FUSE_TAIL=0: three ring GEMMs)
     int fuse_ln_bwd = 1;                  // training at batch size: LayerNorm1's backward in the epilogue of the dgrad GEMM in front of it (MST_FUSE_LN_BWD=0: two launches)
@@ -392,6 +396,7 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     if (const char* v = getenv("MST_FUSE_LN_BWD")) e->fuse_ln_bwd = atoi(v) != 0;
     if (const char* v = getenv("MST_TRAIN_FUSE_TAIL")) e->train_fuse_tail = atoi(v) != 0;
     if (const char* v = getenv("MST_TRAIN_SMALL_LN")) e->train_small_ln = atoi(v) != 0;
+    if (const char* v = getenv("MST_TRAIN_FUSE_BWD_TAIL")) e->train_fuse_bwd_tail = atoi(v) != 0;
     if (const char* v = getenv("MST_SMALL_LN")) e->small_ln = atoi(v) != 0;
     if (const char* v = getenv("MST_SMALL_LN_M")) e->small_ln_m = atoi(v);
     if (const char* v = getenv("MST_TAIL_NTB")) { int n = atoi(v); e->tail_ntb = (n >= 2 && n <= 4) ? n : 0; }
@@ -422,7 +427,7 @@ extern "C" void mst_engine_destroy(mst_engine* e) {
     for (int l = 0; l < e->cfg.num_layers; l++) {
         LayerW& w = e->L[l];
         void* p[] = {w.w_in, w.w_out, w.w1, w.w2, w.b_in, w.b_out, w.b1, w.b2, w.g1, w.be1, w.g2, w.be2,
-                     w.w_inT, w.w_outT, w.w1T, w.w2T, w.wtail, w.wqkv, w.w_in_lo, w.w_out_lo, w.w1_lo, w.w2_lo, w.wsm_in, w.wsm_out, w.wsm_1, w.wsm_2};
+                     w.w_inT, w.w_outT, w.w1T, w.w2T, w.wtail, w.wtail_bwd, w.wqkv, w.w_in_lo, w.w_out_lo, w.w1_lo, w.w2_lo, w.wsm_in, w.wsm_out, w.wsm_1, w.wsm_2};
         for (void* q : p) (void)hipFree(q);
     }
     {
@@ -515,7 +520,7 @@ extern "C" int mst_load_weight(mst_engine* e, const char* name, const float* src
         // The fused kernels' packed copies (k_pack_qkv, k_pack_tail) are made once per re-upload and layer, and only if a sampling launch
         // follows (ensure_packed): a fine-tune iteration re-uploads all 96 tensors and its training node reads the plain matrices.
         if (rc == 0 && r == "self_attn.in_proj_weight") w.qkv_dirty = true;
-        if (rc == 0 && repack) w.tail_dirty = true;
+        if (rc == 0 && repack) w.tail_dirty = w.tailb_dirty = true;
         if (rc == 0 && is_gemm_w) w.small_dirty = true;
         if (rc == 0 && is_gemm_w) { if (e->precise) e->lo_missing.erase(n); else e->lo_missing.insert(n); }
     } else if (n == "input_process.poseEmbedding.weight") {
@@ -596,7 +601,7 @@ extern "C" int mst_load_layers(mst_engine* e, const float* const* srcs, void* st
         HIPCHECK(hipGetLastError());
     }
     for (int l = 0; l < nl; l++) {
-        e->L[l].qkv_dirty = e->L[l].tail_dirty = e->L[l].small_dirty = true;
+        e->L[l].qkv_dirty = e->L[l].tail_dirty = e->L[l].tailb_dirty = e->L[l].small_dirty = true;
         for (int k = 0; k < 12; k++) {
             char name[160];
             snprintf(name, sizeof(name), "seqTransEncoder.layers.%d.%s", l, kNames[k]);
@@ -2004,6 +2009,19 @@ static int train_stack_backward(mst_engine* e, const Tape& t, int rows, int S, f
         HIPCHECK(hipEventRecord(w_.ev_ready, st));                  \
         HIPCHECK(hipStreamWaitEvent(sw, w_.ev_ready, 0));           \
     }
+    const bool fused_bwd = e->train_fuse_bwd_tail && !small && ln_tiles <= 512;
+    if (fused_bwd) {
+        for (int l = 0; l < nl; l++) {
+            LayerW& w = e->L[l];
+            if (!w.wtail_bwd) CHECK(dmalloc(&w.wtail_bwd, TailCfg::LAYER_BYTES / 2));
+            if (!w.tailb_dirty) continue;
+            hipLaunchKernelGGL(k_pack_tail_bwd, dim3(640), dim3(256), 0, st, w.w_outT, w.w2T, w.w1T, w.wtail_bwd);
+            HIPCHECK(hipGetLastError());
+            w.tailb_dirty = false;
+        }
+        CHECK(ensure_dyn_lds((const void*)k_layer_tail_bwd<true>, TailBwdCfg::SMEM));
+        CHECK(ensure_dyn_lds((const void*)k_layer_tail_bwd<false>, TailBwdCfg::SMEM));
+    }
     for (int l = nl - 1; l >= 0; l--) {
         const LayerW& w = e->L[l];
         const TapeL& a = t.L[l];
@@ -2025,6 +2043,20 @@ static int train_stack_backward(mst_engine* e, const Tape& t, int rows, int S, f
         // anyway (round 6: the fused training forward no longer writes hid to the tape -- 2 KB per token and layer less, and a frozen stack
         // never needs it)
         f16* hidr = wg ? w_.hidr[par] : nullptr;
+        if (fused_bwd) {
+            // round 6: FFN2 dgrad + GELU' + FFN1 dgrad + LayerNorm1 backward + out-proj dgrad in ONE launch (mst_tail_bwd.h): dz1 -> gA in place,
+            // d att; with gradients wanted also dpre, hid, dbr1 and the tiles' [dgamma1 | dbeta1 | db_out] sums
+            auto td = [&](int site) { const Drop d = make_drop(seed, l, site, p_drop); return TailDrop{d.key, d.thr, d.inv}; };
+            const TailBwdOut o{wg ? dpre : nullptr, hidr, wg ? dbr1 : nullptr, wg ? w_.ln_part : nullptr};
+            if (wg) hipLaunchKernelGGL(k_layer_tail_bwd<true>, dim3(ln_tiles), dim3(512), TailBwdCfg::SMEM, st, dbr2, w.wtail_bwd, a.pre, a.z1h, a.z1l, w.g1, gA, w_.datt, o, td(1), td(2), M, e->gelu_tab);
+            else hipLaunchKernelGGL(k_layer_tail_bwd<false>, dim3(ln_tiles), dim3(512), TailBwdCfg::SMEM, st, dbr2, w.wtail_bwd, a.pre, a.z1h, a.z1l, w.g1, gA, w_.datt, o, td(1), td(2), M, e->gelu_tab);
+            if (wg) hipLaunchKernelGGL(k_ln_bwd_finish, dim3(3 * MST_D / kFinOut), dim3(256), 0, st, w_.ln_part, ln_tiles, w_.gscale, G[8], G[9], G[3]);
+            HIPCHECK(hipGetLastError());
+            TO_SIDE()
+            if (wg) CHECK(wgrad(e, dbr2, MST_D, hidr, MST_FF, M, G[6], nullptr, sw));                  // dW2 += dbr2^T hid
+            if (wg) CHECK(wgrad(e, dpre, MST_FF, a.x1h, MST_D, M, G[4], G[5], sw));                    // dW1 += dpre^T x1, db1
+            if (wg) CHECK(wgrad(e, dbr1, MST_D, a.att, MST_D, M, G[2], nullptr, sw));                  // dW_out += dbr1^T att
+        } else {
         {
             DEpiRowOp<OpGeluBwd> epi{nullptr, M, OpGeluBwd{a.pre, dpre, MST_FF, make_drop(seed, l, 2, p_drop), hidr}};
             CHECK(small ? launch_small(M, MST_FF, RowsDirect{dbr2, MST_D}, w.w2T, MST_D, MST_D, epi, st)
@@ -2060,6 +2092,7 @@ static int train_stack_backward(mst_engine* e, const Tape& t, int rows, int S, f
             CHECK(small ? launch_small(M, MST_D, RowsDirect{dbr1, MST_D}, w.w_outT, MST_D, MST_D, epi, st)
                         : launch_wide(M, MST_D / 256, RowsDirect{dbr1, MST_D}, w.w_outT, MST_D, MST_D, epi, st));
         }
+        }   // !fused_bwd
         // attention backward -> d qkv
         CHECK(launch_attn_bwd(a.qkv, a.att, w_.datt, dqkv, S, rows, make_drop(seed, l, 0, p_drop), key_keep, a.lse, small ? 1 : 0, st));
         TO_SIDE()

@@ -44,7 +44,7 @@ grads = [torch.zeros(torch.from_numpy(w[f"seqTransEncoder.layers.{i}.{k}"]).shap
 tape = eng.train_tape(B, S)
 res = {"batch": B, "tokens": B * S, "dropout": P}
 res["native_fwd_ms"] = timed(lambda: eng.train_forward(h, P, 1, tape))
-res["native_bwd_ms"] = timed(lambda: eng.train_backward(tape, r, P, 1, grads))
+res["native_bwd_ms"] = timed(lambda: eng.train_backward(tape, r, P, 1, None if os.environ.get("TB_FROZEN") else grads))   # TB_FROZEN=1: input gradient only (a frozen stack)
 flop_fwd = 8 * 905.76e6 * B
 res["native_fwd_tflops"] = flop_fwd / res["native_fwd_ms"] / 1e9
 res["native_fwdbwd_tflops"] = 3 * flop_fwd / (res["native_fwd_ms"] + res["native_bwd_ms"]) / 1e9
