@@ -177,7 +177,8 @@ struct mst_engine {
     f16 *w_pose_in_pk = nullptr, *w_pose_out_pk = nullptr;      // the two projections as per-wave fragment streams (mst_embed.h, k_pack_wave_blocks)
     bool pose_in_dirty = true, pose_out_dirty = true;          // ... older than w_pose_in / w_pose_out: repacked by ensure_packed()
     int small_ln = 1, small_ln_m = 512;   // ... with the LayerNorms inside the consuming GEMMs, up to this many stream rows (MST_SMALL_LN, MST_SMALL_LN_M; tools/experiments/r4_small_sweep.sh: ahead through 2 clips x 197 rows, behind from 4)
-    int train_fuse_bwd_tail = 0;          // training backward at batch size: FFN2 dgrad + GELU' + FFN1 dgrad + LayerNorm1 backward + out-proj dgrad as k_layer_tail_bwd (MST_TRAIN_FUSE_BWD_TAIL)
+    int train_fuse_bwd_tail = 1;          // training backward at batch size: FFN2 dgrad + GELU' + FFN1 dgrad + LayerNorm1 backward + out-proj dgrad as k_layer_tail_bwd
+                                          // (MST_TRAIN_FUSE_BWD_TAIL: 0 = three dgrad launches, 1 = frozen stacks (no parameter gradients: the motion encoder), 2 = every stack)
     int train_small_ln = 1;               // training at a clip or two: the LayerNorms inside the GEMMs behind them (MST_TRAIN_SMALL_LN=0: k_ln_rows_train launches)
     int train_fuse_tail = 1;              // training forward at batch size: out-proj + LN1 + FFN + LN2 as k_layer_tail_train, writing the tape (MST_TRAIN_FUSE_TAIL=0: three ring GEMMs)
     int fuse_ln_bwd = 1;                  // training at batch size: LayerNorm1's backward in the epilogue of the dgrad GEMM in front of it (MST_FUSE_LN_BWD=0: two launches)
@@ -396,7 +397,7 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     if (const char* v = getenv("MST_FUSE_LN_BWD")) e->fuse_ln_bwd = atoi(v) != 0;
     if (const char* v = getenv("MST_TRAIN_FUSE_TAIL")) e->train_fuse_tail = atoi(v) != 0;
     if (const char* v = getenv("MST_TRAIN_SMALL_LN")) e->train_small_ln = atoi(v) != 0;
-    if (const char* v = getenv("MST_TRAIN_FUSE_BWD_TAIL")) e->train_fuse_bwd_tail = atoi(v) != 0;
+    if (const char* v = getenv("MST_TRAIN_FUSE_BWD_TAIL")) e->train_fuse_bwd_tail = atoi(v);
     if (const char* v = getenv("MST_SMALL_LN")) e->small_ln = atoi(v) != 0;
     if (const char* v = getenv("MST_SMALL_LN_M")) e->small_ln_m = atoi(v);
     if (const char* v = getenv("MST_TAIL_NTB")) { int n = atoi(v); e->tail_ntb = (n >= 2 && n <= 4) ? n : 0; }
@@ -2009,7 +2010,9 @@ static int train_stack_backward(mst_engine* e, const Tape& t, int rows, int S, f
         HIPCHECK(hipEventRecord(w_.ev_ready, st));                  \
         HIPCHECK(hipStreamWaitEvent(sw, w_.ev_ready, 0));           \
     }
-    const bool fused_bwd = e->train_fuse_bwd_tail && !small && ln_tiles <= 512;
+    // with parameter gradients the fused launch also writes dpre, hid and dbr1 as 8-byte pieces from the accumulator layout and is no faster
+    // than the three launches yet (113 against 128-155 us beside the wgrad stream: LAB_NOTES R6.9); a frozen stack writes none of them
+    const bool fused_bwd = (e->train_fuse_bwd_tail >= 2 || (e->train_fuse_bwd_tail == 1 && !grads)) && !small && ln_tiles <= 512;
     if (fused_bwd) {
         for (int l = 0; l < nl; l++) {
             LayerW& w = e->L[l];

@@ -322,9 +322,9 @@ __global__ __launch_bounds__(512) void k_layer_tail_bwd(const f16* __restrict__ 
                     // lane, no barrier, no bank conflict): with acc AND xhat in registers the stage was 81 spilled dwords
                     if (nh == 1) *reinterpret_cast<f32x4*>(park + (rb * NTB + tb) * 8192) = acc[nh][rb][tb];
                 }
-                // (one (nh, rb) group of loads at a time: hoisted together the 48 loads of the stage are 128 registers, and a spilled
+                // (one feature half of loads at a time: hoisted together the 48 loads of the stage are 128 registers, and a spilled
                 // register of a weight fragment still in flight is a corrupted register -- tools/audit_stream_isa.py)
-                tail_fence();
+                if (rb == 1) tail_fence();
             }
         float mw[NTB], m2[NTB];
 #pragma unroll

@@ -350,8 +350,12 @@ def test_train_edge_shapes(rows, S, p):
     assert rel_l2(d_in.cpu().numpy(), href.grad.cpu().numpy()) <= TOL_GRAD
     for i in (0, 1, 2, 4, 6, 7, 8, 11, 84 + 0, 84 + 5, 84 + 10):
         assert rel_l2(grads[i].cpu().numpy(), params[i].grad.cpu().numpy()) <= 2 * TOL_GRAD, (i, LAYER_TENSORS[i % 12])
+    # frozen mode (grads=None: the motion encoder's backward).  On the large-tile path it takes the fused backward tail (round 6,
+    # csrc/mst_tail_bwd.h) while the pass with parameter gradients keeps the three dgrad launches: d hid stays fp32 until GELU' is applied
+    # there, the unfused epilogue rounds it to f16 first -- the two agree to f16 rounding, and each has to hold the autograd tolerance
     d_in2 = eng.train_backward(tape, r, p, seed, None)
-    assert rel_l2(d_in2.cpu().numpy(), d_in.cpu().numpy()) < 1e-6
+    assert rel_l2(d_in2.cpu().numpy(), href.grad.cpu().numpy()) <= TOL_GRAD
+    assert rel_l2(d_in2.cpu().numpy(), d_in.cpu().numpy()) < 1.5e-3
 
 
 @pytest.mark.parametrize("rows,p", [(14, 0.1), (20, 0.1)])

@@ -96,7 +96,8 @@ def main():
                 fifo.append(())
             elif op.startswith("global_load"):
                 ops = [o.strip() for o in operands.split(",")]
-                is_stream = op == "global_load_dwordx4" and len(ops) >= 3 and ops[2].split()[0].startswith("s[")
+                # (dwordx2 too: the backward tail's `pre` values come in by hand-counted 8-byte loads, csrc/mst_tail_bwd.h tailb_load8)
+                is_stream = op in ("global_load_dwordx4", "global_load_dwordx2") and len(ops) >= 3 and ops[2].split()[0].startswith("s[")
                 if is_stream:
                     nstream += 1
                 fifo.append(tuple(sorted(regs(ops[0]))) if is_stream else ())
@@ -106,7 +107,9 @@ def main():
           f"{len(fifo)} VM ops still in flight at s_endpgm, {len(bad)} hazards")
     for b in bad[:40]:
         print("  line %d: %s   <- in-flight v%s" % (b[0], b[1], list(b[2])))
-    return 1 if bad or spill or agpr else 0
+    # --allow-spills (the training kernels): scratch traffic costs time -- every reload is a vmcnt(0) -- but is only WRONG when it touches a
+    # register of a load in flight, which is what `hazards` counts
+    return 1 if bad or agpr or (spill and "--allow-spills" not in sys.argv) else 0
 
 
 if __name__ == "__main__":
