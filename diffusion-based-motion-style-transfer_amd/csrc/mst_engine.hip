@@ -177,6 +177,7 @@ struct mst_engine {
     f16 *w_pose_in_pk = nullptr, *w_pose_out_pk = nullptr;      // the two projections as per-wave fragment streams (mst_embed.h, k_pack_wave_blocks)
     bool pose_in_dirty = true, pose_out_dirty = true;          // ... older than w_pose_in / w_pose_out: repacked by ensure_packed()
     int small_ln = 1, small_ln_m = 512;   // ... with the LayerNorms inside the consuming GEMMs, up to this many stream rows (MST_SMALL_LN, MST_SMALL_LN_M; tools/experiments/r4_small_sweep.sh: ahead through 2 clips x 197 rows, behind from 4)
+    int train_fuse_ln2_bwd = 0;           // ... with LayerNorm2's backward at the head of the same launch (MST_TRAIN_FUSE_LN2_BWD; LAB_NOTES R6.9)
     int train_fuse_bwd_tail = 1;          // training backward at batch size: FFN2 dgrad + GELU' + FFN1 dgrad + LayerNorm1 backward + out-proj dgrad as k_layer_tail_bwd
                                           // (MST_TRAIN_FUSE_BWD_TAIL: 0 = three dgrad launches, 1 = frozen stacks (no parameter gradients: the motion encoder), 2 = every stack)
     int train_small_ln = 1;               // training at a clip or two: the LayerNorms inside the GEMMs behind them (MST_TRAIN_SMALL_LN=0: k_ln_rows_train launches)
@@ -398,6 +399,7 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     if (const char* v = getenv("MST_TRAIN_FUSE_TAIL")) e->train_fuse_tail = atoi(v) != 0;
     if (const char* v = getenv("MST_TRAIN_SMALL_LN")) e->train_small_ln = atoi(v) != 0;
     if (const char* v = getenv("MST_TRAIN_FUSE_BWD_TAIL")) e->train_fuse_bwd_tail = atoi(v);
+    if (const char* v = getenv("MST_TRAIN_FUSE_LN2_BWD")) e->train_fuse_ln2_bwd = atoi(v);
     if (const char* v = getenv("MST_SMALL_LN")) e->small_ln = atoi(v) != 0;
     if (const char* v = getenv("MST_SMALL_LN_M")) e->small_ln_m = atoi(v);
     if (const char* v = getenv("MST_TAIL_NTB")) { int n = atoi(v); e->tail_ntb = (n >= 2 && n <= 4) ? n : 0; }
@@ -2024,7 +2026,9 @@ static int train_stack_backward(mst_engine* e, const Tape& t, int rows, int S, f
         }
         CHECK(ensure_dyn_lds((const void*)k_layer_tail_bwd<true>, TailBwdCfg::SMEM));
         CHECK(ensure_dyn_lds((const void*)k_layer_tail_bwd<false>, TailBwdCfg::SMEM));
+        CHECK(ensure_dyn_lds((const void*)k_layer_tail_bwd<false, true>, TailBwdCfg::SMEM));
     }
+    const bool fused_ln2 = fused_bwd && e->train_fuse_ln2_bwd && !grads;      // (frozen stacks: with gradients dbr2 and LayerNorm2's sums must reach HBM anyway)
     for (int l = nl - 1; l >= 0; l--) {
         const LayerW& w = e->L[l];
         const TapeL& a = t.L[l];
@@ -2038,10 +2042,12 @@ static int train_stack_backward(mst_engine* e, const Tape& t, int rows, int S, f
         for (int i = 0; i < 12; i++) if (!G[i]) return fail("mst_train_backward: null gradient buffer (layer %d, tensor %d)", l, i);
         if (two && side_used[par]) HIPCHECK(hipStreamWaitEvent(st, w_.ev_side[par], 0));
         // LayerNorm2 backward: gB -> dz2 (gA, fp32) and the branch gradient dbr2 (f16); dgamma2, dbeta2, db2
+        if (!fused_ln2) {
         hipLaunchKernelGGL(ln_bwd, dim3(ln_blocks), dim3(64 * ln_wpb), 0, st, gB, a.z2h, a.z2l, w.g2, M, make_drop(seed, l, 3, p_drop), w_.gscale,
                            gA, dbr2, w_.ln_part);
         if (wg) hipLaunchKernelGGL(k_ln_bwd_finish, dim3(3 * MST_D / kFinOut), dim3(256), 0, st, w_.ln_part, ln_blocks, w_.gscale, G[10], G[11], G[7]);
         HIPCHECK(hipGetLastError());
+        }
         // d pre = (dbr2 W2) * mask * gelu'(pre); the same epilogue regenerates hid = dropout(GELU(pre)), dW2's operand, from the pre it reads
         // anyway (round 6: the fused training forward no longer writes hid to the tape -- 2 KB per token and layer less, and a frozen stack
         // never needs it)
@@ -2051,7 +2057,9 @@ static int train_stack_backward(mst_engine* e, const Tape& t, int rows, int S, f
             // d att; with gradients wanted also dpre, hid, dbr1 and the tiles' [dgamma1 | dbeta1 | db_out] sums
             auto td = [&](int site) { const Drop d = make_drop(seed, l, site, p_drop); return TailDrop{d.key, d.thr, d.inv}; };
             const TailBwdOut o{wg ? dpre : nullptr, hidr, wg ? dbr1 : nullptr, wg ? w_.ln_part : nullptr};
-            if (wg) hipLaunchKernelGGL(k_layer_tail_bwd<true>, dim3(ln_tiles), dim3(512), TailBwdCfg::SMEM, st, dbr2, w.wtail_bwd, a.pre, a.z1h, a.z1l, w.g1, gA, w_.datt, o, td(1), td(2), M, e->gelu_tab);
+            const TailBwdLn2 n2{gB, a.z2h, a.z2l, w.g2, td(3)};
+            if (fused_ln2) hipLaunchKernelGGL((k_layer_tail_bwd<false, true>), dim3(ln_tiles), dim3(512), TailBwdCfg::SMEM, st, dbr2, w.wtail_bwd, a.pre, a.z1h, a.z1l, w.g1, gA, w_.datt, o, td(1), td(2), M, e->gelu_tab, n2);
+            else if (wg) hipLaunchKernelGGL(k_layer_tail_bwd<true>, dim3(ln_tiles), dim3(512), TailBwdCfg::SMEM, st, dbr2, w.wtail_bwd, a.pre, a.z1h, a.z1l, w.g1, gA, w_.datt, o, td(1), td(2), M, e->gelu_tab);
             else hipLaunchKernelGGL(k_layer_tail_bwd<false>, dim3(ln_tiles), dim3(512), TailBwdCfg::SMEM, st, dbr2, w.wtail_bwd, a.pre, a.z1h, a.z1l, w.g1, gA, w_.datt, o, td(1), td(2), M, e->gelu_tab);
             if (wg) hipLaunchKernelGGL(k_ln_bwd_finish, dim3(3 * MST_D / kFinOut), dim3(256), 0, st, w_.ln_part, ln_tiles, w_.gscale, G[8], G[9], G[3]);
             HIPCHECK(hipGetLastError());

@@ -22,6 +22,9 @@
 #include "mst_tail.h"
 #include "mst_train.h"
 
+#ifndef MST_TB_PROBE          // timing-only probe builds of tools/r6_tb_probe2.sh: 1 = no LayerNorm-stage global loads / stores, 2 = no out-proj phase, 3 = no pre loads / GELU'
+#define MST_TB_PROBE 0
+#endif
 namespace mst {
 
 struct TailBwdCfg {
@@ -72,6 +75,16 @@ struct TailBwdOut {                                       // WG only (null other
     f16 *dpre, *hid, *dbr1;                               // [M][1024], [M][1024], [M][512]: operands of dW1, dW2, dW_out
     float* part;                                          // [tiles][3][512]: the tile's dgamma1 | dbeta1 | db_out sums (k_ln_bwd_finish adds them in tile order)
 };
+// LN2 = true: LayerNorm2's backward (k_ln_bwd's row arithmetic, gaussian_diffusion.py's post-norm block differentiated) runs at the head of
+// this launch instead of as a launch of its own in front of it: the tile's rows of the incoming gradient and of z2 come in as coalesced row
+// loads, dz2 leaves for `g` as rows, and the dbr2 image is written straight into LDS (no HBM round trip for it).  Frozen stacks only
+// (WG = false): with parameter gradients dbr2 must reach HBM for dW2 anyway and the three LayerNorm2 sums need a tile reduction.
+struct TailBwdLn2 {
+    const float* g_in;                                    // [M][512] fp32: gradient wrt the layer's output
+    const f16 *z2h, *z2l;                                 // tape: LayerNorm2's input rows
+    const float* g2;                                      // LayerNorm2 weight
+    TailDrop d3;                                          // keep mask of the FFN2 output
+};
 
 // one 8-byte asm load (counted in vmcnt with the stream; hipcc must not wait for it)
 __device__ __forceinline__ void tailb_load8(u32x2_t& d, unsigned voff, unsigned long long sbase) {
@@ -79,12 +92,12 @@ __device__ __forceinline__ void tailb_load8(u32x2_t& d, unsigned voff, unsigned 
 }
 __device__ __forceinline__ void tailb_touch(u32x2_t& d) { asm volatile("" : "+v"(d)); }
 
-template <bool WG>
+template <bool WG, bool LN2 = false>
 __global__ __launch_bounds__(512) void k_layer_tail_bwd(const f16* __restrict__ dbr2, const f16* __restrict__ wt, const f16* __restrict__ pre,
                                                         const f16* __restrict__ z1h, const f16* __restrict__ z1l,
                                                         const float* __restrict__ g1, float* __restrict__ g, f16* __restrict__ datt,
                                                         const TailBwdOut o, const TailDrop d1, const TailDrop d2, int M,
-                                                        const float* __restrict__ gelu_tab) {
+                                                        const float* __restrict__ gelu_tab, const TailBwdLn2 n2 = TailBwdLn2{}) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using C = TailCfg;
     using B = TailBwdCfg;
@@ -98,6 +111,7 @@ __global__ __launch_bounds__(512) void k_layer_tail_bwd(const f16* __restrict__ 
     if (tid < 4) arrived[tid] = 0;
 
     // ---- kernel-start burst: the tile's dbr2 rows -> the image (row r = 1 KB, 16-B chunk c at c ^ (r & 15)), LayerNorm1's weight -> LDS
+    if constexpr (!LN2) {
 #pragma unroll
     for (int j = 0; j < RPW; j++) {
         const int r = RPW * wave + j;
@@ -105,6 +119,7 @@ __global__ __launch_bounds__(512) void k_layer_tail_bwd(const f16* __restrict__ 
         if (tok >= M) tok = M - 1;
         const unsigned voff = (unsigned)tok * (unsigned)(MST_D * 2) + (unsigned)((lane ^ (r & 15)) << 4);
         tail_glds1(voff, (unsigned long long)dbr2, __builtin_amdgcn_readfirstlane(smem_base + B::OFF_IMG + r * 1024));
+    }
     }
     if (wave < 2) tail_glds1((unsigned)lane * 16u, (unsigned long long)(g1 + 256 * wave), __builtin_amdgcn_readfirstlane(smem_base + B::OFF_G1 + 1024 * wave));
     tail_glds1((unsigned)lane * 16u, (unsigned long long)(gelu_tab + 256 * wave), __builtin_amdgcn_readfirstlane(smem_base + B::OFF_TAB + 1024 * wave));
@@ -182,8 +197,70 @@ __global__ __launch_bounds__(512) void k_layer_tail_bwd(const f16* __restrict__ 
         for (int rb = 0; rb < 2; rb++)
 #pragma unroll
             for (int tb = 0; tb < NTB; tb++) acc[nh][rb][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (LN2) {
+        // =========================================================================================== LayerNorm2 backward (row layout)
+        // wave w: rows [8 w, 8 w + 8) of the tile; lane l: features 4 l .. + 3 and 256 + 4 l .. + 3 (k_ln_bwd's map).  The D weight fragments
+        // requested above travel meanwhile (hipcc's waits for the loads below can only be stricter for them being older).
+        const int fa = lane * 4, fb = 256 + lane * 4;
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(n2.g2 + fa), gb = *reinterpret_cast<const f32x4*>(n2.g2 + fb);
+        static_assert(!(WG && LN2), "LayerNorm2 rides in the frozen-stack launch only");
+        char* const dimg = smem + B::OFF_IMG;
+#pragma unroll
+        for (int h4 = 0; h4 < RPW / 4; h4++) {
+            uint2 zr[4][4];
+            f32x4 gy[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                int tok = tok0 + RPW * wave + 4 * h4 + i;
+                if (tok >= M) tok = M - 1;
+                const size_t off = (size_t)tok * MST_D;
+                zr[i][0] = *reinterpret_cast<const uint2*>(n2.z2h + off + fa);
+                zr[i][1] = *reinterpret_cast<const uint2*>(n2.z2l + off + fa);
+                zr[i][2] = *reinterpret_cast<const uint2*>(n2.z2h + off + fb);
+                zr[i][3] = *reinterpret_cast<const uint2*>(n2.z2l + off + fb);
+                gy[i][0] = *reinterpret_cast<const f32x4*>(n2.g_in + off + fa);
+                gy[i][1] = *reinterpret_cast<const f32x4*>(n2.g_in + off + fb);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int r = RPW * wave + 4 * h4 + i, tok = tok0 + r;
+                f32x4 xa = join4_f16(zr[i][0], zr[i][1]), xb = join4_f16(zr[i][2], zr[i][3]);
+                const f32x4 ya = gy[i][0], yb = gy[i][1];
+                const f32x4 t = xa + xb;
+                const float mean = wave_sum((t[0] + t[1]) + (t[2] + t[3])) * (1.0f / MST_D);
+                xa -= mean;
+                xb -= mean;
+                const f32x4 sq = {fmaf(xa[0], xa[0], xb[0] * xb[0]), fmaf(xa[1], xa[1], xb[1] * xb[1]), fmaf(xa[2], xa[2], xb[2] * xb[2]),
+                                  fmaf(xa[3], xa[3], xb[3] * xb[3])};
+                const float rstd = ln_rstd(wave_sum((sq[0] + sq[1]) + (sq[2] + sq[3])));
+                xa *= rstd;                                            // xhat
+                xb *= rstd;
+                const f32x4 aa = ga * ya, ab = gb * yb;
+                const f32x4 u1 = aa + ab, u2 = aa * xa + ab * xb;
+                const float c1 = wave_sum((u1[0] + u1[1]) + (u1[2] + u1[3])) * (1.0f / MST_D);
+                const float c2 = wave_sum((u2[0] + u2[1]) + (u2[2] + u2[3])) * (1.0f / MST_D);
+                const f32x4 za = (aa - c1 - xa * c2) * rstd, zb = (ab - c1 - xb * c2) * rstd;
+                const uint32_t ia = (uint32_t)tok * (uint32_t)MST_D + (uint32_t)fa, ib = (uint32_t)tok * (uint32_t)MST_D + (uint32_t)fb;
+                const f32x4 qa = {za[0] * tail_drop_mul(n2.d3, ia), za[1] * tail_drop_mul(n2.d3, ia + 1), za[2] * tail_drop_mul(n2.d3, ia + 2),
+                                  za[3] * tail_drop_mul(n2.d3, ia + 3)};
+                const f32x4 qb = {zb[0] * tail_drop_mul(n2.d3, ib), zb[1] * tail_drop_mul(n2.d3, ib + 1), zb[2] * tail_drop_mul(n2.d3, ib + 2),
+                                  zb[3] * tail_drop_mul(n2.d3, ib + 3)};
+                const uint2 pa = pack4_f16(qa[0], qa[1], qa[2], qa[3]), pb = pack4_f16(qb[0], qb[1], qb[2], qb[3]);
+                // features fa .. + 3 = bytes 8 l .. of the row: chunk l / 2 (fb: 32 + l / 2), half (l & 1)
+                char* dst = dimg + r * 1024 + (lane & 1) * 8;
+                *reinterpret_cast<uint2*>(dst + (((lane >> 1) ^ (r & 15)) << 4)) = pa;
+                *reinterpret_cast<uint2*>(dst + (((32 + (lane >> 1)) ^ (r & 15)) << 4)) = pb;
+                if (tok < M) {
+                    const size_t off = (size_t)tok * MST_D;
+                    *reinterpret_cast<f32x4*>(g + off + fa) = za;
+                    *reinterpret_cast<f32x4*>(g + off + fb) = zb;
+                }
+            }
+        }
+        tail_fence();
+    }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D) : "memory");          // this wave's dbr2 rows (and its g1 / table pieces) have landed: behind them only the D fragments
-    tail_barrier();                                                    // ... and everybody's
+    tail_barrier();                                                    // ... and everybody's (LN2: the image the waves have just written)
 
     // =========================================================================================== FFN backward, four hidden chunks
     // "F1"(hc): acch = W2^T[chunk hc] . dbr2^T = d hid of the chunk;  G'(hc): d pre = d hid * keep2 * GELU'(pre) -> H image (+ tape);
@@ -206,7 +283,9 @@ __global__ __launch_bounds__(512) void k_layer_tail_bwd(const f16* __restrict__ 
             for (int rb = 0; rb < 2; rb++)
 #pragma unroll
                 for (int tb = 0; tb < NTB; tb++) acch[rb][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if MST_TB_PROBE != 3
             pre_issue(hc);
+#endif
             xread(img, RB1K(), 0, xs[0]);
 #pragma unroll 1
             for (int ps = 0; ps < C::F1_FRAG / D; ps++) pass(img, RB1K(), RA2(), LD1(), ps * (D / 2), ps + 1 < C::F1_FRAG / D, [](int) {});
@@ -229,8 +308,13 @@ __global__ __launch_bounds__(512) void k_layer_tail_bwd(const f16* __restrict__ 
                 const float2 e = *reinterpret_cast<const float2*>(gtab + ((unsigned)u << 3));
                 const float Phi = fmaf(e.y, __builtin_amdgcn_fractf(u), e.x);
                 const float phi = 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);
+#if MST_TB_PROBE == 3
+                dp[i] = v[i] * m;
+                if constexpr (WG) hh[i] = v[i];
+#else
                 dp[i] = v[i] * m * fmaf(x, phi, Phi);
                 if constexpr (WG) hh[i] = x * Phi * m;
+#endif
             }
             const uint2 d16 = pack4_f16(dp[0], dp[1], dp[2], dp[3]);
             *reinterpret_cast<uint2*>(smem + B::OFF_H + (hc & 1) * B::HBUF + (16 * tb + t16) * 512 + coff) = d16;
@@ -315,8 +399,13 @@ __global__ __launch_bounds__(512) void k_layer_tail_bwd(const f16* __restrict__ 
                     int tok = tok0 + 16 * tb + t16;
                     if (tok >= M) tok = M - 1;
                     const size_t off = (size_t)tok * MST_D + f;
+#if MST_TB_PROBE == 1
+                    const f32x4 r = {1.f, 2.f, 3.f, (float)off};
+                    zx[nh][rb][tb] = f32x4{(float)tok, 1.f, (float)f, 2.f};
+#else
                     const f32x4 r = *reinterpret_cast<const f32x4*>(g + off);
                     zx[nh][rb][tb] = join4_f16(*reinterpret_cast<const uint2*>(z1h + off), *reinterpret_cast<const uint2*>(z1l + off));
+#endif
                     acc[nh][rb][tb] += r;
                     // g(x1) of the upper feature half waits in the dead H images (16 bytes per lane and slot, lane-linear: private to the
                     // lane, no barrier, no bank conflict): with acc AND xhat in registers the stage was 81 spilled dwords
@@ -416,7 +505,9 @@ __global__ __launch_bounds__(512) void k_layer_tail_bwd(const f16* __restrict__ 
                                       dz[3] * tail_drop_mul(d1, idx + 3)};
                     *reinterpret_cast<uint2*>(dimg + slot1k(nh, rb, tb)) = pack4_f16(db[0], db[1], db[2], db[3]);
                     if (tok < M) {
+#if MST_TB_PROBE != 1
                         *reinterpret_cast<f32x4*>(g + (size_t)tok * MST_D + f) = dz;
+#endif
                         if constexpr (WG) {
                             cg += gy * xh;
                             cb += gy;
@@ -447,6 +538,7 @@ __global__ __launch_bounds__(512) void k_layer_tail_bwd(const f16* __restrict__ 
     tail_barrier();                                                    // the dbr1 image (and the tile sums) are complete
 
     // =========================================================================================== d att = dbr1 W_out
+#if MST_TB_PROBE != 2
     {
         const char* img = smem + B::OFF_IMG;
 #define TB_ISSUE(J) tail_wload<((J) & 3) * 1024>(q[J], w_voff, (unsigned long long)(wnext + ((J) >> 2) * 4096))
@@ -459,6 +551,7 @@ __global__ __launch_bounds__(512) void k_layer_tail_bwd(const f16* __restrict__ 
         for (int pp = 0; pp + 1 < NPP; pp++) pass(img, RB1K(), RA4(), LD1(), pp * (D / 4), true, [](int) {});
         pass(img, RB1K(), RA4(), LD0(), (NPP - 1) * (D / 4), false, [](int) {});
     }
+#endif
     tail_fence();
     {
         // -> the dead H images as a 64 x 1 KB image, then out as whole rows (16 bytes per lane); WG: the dbr1 rows and the tile sums too

@@ -27,8 +27,8 @@ hipcc $FLAGS '-DMST_SRC_HASH="audit"' -save-temps=obj -o $ROOT/gpurun_out/isa/li
 S=$ROOT/gpurun_out/isa/mst_engine-hip-amdgcn-amd-amdhsa-gfx950.s
 test -s $S || { echo "hipcc produced no ISA: see gpurun_out/isa/build.log"; exit 1; }
 rc=0
-for k in k_layer_tail_trainILi4E k_layer_tail_bwdILb0E k_layer_tail_bwdILb1E; do      # training kernels: spills are reported, hazards fail
-  python3 $ROOT/tools/audit_stream_isa.py $S $k --allow-spills || rc=1
+for k in k_layer_tail_trainILi4E k_layer_tail_bwdILb0ELb0E k_layer_tail_bwdILb1ELb0E k_layer_tail_bwdILb0ELb1E; do      # training kernels: spills are reported, hazards fail
+  timeout 300 python3 $ROOT/tools/audit_stream_isa.py $S $k --allow-spills || rc=1
 done
 for k in k_layer_tailILi2E k_layer_tailILi3E k_layer_tailILi4E k_qkv_attention2ILi2E k_qkv_attention2ILi4E k_qkv_attention2ILi6E k_qkv_attention2ILi8E k_qkv_attention2ILi10E k_qkv_attention2ILi12E k_qkv_attention2ILi13E; do
   python3 $ROOT/tools/audit_stream_isa.py $S $k || rc=1
