@@ -528,6 +528,9 @@ def finetune_main(args):
     opt = FusedAdamW(model.parameters_wo_enc(), lr=1e-5, weight_decay=0.0)
     red = LayerBucketReducer(model)
 
+    # MST_FT_OVERLAP_BACKWARD=1: few_shot_style_finetune_losses(overlap_backward=True) -- measured in round 6, no gain (LAB_NOTES R6.10); off
+    OVERLAP = os.environ.get("MST_FT_OVERLAP_BACKWARD", "0") == "1"
+
     def iteration(reduce=True):
         # range((1000 - 700) / 1000 * 20), training_loop.py:247; onto the device as UniformSampler.sample does it (pinned staging, no
         # blocking copy: the host is not tied to the GPU once per iteration -- diffusion/resample.py host_to_device_async)
@@ -535,7 +538,8 @@ def finetune_main(args):
         red.zero_grad()
         red.enabled = reduce
         terms = d_ddim.few_shot_style_finetune_losses(model, t2m, tt, content, style, skip_steps=700, model_kwargs=y1,
-                                                      model_t2m_kwargs=yB, semantic_guidance=1, use_ddim=1, Ls=10)
+                                                      model_t2m_kwargs=yB, semantic_guidance=1, use_ddim=1, Ls=10,
+                                                      overlap_backward=OVERLAP)
         terms["loss"].backward()
         red.finish()
         opt.step()
@@ -546,12 +550,14 @@ def finetune_main(args):
         t0 = time.perf_counter()
         for _ in range(n):
             loss = iteration(reduce)
+        timed.host_s = time.perf_counter() - t0              # the host has enqueued everything; how far ahead of the GPU it is says who bounds the loop
         sharding.barrier(dev)
         return time.perf_counter() - t0, float(loss)
 
     for _ in range(max(1, args.warmup)):
         iteration()
     dt, loss = timed(args.steps)
+    host_s = timed.host_s
     group = sharding.group_report(dt, B * args.steps, dev if args.backend == "nccl" else "cpu")
     dt = sharding.max_over_ranks(dt, dev if args.backend == "nccl" else "cpu")
     comm = None
@@ -601,7 +607,8 @@ def finetune_main(args):
                 "config": {"workload": f"configs[3]: data-parallel fine-tune, {B} clips/GPU x (263,1,196), one 64-clip objective call + "
                            "6 chained single-clip steps + frozen motion encoder + backward + AdamW per iteration",
                            "global_batch": world * B, "parallelism": f"dp{world}, 8 per-layer gradient buckets, all-reduce overlapped with backward"},
-                "iterations_per_s": round(args.steps / dt, 3), "final_loss": round(loss, 5), "allreduce": comm, "distributed": group}
+                "iterations_per_s": round(args.steps / dt, 3), "final_loss": round(loss, 5), "allreduce": comm, "distributed": group,
+                "host_enqueue_ms_per_step": round(1e3 * host_s / args.steps, 3)}     # rank 0's Python + launch time per iteration, no synchronisation inside
         line["roofline"] = finetune_roofline(B, world, dt / args.steps, wgrad)
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -177,7 +177,7 @@ struct mst_engine {
     f16 *w_pose_in_pk = nullptr, *w_pose_out_pk = nullptr;      // the two projections as per-wave fragment streams (mst_embed.h, k_pack_wave_blocks)
     bool pose_in_dirty = true, pose_out_dirty = true;          // ... older than w_pose_in / w_pose_out: repacked by ensure_packed()
     int small_ln = 1, small_ln_m = 512;   // ... with the LayerNorms inside the consuming GEMMs, up to this many stream rows (MST_SMALL_LN, MST_SMALL_LN_M; tools/experiments/r4_small_sweep.sh: ahead through 2 clips x 197 rows, behind from 4)
-    int train_fuse_ln2_bwd = 0;           // ... with LayerNorm2's backward at the head of the same launch (MST_TRAIN_FUSE_LN2_BWD; LAB_NOTES R6.9)
+    int train_fuse_ln2_bwd = 1;           // ... with LayerNorm2's backward at the head of the same launch (frozen stacks; MST_TRAIN_FUSE_LN2_BWD=0: a launch of its own; LAB_NOTES R6.9)
     int train_fuse_bwd_tail = 1;          // training backward at batch size: FFN2 dgrad + GELU' + FFN1 dgrad + LayerNorm1 backward + out-proj dgrad as k_layer_tail_bwd
                                           // (MST_TRAIN_FUSE_BWD_TAIL: 0 = three dgrad launches, 1 = frozen stacks (no parameter gradients: the motion encoder), 2 = every stack)
     int train_small_ln = 1;               // training at a clip or two: the LayerNorms inside the GEMMs behind them (MST_TRAIN_SMALL_LN=0: k_ln_rows_train launches)

@@ -92,6 +92,30 @@ class MaskedL2Fn(torch.autograd.Function):
         return d_a, (d_b if ctx.needs_input_grad[1] else None), None
 
 
+class JoinLossesFn(torch.autograd.Function):
+    """a + b where `a` was produced on a SIDE stream and `b` on the caller's: the sum is evaluated on the side stream (which waits for
+    b; the caller's stream waits for nothing), the node itself belongs to the caller's stream -- autograd files a node under the stream
+    that is current when its forward returns -- so the backward pass hands the incoming gradient to b's branch on the caller's stream at
+    once and to a's branch on the side stream behind an event.  The result must not be read on the caller's stream before the backward
+    pass has joined the streams (GaussianDiffusion.few_shot_style_finetune_losses, overlap_backward)."""
+
+    @staticmethod
+    def forward(ctx, a, b, side):
+        main = torch.cuda.current_stream(b.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        b.record_stream(side)                  # b's memory may go back to the caller's pool only behind the side stream's read
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            out = a + b
+        out.record_stream(main)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g, None
+
+
 class TextCosineFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, f, m):

@@ -416,7 +416,9 @@ class GaussianDiffusion:
             n = self.num_timesteps - skip_timesteps - (stop_timesteps if stop_timesteps is not None else 0)
             ev = self.__dict__.get("_chain_start_event")
             ev, ev_dev = ev if isinstance(ev, tuple) else (ev, None)
-            chain = ChainedCalls(n, start_event=ev, device=ev_dev if ev_dev is not None else device)
+            chain = ChainedCalls(n, start_event=ev, device=ev_dev if ev_dev is not None else device,
+                                 defer_join=bool(self.__dict__.get("_chain_defer_join")))
+            self.__dict__["_chain_last"] = chain
             with chain:
                 device, img, indices = self._loop_setup(model, shape, noise, device, skip_timesteps, init_image, stop_timesteps, model_kwargs)
             yield from self._grad_steps(ddim, model, img, indices, shape, device, progress, clip_denoised, model_kwargs, eta,
@@ -514,12 +516,21 @@ class GaussianDiffusion:
     # ------------------------------------------------------------------------------ fine-tune loss
     def few_shot_style_finetune_losses(self, model, x_start, t, x_content_start, x_style_start, skip_steps=700,
                                        model_kwargs=None, noise=None, model_t2m_kwargs=None, semantic_guidance=0,
-                                       use_ddim=0, Ls=10):
+                                       use_ddim=0, Ls=10, overlap_backward=False):
         """Few-shot style fine-tuning objective (reference :1317-1399): a text-to-motion branch on
         `x_start` (q_sample with UNIFORM noise, sic :1332) whose output is scored by the frozen motion
         encoder against the text feature, plus masked-L2 between the style clip and every x0-hat of a
         short in-graph sampling loop started from the content clip.  Autograd flows through the model,
-        so this path uses torch ops; forward-only pieces (q_sample) use the HIP kernels."""
+        so this path uses torch ops; forward-only pieces (q_sample) use the HIP kernels.
+
+        overlap_backward (not in the reference's signature; default off): the masked-L2 terms and the sum of the two losses are
+        evaluated on the chained steps' SIDE stream and the caller's stream is never made to wait for the chain's forward calls, so
+        `loss.backward()` starts the text branch's backward pass (text cosine, motion encoder, the 64-clip call: nothing of it depends
+        on the chain) while the chain is still in its forward calls, instead of ~1 ms later.  The price is a protocol: until
+        `loss.backward()` has returned, terms["loss"] and terms["rot_mse"] must not be READ on the caller's stream (.item(), printing:
+        they are produced on the side stream); the backward pass joins the streams.  Measured in round 6 (LAB_NOTES R6.10): the caller's
+        stream ends its forward work 1.1 ms earlier, its backward pass then takes 1.2 ms longer beside the chain's last steps, and the
+        iteration is 9.8 ms either way -- bit-identical gradients, no gain, so nothing in the package turns it on."""
         inner = model.model if hasattr(model, "timestep_map") else model
         motion_enc = inner.controlmdm.motion_enc if hasattr(inner, "controlmdm") else inner.motion_enc
         mask = model_kwargs['y']['mask']
@@ -547,21 +558,35 @@ class GaussianDiffusion:
         else:
             sample_fn = self.p_sample_loop
         self.__dict__["_chain_start_event"] = chain_start
+        self.__dict__["_chain_defer_join"] = bool(overlap_backward) and chain_start is not None and bool(semantic_guidance)
+        self.__dict__["_chain_last"] = None
         try:
             sample = sample_fn(model, x_content_start.shape, clip_denoised=False, model_kwargs=model_kwargs,
                                skip_timesteps=skip_steps, init_image=x_content_start, progress=True, dump_steps=None, noise=None,
                                const_noise=False, cond_fn_with_grad=True, pred_xstart_in_graph=True, dump_all_xstart=True)
         finally:
             self.__dict__["_chain_start_event"] = None
-        num_step = len(sample)
-        sample = th.cat(sample, dim=0)
+            self.__dict__["_chain_defer_join"] = False
+            chain, self.__dict__["_chain_last"] = self.__dict__.get("_chain_last"), None
         if self.loss_type not in (LossType.MSE, LossType.RESCALED_MSE):
             raise NotImplementedError(self.loss_type)
         assert self.model_mean_type == ModelMeanType.START_X
         assert x_style_start.shape == x_content_start.shape
-        terms = {"rot_mse": self.masked_l2(x_style_start.expand(num_step, -1, -1, -1), sample,
-                                           mask.expand(num_step, -1, -1, -1))}
-        if semantic_guidance:
+        num_step = len(sample)
+        # the chain's outputs live on its side stream when the join was deferred: their consumers run there too
+        side = chain.side if (chain is not None and chain.deferred) else None
+        # (a chain that took no side stream -- MST_CHAIN / MST_CHAIN_STREAM off -- left everything on the caller's stream: plain path)
+        import contextlib
+        with (th.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            sample = th.cat(sample, dim=0)
+            terms = {"rot_mse": self.masked_l2(x_style_start.expand(num_step, -1, -1, -1), sample,
+                                               mask.expand(num_step, -1, -1, -1))}
+            rot_mean = terms["rot_mse"].mean() if side is not None else None
+        if semantic_guidance and side is not None:
+            from .fused_ops import JoinLossesFn
+            terms["text_cosine"] = text_cosine
+            terms["loss"] = JoinLossesFn.apply(rot_mean, terms["text_cosine"] * Ls, side)
+        elif semantic_guidance:
             terms["text_cosine"] = text_cosine
             terms["loss"] = terms["rot_mse"].mean() + terms["text_cosine"] * Ls
         else:

@@ -83,21 +83,38 @@ class LayerBucketReducer:
         self.launch_order.append(b["layer"])
         self.launched_in.append(where)
 
-    def _native_layer_ready(self, eng, after=None):
+    def _native_layer_ready(self, eng, after=None, chain=None):
         """Called by the LAST native node of a backward pass right after its backward call returned (GPU work enqueued, not
         finished): start every layer's exchange behind that layer's gradient event.  after: a CUDA event behind gradient sums that
-        were added OUTSIDE the engine's own streams (GradSink.join_chain on the caller's stream); the exchange waits for it too."""
+        were added OUTSIDE the engine's own streams (GradSink.join_chain on the caller's stream); the exchange waits for it too.
+        chain: gradient sums of a pass that ran on a SIDE stream into accumulators of its own (GradSink.hand_over_chain): each layer's
+        share is added into its bucket HERE, on the communication stream, behind the layer's gradient event and in front of the
+        bucket's exchange, so the caller's stream never waits for that pass."""
         if all(b["launched"] for b in self.buckets):
             raise RuntimeError(self._TWICE)
         if after is not None:
             self.comm.wait_event(after)
+        if chain is not None:
+            self.comm.wait_stream(chain["side"])
+            extra = chain["views"]
+            if any(id(p) not in extra for b in self.buckets for p in b["params"]):
+                raise RuntimeError("LayerBucketReducer: the chained pass holds no accumulator for a bucket's parameter")
         for b in self.buckets:
             if b["launched"]:
+                if chain is not None:
+                    raise RuntimeError(self._TWICE)
                 continue
             with torch.cuda.stream(self.comm):
                 eng.wait_layer_grads(b["layer"], self.comm)          # comm stream: wait for layer's wgrads, nothing else
                 b["flat"].record_stream(self.comm)
+                if chain is not None:
+                    torch._foreach_add_([p.grad for p in b["params"]], [extra[id(p)] for p in b["params"]])
                 self._launch(b, "backward")
+        if chain is not None:
+            done = torch.cuda.Event()
+            done.record(self.comm)
+            chain["release"](done)
+    _native_layer_ready.adds_chain_sums = True
 
     def _native_grads_ready(self):
         """End of the backward pass (GradSink.flush): whatever was not started from inside the pass starts now."""

@@ -86,6 +86,22 @@ class GradSink:
             cur.wait_stream(main)          # whoever asked for the join reads the sums on ITS stream
         return free                        # recorded on the caller's stream behind the add (a reducer told "ready" right now waits for it)
 
+    def hand_over_chain(self):
+        """Late join with a gradient reducer (round 6): instead of adding the chain's sums on the caller's stream, give them to the
+        reducer, which adds each layer's share into its bucket on the COMMUNICATION stream, behind that layer's gradient event and in
+        front of the bucket's exchange -- the caller's stream never waits for the side stream's pass.  Returns None when nothing is
+        pending, else {"side": stream, "views": {id(param): its private accumulator}, "release": fn(event)}; `release` must be called
+        with an event recorded behind the last add (the accumulators may be zeroed only behind it)."""
+        if self.pending is None:
+            return None
+        side, cviews, _main = self.pending
+        self.pending = None
+        host = self.host
+
+        def release(event):
+            host.__dict__["_mst_chain_acc_free"] = event
+        return {"side": side, "views": {id(p): v for p, v in zip(self.params, cviews)}, "release": release}
+
     def begin(self, device):
         grads = [p.grad for p in self.params]
         if all(g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.device == device for g in grads):
@@ -160,7 +176,7 @@ def _sink_views(ctx, params_need_grad, device, join=True):
         sink.abort()                      # stale: its pass raised before the flush callback could run
     if not sink.active:
         sink.begin(device)
-    if join:
+    if join and not _JOIN_LATE():
         sink.join_chain()
     return sink.views
 
@@ -184,13 +200,27 @@ def _node_done(ctx, had_param_grads):
     if sink.open_nodes == 0 and ready is not None and sink.flat is None:      # in-place mode: p.grad IS the reducer's bucket
         # (the chain as the pass's LAST node: its sums are added on the caller's stream HERE, behind everything the earlier nodes
         # accumulated there; the engine's per-layer events do not cover that add, so the reducer also waits for `after`)
-        after = sink.join_chain()
-        ready(ctx.eng, after)
+        # (late join: only when THIS node is a call of its own on the caller's stream -- its engine's per-layer events then cover
+        # everything but the chain's sums; with the chain as the last node the events are the chain engine's, and `after` is needed)
+        if _JOIN_LATE() and getattr(ready, "adds_chain_sums", False) and getattr(ctx, "chain", None) is None:
+            ready(ctx.eng, None, sink.hand_over_chain())
+        else:
+            ready(ctx.eng, sink.join_chain())
 
 
 def _CHAIN_ON():
     import os
     return os.environ.get("MST_CHAIN", "1") != "0"      # MST_CHAIN=0: every model call differentiates alone (A/B, tests)
+
+
+def _JOIN_LATE():
+    """MST_CHAIN_JOIN_LATE=1 (round 6, measured, OFF by default): the chain's gradient sums join the pass's accumulators at its END
+    (GradSink.flush, or layer by layer on a reducer's communication stream), not in front of the next native node: a + b = b + a bit for
+    bit (tests/test_gpu_boundary.py), and the 64-clip call's backward pass does not wait for the side stream's pass.  Same-box A/B of the
+    fine-tune line: 9.75 / 9.77 / 9.93 ms per iteration with the early join, 9.79 / 9.84 / 10.51 ms with the late one -- the caller's
+    stream was not waiting there (LAB_NOTES R6.10), so the default stays the order of round 5."""
+    import os
+    return os.environ.get("MST_CHAIN_JOIN_LATE", "0") == "1"
 
 
 def _CHAIN_BWD_SIDE_ON():
@@ -228,7 +258,7 @@ class ChainedCalls:
     current = None
     _side = {}
 
-    def __init__(self, n, start_event=None, device=None):
+    def __init__(self, n, start_event=None, device=None, defer_join=False):
         """start_event: a CUDA event recorded (on the caller's stream) where everything the chain reads was ready -- the chain's forward
         calls then run on a SIDE stream behind that event, on a second engine instance, beside whatever the caller's stream has been
         given since (the fine-tune objective: the 64-clip text-to-motion call and the frozen motion encoder, neither of which the
@@ -245,6 +275,11 @@ class ChainedCalls:
         self.main = self.side = self._sctx = None
         self.prev = None
         self._depth = 0
+        # defer_join (round 6): the caller's stream is NOT made to wait for the side stream when a step's block ends; whoever consumes the
+        # steps' outputs does so on `self.side` (GaussianDiffusion.few_shot_style_finetune_losses(overlap_backward=True): the masked-L2
+        # terms and the sum of the losses), so that the caller's stream can start the text branch's backward pass while the chain is still
+        # in its forward calls.  Only honoured when the chain really runs on a side stream.
+        self.defer_join = bool(defer_join)
 
     # The block is entered PER STEP of the *_with_grad loop (`with chain: model call`), never across a generator's yield: between two
     # steps the consumer runs with its own current stream and no chain installed.
@@ -275,8 +310,14 @@ class ChainedCalls:
         if self._sctx is not None:
             self._sctx.__exit__(*exc)
             self._sctx = None
-            self.main.wait_stream(self.side)               # what follows on the caller's stream may read the step's outputs
+            if not self.defer_join:
+                self.main.wait_stream(self.side)           # what follows on the caller's stream may read the step's outputs
         return False
+
+    @property
+    def deferred(self):
+        """True when the steps' outputs live on the side stream and the caller's stream has not been told to wait for them."""
+        return self.defer_join and self.side is not None
 
     @contextlib.contextmanager
     def foreign_call(self, *tensors):

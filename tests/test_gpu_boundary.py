@@ -403,11 +403,12 @@ def test_chain_and_side_stream_switches_give_the_same_gradients(monkeypatch):
     style = cu(syn.normal(SEED, "xia/style", shp))
     names = [n for n, p in model.named_parameters() if not n.startswith("motion_enc.")]
 
-    def objective():
+    def objective(overlap=False):
         model.zero_grad()
         with recorded_noise("xia/ft1"):
             terms = dd.few_shot_style_finetune_losses(model, t2m, torch.tensor([2, 4], device=dev()), motion[:1], style, skip_steps=700,
-                                                      model_kwargs=y1, model_t2m_kwargs=y_t2m, semantic_guidance=1, use_ddim=1, Ls=10)
+                                                      model_kwargs=y1, model_t2m_kwargs=y_t2m, semantic_guidance=1, use_ddim=1, Ls=10,
+                                                      overlap_backward=overlap)
         terms["loss"].backward()
         torch.cuda.synchronize()
         grads = dict(model.named_parameters())
@@ -454,6 +455,21 @@ def test_chain_and_side_stream_switches_give_the_same_gradients(monkeypatch):
         la, ga = res[("1", "1")][part]
         lb, gb = inline[part]
         assert la == lb and all(torch.equal(a, b) for a, b in zip(ga, gb)), ("the side-stream backward pass changed the gradients", part)
+    # round 6: the chain's terms and the sum of the losses left on the side stream, the caller's stream never waiting for the chain's forward
+    # calls (overlap_backward) -- and the chain's sums joined at the END of the pass instead of in front of the 64-clip call's backward
+    # (MST_CHAIN_JOIN_LATE=1; the default is round 5's order): no arithmetic changes, same bits
+    la, ga = res[("1", "1")][0]
+    for tag, late in (("overlap", None), ("overlap, late join", "1"), ("late join", "1")):
+        if late is not None:
+            monkeypatch.setenv("MST_CHAIN_JOIN_LATE", late)
+        lo, go = objective(overlap=tag.startswith("overlap"))
+        monkeypatch.delenv("MST_CHAIN_JOIN_LATE", raising=False)
+        assert lo == la and all(torch.equal(a, b) for a, b in zip(ga, go)), (tag, "changed the gradients")
+    for stream_on in ("0",):            # no side stream to leave anything on: overlap_backward is then the plain path
+        monkeypatch.setenv("MST_CHAIN_STREAM", stream_on)
+        lo, go = objective(overlap=True)
+        monkeypatch.setenv("MST_CHAIN_STREAM", "1")
+        assert lo == la and all(torch.equal(a, b) for a, b in zip(ga, go))
     assert side_taken[("1", "1")] and not side_taken[("1", "0")]
     assert not side_taken[("0", "1")] and not side_taken[("0", "0")], "an unchained call must stay on the caller's stream"
     for part in (0, 1):

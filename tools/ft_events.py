@@ -61,21 +61,29 @@ def _ex(self, *exc):
 _ns.ChainedCalls.__enter__, _ns.ChainedCalls.__exit__ = _en, _ex
 
 
+OVERLAP = os.environ.get("FT_OVERLAP", "0") == "1"      # FT_OVERLAP=1: few_shot_style_finetune_losses(overlap_backward=True)
+QUICK = os.environ.get("FT_QUICK", "0") == "1"           # FT_QUICK=1: only the resident-timestep variants
+side_done = []
+
+
 def iteration(h2d):
     mark("start")
     tt = torch.randint(0, 6, (B,), generator=gen).to(dev) if h2d else tt_dev
     opt.zero_grad(set_to_none=True)
     terms = d_ddim.few_shot_style_finetune_losses(model, t2m, tt, content, style, skip_steps=700, model_kwargs=y1, model_t2m_kwargs=yB,
-                                                  semantic_guidance=1, use_ddim=1, Ls=10)
+                                                  semantic_guidance=1, use_ddim=1, Ls=10, overlap_backward=OVERLAP)
     mark("objective (forward) complete on the caller's stream")
     terms["loss"].backward()
     mark("backward")
+    side = _ns.ChainedCalls._side.get(dev.index if dev.index is not None else torch.cuda.current_device())
+    if collecting[0] and side is not None:                   # where the side stream's last work of the iteration (the chain's backward pass) ends
+        e = torch.cuda.Event(enable_timing=True); e.record(side); side_done.append(e)
     opt.step()
     mark("optimizer step")
     return terms["loss"]
 
 
-for h2d in (True, False, True, False):
+for h2d in ((False,) if QUICK else (True, False, True, False)):
     for _ in range(3):
         iteration(h2d)
     torch.cuda.synchronize()
@@ -88,10 +96,11 @@ for h2d in (True, False, True, False):
     t2 = time.perf_counter()
     print(f"timestep batch {'copied from the host every iteration' if h2d else 'resident on the device'}: {1e3 * (t2 - t0) / N:.2f} ms per iteration, "
           f"host enqueue {1e3 * (t1 - t0) / N:.2f} ms per iteration (host {1e3 * (t2 - t1):.1f} ms ahead at the end)")
-for h2d in (True, False):
+for h2d in ((False,) if QUICK else (True, False)):
     for _ in range(3):
         iteration(h2d)
     torch.cuda.synchronize()
+    side_done.clear()
     collecting[0] = True
     marks.clear()
     for _ in range(10):
@@ -122,6 +131,10 @@ for h2d in (True, False):
         print("  side stream blocks (ms): " + ", ".join(f"{d / n_it:.2f}" for d in dur) + f"   sum {sum(dur) / n_it:.2f}")
         print("  gaps in front of them (first: from the iteration's start): " + ", ".join(f"{g_ / n_it:.2f}" for g_ in gap))
         print(f"  iteration start -> last block's end: {sum(its[it][1].elapsed_time(ends[it * per + per - 1]) for it in range(n_it)) / n_it:.2f}")
+    if side_done:
+        print(f"  iteration start -> end of the side stream's work (chain backward): {sum(its[it][1].elapsed_time(side_done[it]) for it in range(n_it)) / n_it:.2f}")
+        bw = [e for k, e in marks if k == "backward"]
+        print(f"  iteration start -> end of the backward pass on the caller's stream: {sum(its[it][1].elapsed_time(bw[it]) for it in range(n_it)) / n_it:.2f}")
     chain_marks.clear()
     tot = marks[0][1].elapsed_time(marks[-1][1]) / 10
     print(f"  {'first start -> last optimizer step, per iteration':55s} {tot:7.2f}")
