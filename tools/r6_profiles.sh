@@ -19,7 +19,8 @@ step "bench batch 32"; timeout -k 10 300 python bench.py --batch 32 --steps 2 --
 step "bench, resident-group trunk (MST_TRUNK=1)"; MST_TRUNK=1 timeout -k 10 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-boundary > $O/bench_trunk.log 2>&1 || exit 1; tail -1 $O/bench_trunk.log > $O/r06_bench_resident_trunk.json; cut -c1-200 $O/r06_bench_resident_trunk.json
 step "finetune bench"; timeout -k 10 300 python bench.py --mode finetune --steps 50 --warmup 5 > $O/bench_ft.log 2>&1 || exit 1; tail -1 $O/bench_ft.log > $O/r06_finetune_bench_1gpu.json; cut -c1-300 $O/r06_finetune_bench_1gpu.json
 step "finetune bench, MST_CHAIN=0 MST_CHAIN_STREAM=0 (every model call differentiated alone, one stream)"; MST_CHAIN=0 MST_CHAIN_STREAM=0 timeout -k 10 300 python bench.py --mode finetune --steps 50 --warmup 5 > $O/bench_ft0.log 2>&1 || exit 1; tail -1 $O/bench_ft0.log > $O/r06_finetune_bench_1gpu_unchained.json; cut -c1-200 $O/r06_finetune_bench_1gpu_unchained.json
-step "finetune timeline, events, no synchronisation"; timeout -k 10 300 python tools/ft_events.py 2>&1 | grep -v "it/s" | tail -22 > $O/r06_finetune_events.txt; cat $O/r06_finetune_events.txt
+step "finetune timeline, events, no synchronisation (round 5's stream protocol, then overlap_backward: LAB_NOTES R6.10)"
+for v in 0 1; do echo "== overlap_backward=$v"; FT_QUICK=1 FT_OVERLAP=$v timeout -k 10 300 python tools/ft_events.py 2>&1 | grep -E "^timestep|^caller|^  " | grep -v "it/s\|return"; done > $O/r06_finetune_events.txt; cat $O/r06_finetune_events.txt
 step "finetune segments"; timeout -k 10 300 python tools/finetune_segments.py 2>&1 | tail -7 > $O/r06_finetune_segments.txt; cat $O/r06_finetune_segments.txt
 step "kernel stats, one slice"
 MST_STREAMS=1 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-boundary > $O/prof_bench.log 2>&1 || exit 1
@@ -43,5 +44,6 @@ step "phase stamps"; bash tools/phase_stamps.sh > /dev/null 2>&1; cp gpurun_out/
 step "host enqueue share"; timeout -k 10 300 python tools/host_bound.py 2>&1 | grep "^B=" > $O/r06_host_bound.txt; cat $O/r06_host_bound.txt
 step "latency batch 1"; timeout -k 10 300 python tools/latency_b1.py 2>&1 | grep "^F=" > $O/r06_latency_batch1.txt; cat $O/r06_latency_batch1.txt
 step "train stack"; timeout -k 10 300 python tools/train_bench.py > $O/train.log 2>&1; tail -1 $O/train.log > $O/r06_train_stack_bench.json; cut -c1-300 $O/r06_train_stack_bench.json
+step "train stack, frozen (input gradient only: the motion encoder's backward)"; TB_FROZEN=1 timeout -k 10 300 python tools/train_bench.py > $O/train_fr.log 2>&1; tail -1 $O/train_fr.log > $O/r06_train_stack_bench_frozen.json; cut -c1-300 $O/r06_train_stack_bench_frozen.json
 rm -rf $O/prof $O/prof_ft $O/pmcF $O/pmcW $O/pmcA $O/trace3
 ls $O
