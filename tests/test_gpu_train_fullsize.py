@@ -122,6 +122,66 @@ def test_layernorm_backward_in_the_dgrad_epilogue_equals_the_two_launches(monkey
     del two
 
 
+@pytest.mark.parametrize("rows", [64, 37])
+def test_frozen_stack_backward_fused_tail_vs_autograd(rows, monkeypatch):
+    """Round 6: the backward pass of a FROZEN stack at batch size (grads=None: what the motion encoder's backward is in every fine-tune
+    iteration) takes k_layer_tail_bwd<WG=false, LN2=true> (csrc/mst_tail_bwd.h): LayerNorm2 backward, FFN2 dgrad, GELU', FFN1 dgrad, LayerNorm1
+    backward and the out-proj dgrad of a layer in ONE launch.  dL/dh against fp32 autograd with the engine's own dropout masks, with and
+    without dropout, at 64 clips (197 full tiles) and at 37 clips (7289 rows: the last tile holds 57 of 64 tokens); bit-reproducible; and against
+    engines built with the pieces switched off one by one (read when the engine is created): LayerNorm2 in a launch of its own
+    (MST_TRAIN_FUSE_LN2_BWD=0), the three dgrad launches (MST_TRAIN_FUSE_BWD_TAIL=0), and the fused launch for the pass WITH parameter
+    gradients too (=2, k_layer_tail_bwd<WG=true>): all 96 gradient tensors of that one against autograd."""
+    from mst_amd.engine import DenoiserEngine
+    eng, w = big_engine()
+    h, r = stream(rows)
+
+    def variant(**env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = DenoiserEngine(FE, T, B, device=_dev())
+        for k in env:
+            monkeypatch.delenv(k)
+        e.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, layer_prefix="seqTransEncoder.layers.",
+                          pe=torch.from_numpy(syn.positional_table(5000, 512)))
+        return e
+
+    others = {"LayerNorm2 backward in its own launch": variant(MST_TRAIN_FUSE_LN2_BWD="0"),
+              "three dgrad launches": variant(MST_TRAIN_FUSE_BWD_TAIL="0"),
+              "fused with parameter gradients": variant(MST_TRAIN_FUSE_BWD_TAIL="2")}
+    for p in (0.0, 0.1):
+        seed = 991 + rows
+        params = layer_params(w, True)
+        href = h.clone().requires_grad_(True)
+        masks = engine_masks(eng, seed, p, rows, S) if p > 0 else None
+        ref = torch_stack(href, params, masks)
+        (ref * r).sum().backward()
+        del masks, ref
+        want = href.grad.cpu().numpy()
+        out, tape = eng.train_forward(h, p, seed)
+        d_frozen = eng.train_backward(tape, r, p, seed, None)
+        err = rel_l2(d_frozen.cpu().numpy(), want)
+        print(f"{rows} clips, dropout {p}: frozen backward (fused tail) vs autograd {err:.2e}")
+        assert err <= TOL_GRAD, (rows, p, err)
+        assert torch.equal(eng.train_backward(tape, r, p, seed, None), d_frozen), "not bit-reproducible"
+        for name, e in others.items():
+            out_v, tape_v = e.train_forward(h, p, seed)
+            assert torch.equal(out_v, out), name
+            d_v = e.train_backward(tape_v, r, p, seed, None)
+            ev, ed = rel_l2(d_v.cpu().numpy(), want), rel_l2(d_v.cpu().numpy(), d_frozen.cpu().numpy())
+            print(f"    {name}: vs autograd {ev:.2e}, vs the default {ed:.2e}")
+            assert ev <= TOL_GRAD and ed < 1.5e-3, (name, rows, p, ev, ed)
+        e = others["fused with parameter gradients"]
+        out_v, tape_v = e.train_forward(h, p, seed)
+        grads = [torch.zeros_like(q) for q in layer_params(w, False)]
+        d_v = e.train_backward(tape_v, r, p, seed, grads)
+        assert rel_l2(d_v.cpu().numpy(), want) <= TOL_GRAD
+        errs = {f"L{i // 12}.{LAYER_TENSORS[i % 12]}": rel_l2(g.cpu().numpy(), q.grad.cpu().numpy()) for i, (g, q) in enumerate(zip(grads, params))}
+        worst = max(errs, key=errs.get)
+        print(f"    fused with parameter gradients: worst of 96 tensors {worst} {errs[worst]:.2e}")
+        assert errs[worst] <= TOL_GRAD, (worst, errs[worst])
+    del others
+
+
 def test_finetune_objective_at_64_clips_is_finite_and_seeded():
     """One fine-tune iteration exactly as bench.py --mode finetune / train/training_loop.py:249-263 issue it: the 64-clip
     text-to-motion call, the 6 chained single-clip DDIM steps, the frozen motion encoder, backward, fused AdamW."""
