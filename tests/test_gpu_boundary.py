@@ -487,6 +487,68 @@ def test_chain_and_side_stream_switches_give_the_same_gradients(monkeypatch):
     model.zero_grad()
 
 
+def test_late_chain_join_through_a_gradient_reducer(monkeypatch):
+    """MST_CHAIN_JOIN_LATE=1 with a LayerBucketReducer installed (round 6; off by default): the chained calls' gradient sums are not added
+    on the caller's stream but handed to the reducer (GradSink.hand_over_chain), which adds each layer's share into its bucket on the
+    communication stream behind that layer's gradient event.  One process (world size 1: the adds and the stream protocol run, the
+    collective does not): the 96 bucket views must hold the bits of the default order."""
+    from mst_amd.finetune_dp import LayerBucketReducer
+    c = build()
+    model, dd = c["m"], c["ddim"]
+    x, t, y, mask, motion = inputs()
+    shp = (1, F, 1, T)
+    y1 = {"y": {"text": PROMPTS[:1], "mask": torch.ones(1, 1, 1, T, device=dev()), "inpainting_mask": mask[:1], "inpainted_motion": motion[:1]}}
+    t2m = cu(syn.normal(SEED, "xia/t2m", (2, F, 1, T)))
+    y_t2m = {"y": {"text": PROMPTS, "mask": torch.ones(2, 1, 1, T, device=dev()), "inpainting_mask": mask.double(), "inpainted_motion": t2m}}
+    style = cu(syn.normal(SEED, "xia/style", shp))
+    was = {n: p.requires_grad for n, p in model.named_parameters()}
+    for n, p_ in model.named_parameters():
+        p_.requires_grad_(n.startswith("seqTransEncoder.layers."))
+    model.zero_grad(set_to_none=True)
+    red = LayerBucketReducer(model)
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    assert len(names) == 96 and red.native
+    seen = []
+    orig = red._native_layer_ready
+
+    def spy(eng, after=None, chain=None):
+        seen.append(chain is not None)
+        return orig(eng, after, chain)
+    spy.adds_chain_sums = True
+    model.__dict__["_native_layer_ready"] = spy
+
+    def run():
+        red.zero_grad()
+        with recorded_noise("xia/ft1"):
+            terms = dd.few_shot_style_finetune_losses(model, t2m, torch.tensor([2, 4], device=dev()), motion[:1], style, skip_steps=700,
+                                                      model_kwargs=y1, model_t2m_kwargs=y_t2m, semantic_guidance=1, use_ddim=1, Ls=10)
+        terms["loss"].backward()
+        red.finish()
+        torch.cuda.synchronize()
+        assert red.launched_in == ["backward"] * 8
+        g = dict(model.named_parameters())
+        return float(terms["loss"]), [g[n].grad.clone() for n in names]
+
+    try:
+        la, ga = run()
+        assert seen == [False]
+        monkeypatch.setenv("MST_CHAIN_JOIN_LATE", "1")
+        lb, gb = run()
+        assert seen == [False, True], "the chain's sums were not handed to the reducer"
+        lc, gc = run()                     # a second iteration: the private accumulators are re-zeroed behind the reducer's adds
+        monkeypatch.delenv("MST_CHAIN_JOIN_LATE")
+        assert la == lb == lc
+        assert all(float(a.abs().max()) > 0 for a in ga)
+        for n, a, b_, c_ in zip(names, ga, gb, gc):
+            assert torch.equal(a, b_) and torch.equal(a, c_), n
+    finally:
+        for k in ("_native_layer_ready", "_native_grads_ready"):
+            model.__dict__.pop(k, None)
+        for n, p_ in model.named_parameters():
+            p_.requires_grad_(was[n])
+        model.zero_grad(set_to_none=True)
+
+
 @pytest.mark.parametrize("semantic", [0, 1])
 def test_two_objective_evaluations_in_one_backward_pass(semantic):
     """two evaluations of the objective summed into ONE backward pass = two chains of single-clip calls differentiated in the
