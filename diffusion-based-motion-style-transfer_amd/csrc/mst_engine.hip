@@ -1926,11 +1926,20 @@ static int wgrad(mst_engine* e, const f16* dY, int n_out, const f16* X, int k_in
     // ended -- 10.11 / 10.15 / 10.20 ms per iteration without, 10.15 / 10.18 / 10.22 ms with: the wgrad stream's tail is not short of CUs)
     int nsplit = (wg_target + tiles - 1) / tiles;
     const int slabs = (M + 31) / 32;
+    // round 6: splits a multiple of 8 and every split's tiles on ONE XCD (k_wgrad_tr's xcd_tiles): the slabs of dY and X a split walks are
+    // requested by 4 + 4 (W1 / W2) tiles, and those used to sit on all eight L2s.  Same-box A/Bs of the fine-tune line, three alternating rounds
+    // on two boxes: 9.76 / 9.86 / 10.04 -> 9.67 / 9.66 / 9.75 ms and 9.95 / 9.94 / 9.89 -> 9.82 / 9.89 / 9.84 ms (the launch itself 49.7 -> 47.8 us:
+    // most of the gain is the dgrad stream's, which shares the memory system with it).  A deeper slab ring (5 / 6 slabs: 120 / 144 KB of LDS)
+    // was measured with it and is slower -- the 72 KB ring leaves the CU's LDS to a dgrad workgroup.  MST_WGRAD_XCD=0: the 3-D grid of round 5.
+    static const int xcd_on = [] { const char* v = getenv("MST_WGRAD_XCD"); return v ? atoi(v) : 1; }();
+    bool xcd = xcd_on && M > SMALL_M && slabs >= 64;
+    if (xcd) nsplit = ((nsplit + 7) / 8) * 8;
     if (nsplit > slabs) nsplit = slabs;
     if ((size_t)nsplit > t.split_cap) nsplit = (int)t.split_cap;
     if (M <= SMALL_M) nsplit = 1;        // few tokens: one workgroup per tile adds its product straight into dW (no partials, no reduce launch)
     const int kchunk = ((slabs + nsplit - 1) / nsplit) * 32;
     nsplit = (M + kchunk - 1) / kchunk;
+    if (nsplit % 8) xcd = false;
     auto kern = k_wgrad_tr;
     CHECK(ensure_dyn_lds((const void*)kern, WgTile::SMEM));
     static_assert(DEpiF32::smem_bytes<128, 256>() <= WgTile::SMEM, "epilogue tile must fit the ring");
@@ -1943,7 +1952,7 @@ static int wgrad(mst_engine* e, const f16* dY, int n_out, const f16* X, int k_in
         DEpiF32 epi{dW, dW, k_in, n_out, t.gscale};
         {
             ProfScope ps(e, FAM_WGRAD, st);
-            hipLaunchKernelGGL(kern, dim3(n_out / 128, k_in / 256, 1), dim3(512), WgTile::SMEM, st, dY, n_out, X, k_in, M, kchunk, nelem, epi);
+            hipLaunchKernelGGL(kern, dim3(n_out / 128, k_in / 256, 1), dim3(512), WgTile::SMEM, st, dY, n_out, X, k_in, M, kchunk, nelem, epi, 0);
         }
         e->prof_now = prof_keep;
         HIPCHECK(hipGetLastError());
@@ -1951,7 +1960,8 @@ static int wgrad(mst_engine* e, const f16* dY, int n_out, const f16* X, int k_in
         DEpiF32 epi{nullptr, t.part, k_in, n_out};
         {
             ProfScope ps(e, FAM_WGRAD, st);
-            hipLaunchKernelGGL(kern, dim3(n_out / 128, k_in / 256, nsplit), dim3(512), WgTile::SMEM, st, dY, n_out, X, k_in, M, kchunk, nelem, epi);
+            if (xcd) hipLaunchKernelGGL(kern, dim3(tiles * nsplit), dim3(512), WgTile::SMEM, st, dY, n_out, X, k_in, M, kchunk, nelem, epi, tiles);
+            else hipLaunchKernelGGL(kern, dim3(n_out / 128, k_in / 256, nsplit), dim3(512), WgTile::SMEM, st, dY, n_out, X, k_in, M, kchunk, nelem, epi, 0);
         }
         e->prof_now = prof_keep;
         HIPCHECK(hipGetLastError());

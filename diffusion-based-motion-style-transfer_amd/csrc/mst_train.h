@@ -1186,19 +1186,34 @@ __global__ __launch_bounds__(512) void k_attention_bwd(const f16* __restrict__ q
 struct WgTile {
     static constexpr int BLK = 32 * 256;                 // one [32][128] f16 image
     static constexpr int STAGE = 3 * BLK;                // dY block + two X blocks
-    static constexpr int NSTAGE = 3;
+#ifndef MST_WG_NSTAGE
+#define MST_WG_NSTAGE 3
+#endif
+    static constexpr int NSTAGE = MST_WG_NSTAGE;         // slabs in the ring (NSTAGE - 1 in flight per workgroup: 24 KB each)
     static constexpr int SMEM = NSTAGE * STAGE;
     static constexpr int PER = 3;                        // 1-KiB pieces per wave per slab (24 / 8)
 };
 
 __global__ __launch_bounds__(512) void k_wgrad_tr(const f16* __restrict__ dY, int n_out, const f16* __restrict__ X, int k_in,
-                                                  int M, int kchunk, size_t out_stride, DEpiF32 epi) {
+                                                  int M, int kchunk, size_t out_stride, DEpiF32 epi, int xcd_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using TL = WgTile;
     constexpr int BT = 128, BF = 256, MT = 2, NT = 2;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r0 = blockIdx.x * BT, c0 = blockIdx.y * BF, z = blockIdx.z;
+    // xcd_tiles > 0 (a 1-D grid of tiles x splits workgroups, splits a multiple of 8): workgroup L runs on XCD L % 8 (round-robin dispatch),
+    // and all tiles of a split are given to ONE XCD -- split z lives on XCD z % 8 -- so that the 32-token slabs of dY and X a split walks
+    // are fetched into that XCD's L2 once and shared by its tiles (each slab is otherwise requested by n_out / 128 resp. k_in / 256
+    // workgroups scattered over all eight L2s)
+    int bx = blockIdx.x, by = blockIdx.y, z = blockIdx.z;
+    if (xcd_tiles > 0) {
+        const int L = blockIdx.x, xcd = L & 7, slot = L >> 3, gx = n_out / BT;
+        const int tile = slot % xcd_tiles;
+        z = xcd + 8 * (slot / xcd_tiles);
+        bx = tile % gx;
+        by = tile / gx;
+    }
+    const int r0 = bx * BT, c0 = by * BF;
     const int k0 = z * kchunk;
     int ntok = M - k0;
     if (ntok > kchunk) ntok = kchunk;
