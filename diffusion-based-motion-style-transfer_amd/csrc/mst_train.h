@@ -965,8 +965,9 @@ __device__ __forceinline__ void stage_image(char* img, const f16* src, size_t ro
 // Backward of one (clip, head):  with P = softmax(Q K^T * scale), Pd = dropout(P), O = Pd V:
 //   dV = Pd^T dO,  dPd = dO V^T,  dP = dPd * mask,  dS = P (dP - D) * scale with D_q = sum_d dO[q][d] O[q][d],
 //   dQ = dS K,  dK = dS^T Q.
-// Pass 1 (wave = 32-query tile, lane = query; K, V images in LDS): row statistics, dQ.
-// Pass 2 (wave = 32-key tile, lane = key; Q, dO images in LDS): dK, dV.  P is recomputed in both passes.
+// Pass 1 (wave = 32-query tile, lane = query; K, V images in LDS): dQ.
+// Pass 2 (wave = 32-key tile, lane = key; Q, dO images in LDS): dK, dV.  P is recomputed in both passes from the forward's row
+// statistics (lse_in, one float per query row in the tape).
 template <int NKT>
 __global__ __launch_bounds__(512) void k_attention_bwd(const f16* __restrict__ qkv, const f16* __restrict__ att,
                                                        const f16* __restrict__ datt, f16* __restrict__ dqkv, int S, Drop d,
@@ -1018,52 +1019,32 @@ __global__ __launch_bounds__(512) void k_attention_bwd(const f16* __restrict__ q
             }
         }
         D += __shfl_xor(D, 32);
-        f32x16 sc[NKT];
-#pragma unroll
-        for (int kt = 0; kt < NKT; kt++) {
-#pragma unroll
-            for (int r = 0; r < 16; r++) sc[kt][r] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 8; s++) sc[kt] = mfma_f16(img_row_frag(img0, kt * 32 + l31, s, hh), qf[s], sc[kt]);
-        }
-        float m = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < NKT; kt++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const float v = sc[kt][r] * scale + kbias[kt * 32 + mfma_row(r, lane)];
-                sc[kt][r] = v;
-                m = fmaxf(m, v);
-            }
-        m = fmaxf(m, __shfl_xor(m, 32));
-        float l = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < NKT; kt++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const float p = __expf(sc[kt][r] - m);
-                sc[kt][r] = p;
-                l += p;
-            }
-        l += __shfl_xor(l, 32);
-        const float inv_l = 1.0f / l;
+        // Row statistics: the forward pass left lse = max + log(sum) of every query row in the tape (k_attention_train), so P = exp(s - lse)
+        // directly -- no max / sum sweeps over the scores here and, above all, no need to hold all NKT score tiles at once (112 registers at
+        // 197 tokens: the kernel spilled 30 registers, 48 scratch instructions; now 8; round 6).  Padded queries: lse = inf -> P = 0.
+        // (Requesting the wave's own q / dO / O rows in front of the image staging was tried with it: 26 scratch instructions and +3 us.)
+        const float ls = q_idx < S ? lse_in[(size_t)ch * S + q_idx] : INFINITY;
         if (hh == 0) {
-            lse_s[q_idx] = q_idx < S ? m + __logf(l) : INFINITY;     // padded queries: P = exp(s - inf) = 0 in pass 2
+            lse_s[q_idx] = ls;
             dq_s[q_idx] = D;
         }
         f16x8 dsf[NKT][2];
 #pragma unroll
         for (int kt = 0; kt < NKT; kt++) {
-            f32x16 dp;
+            f32x16 sc, dp;
 #pragma unroll
-            for (int r = 0; r < 16; r++) dp[r] = 0.f;
+            for (int r = 0; r < 16; r++) { sc[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-            for (int s = 0; s < 8; s++) dp = mfma_f16(img_row_frag(img1, kt * 32 + l31, s, hh), dof[s], dp);
+            for (int s = 0; s < 8; s++) {
+                sc = mfma_f16(img_row_frag(img0, kt * 32 + l31, s, hh), qf[s], sc);
+                dp = mfma_f16(img_row_frag(img1, kt * 32 + l31, s, hh), dof[s], dp);
+            }
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int key = kt * 32 + mfma_row(r, lane);
+                const float p = __expf(sc[r] * scale + kbias[key] - ls);
                 const float mul = drop_mul(d, p_index(ch, S, q_idx, key));
-                dsf[kt][r >> 3][r & 7] = (f16)(sc[kt][r] * inv_l * (dp[r] * mul - D) * scale);
+                dsf[kt][r >> 3][r & 7] = (f16)(p * (dp[r] * mul - D) * scale);
             }
         }
 #pragma unroll
