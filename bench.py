@@ -464,6 +464,18 @@ def finetune_roofline(B, world, s_per_iter, wgrad=None):
             "event_pair_overhead_us_subtracted": round(wgrad["event_pair_overhead_us"], 2),
             "algorithmic_gflop_per_iteration": round(wgrad_flops(B) * 1e-9, 1), "achieved_tflops": round(tflops, 1),
             "frac_of_mfma_peak": round(tflops / MFMA_PEAK_TFLOPS, 4)}
+        # HBM bytes of the batch-size launches of that kernel by PMC (tools/r6_train_pmc.sh: FETCH_SIZE x 2 + WRITE_SIZE, separate passes
+        # over one stack forward + backward at 64 clips on one stream) -- quoted only from a file measured on THIS library build
+        try:
+            from mst_amd import _native
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r06_train_pmc_traffic.json")))
+            if pm.get("source_hash") == _native.built_hash() and B == pm.get("clips"):
+                k = pm["kernels"]["k_wgrad_tr"]
+                out["traffic"] = int(k["hbm_bytes"])
+                out["traffic_source"] = ("profiles/r06_train_pmc_traffic.json: k_wgrad_tr at 64 clips, mean of the four weight-gradient shapes of a layer "
+                                         f"({k['launches']} launches), same library build {pm['source_hash']}; every training kernel is in that file")
+        except (OSError, KeyError, ValueError):
+            pass
     # A committed rocprofv3 summary of the same command from an earlier run (possibly another build), with the file's hash: the share of
     # device time that names the dominant kernel comes from there.
     for name in ("r06_finetune_kernel_stats_streams1.csv", "r05_finetune_kernel_stats_streams1.csv", "r04_finetune_kernel_stats_streams1.csv"):
