@@ -17,6 +17,8 @@ step "bench cfg";      timeout -k 10 300 python bench.py --cfg --steps 2 --warmu
 step "bench batch 128"; timeout -k 10 300 python bench.py --batch 128 --steps 2 --warmup 1 --no-cpu-baseline --no-boundary > $O/bench_b128.log 2>&1 || exit 1; tail -1 $O/bench_b128.log > $O/r06_bench_batch128.json; cut -c1-200 $O/r06_bench_batch128.json
 step "bench batch 32"; timeout -k 10 300 python bench.py --batch 32 --steps 2 --warmup 1 --no-cpu-baseline --no-boundary > $O/bench_b32.log 2>&1 || exit 1; tail -1 $O/bench_b32.log > $O/r06_bench_batch32.json; cut -c1-200 $O/r06_bench_batch32.json
 step "bench, resident-group trunk (MST_TRUNK=1)"; MST_TRUNK=1 timeout -k 10 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-boundary > $O/bench_trunk.log 2>&1 || exit 1; tail -1 $O/bench_trunk.log > $O/r06_bench_resident_trunk.json; cut -c1-200 $O/r06_bench_resident_trunk.json
+step "pmc traffic of the training kernels (bench.py --mode finetune quotes roofline.traffic from it for this build)"
+bash tools/r6_train_pmc.sh > $O/train_pmc.log 2>&1 && cp gpurun_out/r06_train_pmc_traffic.json $O/ && cp gpurun_out/r06_train_pmc_traffic.json profiles/ && cp gpurun_out/r6_train_pmc.txt $O/r06_train_kernels_hbm_traffic.txt; head -5 $O/r06_train_kernels_hbm_traffic.txt | cut -c1-120
 step "finetune bench"; timeout -k 10 300 python bench.py --mode finetune --steps 50 --warmup 5 > $O/bench_ft.log 2>&1 || exit 1; tail -1 $O/bench_ft.log > $O/r06_finetune_bench_1gpu.json; cut -c1-300 $O/r06_finetune_bench_1gpu.json
 step "finetune bench, MST_CHAIN=0 MST_CHAIN_STREAM=0 (every model call differentiated alone, one stream)"; MST_CHAIN=0 MST_CHAIN_STREAM=0 timeout -k 10 300 python bench.py --mode finetune --steps 50 --warmup 5 > $O/bench_ft0.log 2>&1 || exit 1; tail -1 $O/bench_ft0.log > $O/r06_finetune_bench_1gpu_unchained.json; cut -c1-200 $O/r06_finetune_bench_1gpu_unchained.json
 step "finetune timeline, events, no synchronisation (round 5's stream protocol, then overlap_backward: LAB_NOTES R6.10)"
