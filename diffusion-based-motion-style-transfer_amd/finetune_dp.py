@@ -114,6 +114,8 @@ class LayerBucketReducer:
             done = torch.cuda.Event()
             done.record(self.comm)
             chain["release"](done)
+    # (capability flag read by native_stack._node_done: this callback accepts the `chain` argument and adds those sums itself; a callback
+    # without it -- another reducer written against round 5's two-argument protocol -- gets the sums joined on the caller's stream first)
     _native_layer_ready.adds_chain_sums = True
 
     def _native_grads_ready(self):
