@@ -43,6 +43,7 @@ SIGNATURES = {
     "mst_schedule_create": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
     "mst_schedule_destroy": (None, [C.c_void_p]),
     "mst_set_text": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "mst_set_text_dropped": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "mst_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                               C.c_void_p, C.c_void_p]),
     "mst_sample_loop": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(MstLoopArgs), C.c_void_p]),

@@ -396,3 +396,19 @@ __device__ __forceinline__ StepArgs step_resolve(StepArgs sa) {
     sa.scale = sa.scale ? d.scale + sa.clip0 : nullptr;
     return sa;
 }
+
+namespace mst {
+// ------------------------------------------------------------------------------------------------------------
+// Dropout: a counter-based keep mask, regenerated (never stored) by the backward kernels.
+// Element idx of a site is kept iff mix32(idx * phi + key) >= thr; kept values are multiplied by inv = 1/(1-p).
+// thr = 0 keeps everything (eval / p = 0).  `key` mixes the call's seed, the layer and the site on the host.
+// ------------------------------------------------------------------------------------------------------------
+struct Drop { uint32_t key, thr; float inv; };
+__host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float drop_mul(const Drop& d, uint32_t idx) {
+    return mix32(idx * 0x9E3779B9u + d.key) >= d.thr ? d.inv : 0.f;
+}
+}  // namespace mst

@@ -99,13 +99,13 @@ __global__ __launch_bounds__(256) void k_rowwise_linear(const float* __restrict_
                                                         const long long* __restrict__ gather,
                                                         const float* __restrict__ rowscale, int rows_zero_from,
                                                         const float* __restrict__ W, const float* __restrict__ b,
-                                                        int K, int N, int act, float* __restrict__ out, int in_row_mod) {
+                                                        int K, int N, int act, float* __restrict__ out, int in_row_mod, int rowscale_is_drop = 0) {
     const int row = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int src_row = in_row_mod > 0 ? row % in_row_mod : row;
     const float* x = in + (size_t)(gather ? gather[src_row] : src_row) * ldin;
     float rs = 1.0f;
-    if (rowscale) rs = rowscale[src_row];
+    if (rowscale) rs = rowscale_is_drop ? 1.0f - rowscale[src_row] : rowscale[src_row];       // (a Bernoulli DROP mask: cond * (1 - mask), mdm :288-296)
     if (row >= rows_zero_from) rs = 0.0f;
     for (int n = blockIdx.y * 4 + wave; n < N; n += gridDim.y * 4) {
         const float* w = W + (size_t)n * K;

@@ -196,6 +196,12 @@ struct mst_engine {
     f16* xt_lo = nullptr;     // lo half of the frame rows: the pose embedding multiplies x_t as hi + lo (RowsDirect::Xlo)
     float *temb_hid = nullptr, *temb = nullptr, *textproj = nullptr;
     int temb_cap = 0;
+    // round 6: the timestep embedding of EVERY timestep (pe_len rows), built once per load of the (frozen) timestep MLP: a training call reads its
+    // clips' rows through their timestep indices inside the embedding kernel instead of running the two-layer MLP on them first -- two dependent
+    // launches less at the head of every model call, six of the seven per fine-tune iteration on the chained steps' critical path.  MST_TEMB_TABLE=0: off.
+    float *temb_table = nullptr, *temb_table_hid = nullptr;
+    bool temb_table_valid = false;
+    int temb_table_on = 1;
     std::vector<std::string> loaded;
     std::set<std::string> lo_missing;     // GEMM weights uploaded while precise mode was off: their lo halves f16(w - f16(w)) were not written
                                           // (a fine-tune iteration re-uploads all 96 tensors and never reads them); precise mode refuses to run on those
@@ -400,6 +406,7 @@ extern "C" int mst_engine_create(const mst_config* c, mst_engine** out) {
     if (const char* v = getenv("MST_TRAIN_SMALL_LN")) e->train_small_ln = atoi(v) != 0;
     if (const char* v = getenv("MST_TRAIN_FUSE_BWD_TAIL")) e->train_fuse_bwd_tail = atoi(v);
     if (const char* v = getenv("MST_TRAIN_FUSE_LN2_BWD")) e->train_fuse_ln2_bwd = atoi(v);
+    if (const char* v = getenv("MST_TEMB_TABLE")) e->temb_table_on = atoi(v);
     if (const char* v = getenv("MST_SMALL_LN")) e->small_ln = atoi(v) != 0;
     if (const char* v = getenv("MST_SMALL_LN_M")) e->small_ln_m = atoi(v);
     if (const char* v = getenv("MST_TAIL_NTB")) { int n = atoi(v); e->tail_ntb = (n >= 2 && n <= 4) ? n : 0; }
@@ -443,7 +450,7 @@ extern "C" void mst_engine_destroy(mst_engine* e) {
         for (void* q : p) (void)hipFree(q);
     }
     void* p[] = {e->w_pose_in_pk, e->w_pose_out_pk, e->w_pose_in_lo, e->w_pose_out_lo, e->w_pose_in, e->b_pose_in, e->w_pose_out, e->b_pose_out, e->w_pose_inT, e->w_pose_outT, e->w_t0, e->b_t0, e->w_t2, e->b_t2,
-                 e->w_text, e->b_text, e->pe, e->hl, e->hx, e->hx2, e->hl2, e->qkv, e->att, e->hid, e->xt, e->xt_lo, e->gelu_tab, e->temb_hid, e->temb, e->textproj, e->zacc};
+                 e->w_text, e->b_text, e->pe, e->hl, e->hx, e->hx2, e->hl2, e->qkv, e->att, e->hid, e->xt, e->xt_lo, e->gelu_tab, e->temb_hid, e->temb, e->textproj, e->zacc, e->temb_table, e->temb_table_hid};
     for (void* q : p) (void)hipFree(q);
     for (int i = 0; i < mst_engine::MAX_SLICES - 1; i++) {
         if (e->aux_stream[i]) (void)hipStreamDestroy(e->aux_stream[i]);
@@ -551,9 +558,11 @@ extern "C" int mst_load_weight(mst_engine* e, const char* name, const float* src
     } else if (n == "embed_timestep.time_embed.0.weight" || n == "embed_timestep.time_embed.2.weight") {
         if (!shape_is(shape, ndim, MST_D, MST_D)) return fail("mst_load_weight: %s: bad shape", name);
         rc = put_vector(src, MST_D * MST_D, n[26] == '0' ? e->w_t0 : e->w_t2, MST_D * MST_D, st);
+        e->temb_table_valid = false;
     } else if (n == "embed_timestep.time_embed.0.bias" || n == "embed_timestep.time_embed.2.bias") {
         if (!shape_is(shape, ndim, MST_D)) return fail("mst_load_weight: %s: bad shape", name);
         rc = put_vector(src, MST_D, n[26] == '0' ? e->b_t0 : e->b_t2, MST_D, st);
+        e->temb_table_valid = false;
     } else if (n == "embed_text.weight") {
         if (!shape_is(shape, ndim, MST_D, C)) return fail("mst_load_weight: %s: bad shape", name);
         rc = put_vector(src, MST_D * C, e->w_text, MST_D * C, st);
@@ -565,6 +574,7 @@ extern "C" int mst_load_weight(mst_engine* e, const char* name, const float* src
         int64_t cols = ndim == 3 ? shape[1] * shape[2] : (ndim == 2 ? shape[1] : -1);
         if (cols != MST_D || rows < e->cfg.pe_len) return fail("mst_load_weight: %s: bad shape", name);
         rc = put_vector(src, e->cfg.pe_len * MST_D, e->pe, e->cfg.pe_len * MST_D, st);
+        e->temb_table_valid = false;
     }
     if (rc == -1) return fail("mst_load_weight: unknown tensor name '%s'", name);
     if (rc) return rc;
@@ -830,12 +840,26 @@ static int launch_attn(const f16* qkv, f16* out, int S, int rows, hipStream_t st
 
 static int rowwise_linear(const float* in, int ldin, const long long* gather, const float* rowscale, int rows_zero_from,
                           const float* W, const float* b, int K, int N, int act, float* out, int in_row_mod, int rows,
-                          hipStream_t st) {
+                          hipStream_t st, int rowscale_is_drop = 0) {
     // a wave per output where the rows are few (64 rows x 128 = 8 K blocks; the hoisted timestep rows of a 1000-step loop keep 16 per row)
     const int gy = rows <= 64 ? (N + 3) / 4 : 16;
     hipLaunchKernelGGL(k_rowwise_linear, dim3(rows, gy), dim3(256), 0, st, in, ldin, gather, rowscale, rows_zero_from, W, b,
-                       K, N, act, out, in_row_mod);
+                       K, N, act, out, in_row_mod, rowscale_is_drop);
     HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+// the timestep embedding of every timestep there is (rows of the positional table), once per load of the timestep MLP
+static int ensure_temb_table(mst_engine* e, hipStream_t st) {
+    if (e->temb_table_valid) return 0;
+    const int rows = e->cfg.pe_len;
+    if (!e->temb_table) {
+        CHECK(dmalloc(&e->temb_table, (size_t)rows * MST_D));
+        CHECK(dmalloc(&e->temb_table_hid, (size_t)rows * MST_D));
+    }
+    CHECK(rowwise_linear(e->pe, MST_D, nullptr, nullptr, rows, e->w_t0, e->b_t0, MST_D, MST_D, 1, e->temb_table_hid, 0, rows, st));
+    CHECK(rowwise_linear(e->temb_table_hid, MST_D, nullptr, nullptr, rows, e->w_t2, e->b_t2, MST_D, MST_D, 0, e->temb_table, 0, rows, st));
+    e->temb_table_valid = true;
     return 0;
 }
 
@@ -857,6 +881,17 @@ extern "C" int mst_set_text(mst_engine* e, const float* text_emb, const float* k
                          MST_D, 0, e->textproj, batch, rows, st));
     e->text_batch = batch;
     e->text_cfg = cfg ? 1 : 0;
+    return 0;
+}
+
+extern "C" int mst_set_text_dropped(mst_engine* e, const float* text_emb, const float* drop, int32_t batch, void* stream) {
+    if (!e || !text_emb || !drop) return fail("mst_set_text_dropped: null argument");
+    if (batch < 1 || batch > e->cfg.max_rows) return fail("mst_set_text_dropped: %d rows exceed max_rows %d", batch, e->cfg.max_rows);
+    hipStream_t st = (hipStream_t)stream;
+    ON_DEVICE(e->cfg.device);
+    CHECK(rowwise_linear(text_emb, e->cfg.clip_dim, nullptr, drop, batch, e->w_text, e->b_text, e->cfg.clip_dim, MST_D, 0, e->textproj, batch, batch, st, 1));
+    e->text_batch = batch;
+    e->text_cfg = 0;
     return 0;
 }
 
@@ -1040,17 +1075,19 @@ static int launch_embed_in(mst_engine* e, const WS& ws, int tot, const DEpiEmbed
 
 // the pose embedding's epilogue of a model call / loop step: positional rows, stream rows, conditioning tokens
 static DEpiEmbedIn embed_in_epi(const mst_engine* e, const WS& ws, int clips_x, int rows, int T, int temb_uniform_row, int temb_mod, int tp_uncond,
-                                const LoopDev* ld, int joff) {
+                                const LoopDev* ld, int joff, const long long* tidx_table = nullptr, const Drop* pe_dropout = nullptr) {
     const int S = T + 1, tot = clips_x * T;
     DEpiEmbedIn epi{e->b_pose_in, e->pe, ws.hx, ws.hl, T, S, tot, rows > clips_x ? (size_t)clips_x * S * MST_D : 0};
     epi.ct.temb = e->temb; epi.ct.textproj = ws.textproj; epi.ct.ld = ld;
     epi.ct.uniform_row = temb_uniform_row; epi.ct.temb_mod = temb_mod; epi.ct.joff = joff; epi.ct.rows = rows;
     epi.ct.tp_half = rows > clips_x ? clips_x : 0; epi.ct.tp_uncond = rows > clips_x ? tp_uncond : 0;
+    if (tidx_table) { epi.ct.temb = e->temb_table; epi.ct.tidx = tidx_table; }
+    if (pe_dropout) epi.pd = *pe_dropout;
     return epi;
 }
 
 static int assemble_stream(mst_engine* e, const WS& ws, const float* x, int clips_x, int rows, int T, int temb_uniform_row, int temb_mod,
-                           hipStream_t st, int tp_uncond, LoopRef lr = LoopRef()) {
+                           hipStream_t st, int tp_uncond, LoopRef lr = LoopRef(), const long long* tidx_table = nullptr, const Drop* pe_dropout = nullptr) {
     if (lr.stream_ready) return 0;
     const int S = T + 1;
     (void)S;
@@ -1065,7 +1102,7 @@ static int assemble_stream(mst_engine* e, const WS& ws, const float* x, int clip
             hipLaunchKernelGGL(k_frames_f16, dim3((T + 31) / 32, e->kin_pad / 32, clips_x), dim3(256), 0, st, x, F, T, e->kin_pad, ws.xt, (const float*)nullptr, lr.ld, lr.eo, ws.xt_lo);
             HIPCHECK(hipGetLastError());
         }
-        const DEpiEmbedIn epi = embed_in_epi(e, ws, clips_x, rows, T, temb_uniform_row, temb_mod, tp_uncond, lr.ld, lr.joff);
+        const DEpiEmbedIn epi = embed_in_epi(e, ws, clips_x, rows, T, temb_uniform_row, temb_mod, tp_uncond, lr.ld, lr.joff, tidx_table, pe_dropout);
         if (e->embed_fast && !e->precise) return launch_embed_in(e, ws, tot, epi, st);
         // x_t as hi + lo (RowsDirect::Xlo): both halves of a k-slab beside ONE copy of the weight slab
         CHECK((launch_gemm_dma<64, 512, 2, 2, 4, 1, 32, 2>(dim3((tot + 63) / 64, 1), RowsDirect{ws.xt, e->kin_pad, ws.xt_lo, e->precise ? e->w_pose_in_lo : nullptr},
@@ -2199,12 +2236,18 @@ extern "C" int mst_train_model_forward(mst_engine* e, const float* x, const int6
     tape_shift(t, nl, (size_t)clip0 * S);
     e->prof_now = 0;
     CHECK(ensure_packed(e, st, false));
-    CHECK(timestep_rows(e, (const long long*)t_idx, batch, st));
+    const bool table = e->temb_table_on != 0;
+    if (table) CHECK(ensure_temb_table(e, st));
+    else CHECK(timestep_rows(e, (const long long*)t_idx, batch, st));
     WS ws = ws_slice(e, 0, frames);
     ws.hx = t.sh[0];                                      // the token stream is assembled straight into tape slot 0
     ws.hl = t.sl[0];
-    CHECK(assemble_stream(e, ws, x, batch, batch, frames, -1, batch, st, batch));
-    if (p_pe > 0.f) {
+    // round 6: PositionalEncoding's dropout rides in the embedding kernel's epilogue (MST_TRAIN_FUSE_PE_DROP=0: k_dropout_stream behind it)
+    static const int fuse_pe = [] { const char* v = getenv("MST_TRAIN_FUSE_PE_DROP"); return v ? atoi(v) : 1; }();
+    const Drop ped = pe_drop(seed, p_pe, (uint32_t)clip0 * S * MST_D);
+    CHECK(assemble_stream(e, ws, x, batch, batch, frames, -1, batch, st, batch, LoopRef(), table ? (const long long*)t_idx : nullptr,
+                          (fuse_pe && p_pe > 0.f) ? &ped : nullptr));
+    if (p_pe > 0.f && !fuse_pe) {
         hipLaunchKernelGGL(k_dropout_stream, dim3(1024), dim3(256), 0, st, t.sh[0], t.sl[0], (size_t)M * MST_D,
                            pe_drop(seed, p_pe, (uint32_t)clip0 * S * MST_D));
         HIPCHECK(hipGetLastError());

@@ -471,11 +471,14 @@ struct DEpiResidLN {
 struct CondTok {
     const float* temb = nullptr; const float* textproj = nullptr; const LoopDev* ld = nullptr;
     int uniform_row = 0, temb_mod = 1, tp_half = 0, tp_uncond = 0, joff = 0, rows = 0;
+    const long long* tidx = nullptr;          // non-null (training calls, round 6): `temb` is the TABLE over every timestep, clip's row = tidx[clip % temb_mod]
 };
 struct DEpiEmbedIn {
     const float* bias; const float* pe; f16* hi; f16* lo; int T, S, total; size_t dup;
     int tok_off = 1;                          // frame t becomes token tok_off + t (positional row included)
     CondTok ct;                               // ct.temb != null: also write the conditioning tokens (tok_off == 1 callers)
+    Drop pd = {0u, 0u, 1.0f};                 // pd.thr != 0 (training calls, round 6): PositionalEncoding's dropout on the assembled stream, element index =
+                                              // offset in `hi` -- what k_dropout_stream did in a launch of its own behind this kernel
     __device__ __forceinline__ int rows() const { return total; }
     template <int BT, int BF> static constexpr int smem_bytes() { return BT * (MST_D * 4 + 16); }
     template <int BT, int BF, int MT, int NT>
@@ -529,6 +532,13 @@ struct DEpiEmbedIn {
                 xb[i] = xb[i] + bb[i] + pb[r][i];
             }
             size_t off = ((size_t)clip * S + tok_off + t) * MST_D;
+            if (pd.thr) {                                      // kernel-uniform
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    xa[i] *= drop_mul(pd, (uint32_t)(off + fa + i));
+                    xb[i] *= drop_mul(pd, (uint32_t)(off + fb + i));
+                }
+            }
             uint2 ha, la, hb, lb;
             split4_f16(xa, ha, la);
             split4_f16(xb, hb, lb);
@@ -551,10 +561,11 @@ struct DEpiEmbedIn {
             const int lim = tok0 + BT < total ? tok0 + BT : total;
             for (int c = (tok0 + T - 1) / T; c * T < lim; c++)
                 for (int clip = c; clip < ct.rows; clip += x_clips) {                // the clip and, under CFG, its uncond twin
-                    const int tr = uniform_row >= 0 ? uniform_row : clip % ct.temb_mod;
+                    const int tr = ct.tidx ? (int)ct.tidx[clip % ct.temb_mod] : (uniform_row >= 0 ? uniform_row : clip % ct.temb_mod);
                     const int tp = (ct.tp_half > 0 && clip >= ct.tp_half) ? clip - ct.tp_half + ct.tp_uncond : clip;
-                    const float v = ct.temb[(size_t)tr * MST_D + f] + ct.textproj[(size_t)tp * MST_D + f] + pe[f];
+                    float v = ct.temb[(size_t)tr * MST_D + f] + ct.textproj[(size_t)tp * MST_D + f] + pe[f];
                     const size_t o = (size_t)clip * S * MST_D + f;
+                    if (pd.thr) v *= drop_mul(pd, (uint32_t)o);
                     const f16 h = (f16)v;
                     hi[o] = h;
                     lo[o] = (f16)(v - (float)h);

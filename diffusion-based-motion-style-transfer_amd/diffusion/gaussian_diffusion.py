@@ -447,6 +447,20 @@ class GaussianDiffusion:
                 yield out
                 img = out["sample"]
 
+    def _const_timesteps(self, i, n, device):
+        """th.full((n,), i) of the reference's loops (gaussian_diffusion.py:775 / :1063) as a cached read-only tensor: one fill less per chained
+        step, and `_WrappedModel` recognises it (`_mst_const`) and serves the respaced timesteps from a cache as well (no index launch)."""
+        import os
+        if os.environ.get("MST_GLUE_CACHE", "1") == "0":      # A/B: a fresh fill per step, no cached respacing
+            return th.full((n,), int(i), device=device, dtype=th.long)
+        cache = self.__dict__.setdefault("_t_const", {})
+        key = (int(i), int(n), th.device(device))
+        t = cache.get(key)
+        if t is None:
+            t = cache[key] = th.full((n,), int(i), device=device, dtype=th.long)
+            t._mst_const = int(i)
+        return t
+
     def _grad_steps(self, ddim, model, img, indices, shape, device, progress, clip_denoised, model_kwargs, eta, const_noise,
                     pred_xstart_in_graph, chain):
         """The *_with_grad loop (reference gaussian_diffusion.py:775-794 with cond_fn_with_grad): every step's x0-hat stays in the graph."""
@@ -455,7 +469,7 @@ class GaussianDiffusion:
             indices = tqdm(indices)
         for i in indices:
             with chain:
-                t = th.full((shape[0],), int(i), device=device, dtype=th.long)
+                t = self._const_timesteps(int(i), shape[0], device)
                 with th.no_grad():
                     out = (self.ddim_sample_with_grad(model, img, t, clip_denoised=clip_denoised, model_kwargs=model_kwargs, eta=eta,
                                                       pred_xstart_in_graph=pred_xstart_in_graph) if ddim else

@@ -85,7 +85,13 @@ class _WrappedModel:
         key = (ts.device, ts.dtype)
         if key not in self._maps:        # one upload per device instead of one per step
             self._maps[key] = th.tensor(self.timestep_map, device=ts.device, dtype=ts.dtype)
-        new_ts = self._maps[key][ts]
-        if self.rescale_timesteps:
-            new_ts = new_ts.float() * (1000.0 / self.original_num_steps)
+        const = getattr(ts, "_mst_const", None)           # a cached constant batch of the *_with_grad loops (GaussianDiffusion._const_timesteps)
+        ckey = (key, const, ts.shape[0]) if const is not None else None
+        new_ts = self._maps.get(ckey) if ckey is not None else None
+        if new_ts is None:
+            new_ts = self._maps[key][ts]
+            if self.rescale_timesteps:
+                new_ts = new_ts.float() * (1000.0 / self.original_num_steps)
+            if ckey is not None:
+                self._maps[ckey] = new_ts
         return self.model(x, new_ts, **kwargs)

@@ -224,8 +224,15 @@ class DenoiserEngine:
                 "recommend_precise": bool(why), "why": "; ".join(why)}
 
     # ------------------------------------------------------------------------------ conditioning
-    def set_text(self, text_emb, keep=None, cfg=False):
+    def set_text(self, text_emb, keep=None, cfg=False, drop=None):
+        """drop: the Bernoulli mask of the training-mode mask_cond as drawn (1 = dropped): cond * (1 - drop) inside the projection launch."""
         te = _f32c(text_emb, self.device, "text_emb")
+        if drop is not None:
+            assert keep is None and not cfg
+            dr = _f32c(drop.reshape(-1), self.device, "drop")
+            N.check(N.lib().mst_set_text_dropped(self.handle, N.ptr(te), N.ptr(dr), te.shape[0], N.stream_ptr(self.device)))
+            self._text_keepalive = (te, dr)
+            return
         kp = None if keep is None else _f32c(keep, self.device, "keep")
         N.check(N.lib().mst_set_text(self.handle, N.ptr(te), N.ptr(kp), te.shape[0], int(bool(cfg)),
                                      N.stream_ptr(self.device)))

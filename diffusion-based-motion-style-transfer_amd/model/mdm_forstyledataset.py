@@ -95,13 +95,32 @@ class OutputProcess(nn.Module):
         return output.reshape(nframes, bs, self.njoints, self.nfeats).permute(1, 2, 3, 0)
 
 
+from os import environ as _environ
+_os_environ_get = _environ.get
+
+
+def _cond_drop(module, cond):
+    """The Bernoulli drop mask of mask_cond, float32 [bs] (1 = drop the clip's text): the probability vector is a cached constant."""
+    key = (cond.shape[0], cond.device, float(module.cond_mask_prob))
+    ent = module.__dict__.get("_mst_mask_p")
+    if ent is None or ent[0] != key:
+        ent = module.__dict__["_mst_mask_p"] = (key, torch.full((cond.shape[0],), float(module.cond_mask_prob), device=cond.device))
+    return torch.bernoulli(ent[1])
+
+
 def _mask_cond(module, cond, force_mask=False):
     """mask_cond of the reference (:288-296 / :592-600)."""
     if force_mask:
         return torch.zeros_like(cond)
-    if module.training and module.cond_mask_prob > 0.:
+    if module.training and module.cond_mask_prob > 0. and _os_environ_get("MST_GLUE_CACHE", "1") == "0":      # the reference's five launches (A/B)
         drop = torch.bernoulli(torch.ones(cond.shape[0], device=cond.device) * module.cond_mask_prob).view(-1, 1)
         return cond * (1. - drop)
+    if module.training and module.cond_mask_prob > 0.:
+        # the reference: bernoulli(ones(bs) * p).view(-1, 1); cond * (1 - mask).  Same draw from the same generator state, two launches
+        # instead of five: the probability vector is a cached constant, and cond - cond * mask is one fused multiply-add (mask is 0 or 1:
+        # the same values).  Seven model calls per fine-tune iteration, six of them on the chained steps' critical path (LAB_NOTES R6.17).
+        drop = _cond_drop(module, cond).view(-1, 1)
+        return torch.addcmul(cond, cond, drop.to(cond.dtype), value=-1.0)
     return cond
 
 
@@ -207,7 +226,13 @@ class _EngineHost:
         from .native_stack import DenoiserTrainFn, stack_parameters
         prior = self._prior()
         enc = y['text_embed'] if y.get('text_embed') is not None else prior.encode_text(y['text'])
-        enc = self.mask_cond(enc, force_mask=y.get('uncond', False))
+        force = y.get('uncond', False)
+        if not force and self.training and self.cond_mask_prob > 0. and _os_environ_get("MST_GLUE_CACHE", "1") != "0":
+            # mask_cond (:592-600) with the mask handed to the engine as drawn: cond * (1 - drop) happens inside the text projection's launch
+            # (mst_set_text_dropped).  Same draw from the same generator state as `bernoulli(ones(bs) * p)`.
+            self.__dict__["_mst_cond_drop"] = _cond_drop(self, enc)
+        else:
+            enc = self.mask_cond(enc, force_mask=force)
         stack, pe = self.seqTransEncoder, prior.sequence_pos_encoder
         p = stack.layers[0].dropout.p if stack.training else 0.0
         p_pe = pe.dropout.p if pe.training else 0.0

@@ -411,6 +411,7 @@ class DenoiserTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, host, p_drop, p_pe, timesteps, text_emb, *params):
         B, F, one, T = x.shape
+        cond_drop = host.__dict__.pop("_mst_cond_drop", None)      # mask_cond's Bernoulli mask, applied inside the projection (_native_train_call)
         block = ChainedCalls.current
         chain = block if _CHAIN_ON() else None
         if chain is not None and not (B == 1 and not ctx.needs_input_grad[0] and any(ctx.needs_input_grad[6:])):
@@ -422,7 +423,7 @@ class DenoiserTrainFn(torch.autograd.Function):
             eng = host.mst_engine(max(B, chain.n), T, slot="chain" if chain.side is not None else None)
             key = (id(eng), B, F, T, float(p_drop), float(p_pe))
             if chain.accepts(key):
-                eng.set_text(text_emb.detach())
+                eng.set_text(text_emb.detach(), drop=cond_drop)
                 ctx.eng = eng
                 if chain.k == 0:
                     chain.key, chain.seed, chain.tape = key, seed, eng.train_tape(chain.n, T + 1, zero=True)
@@ -435,7 +436,7 @@ class DenoiserTrainFn(torch.autograd.Function):
         # a call of its own: the module's one engine, on the caller's stream (inside a side-stream block too: foreign_call)
         with (block.foreign_call(x, timesteps, text_emb) if block is not None else contextlib.nullcontext()):
             eng = host.mst_engine(B, T)
-            eng.set_text(text_emb.detach())
+            eng.set_text(text_emb.detach(), drop=cond_drop)
             ctx.eng = eng
             out, tape = eng.train_model_forward(x.detach(), timesteps, p_drop, p_pe, seed)
             if block is not None and block.side is not None:

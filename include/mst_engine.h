@@ -116,6 +116,10 @@ void mst_schedule_destroy(mst_schedule* s);
  * ----------------------------------------------------------------------------------------- */
 int mst_set_text(mst_engine* e, const float* text_emb_dev, const float* keep_dev,
                  int32_t batch, int32_t cfg, void* stream);
+/* The training-mode mask_cond (model/mdm_forstyledataset.py:288-296 / :592-600: `cond * (1. - bernoulli(ones(bs) * p))`) with the
+ * mask handed over as drawn: drop_dev float32 [batch], 1 = the clip's text embedding is dropped.  Same projection, one
+ * elementwise launch less on the caller's side than masking first and calling mst_set_text. */
+int mst_set_text_dropped(mst_engine* e, const float* text_emb_dev, const float* drop_dev, int32_t batch, void* stream);
 
 /* -------------------------------------------------------------------------------------------
  * one model evaluation: replaces StyleDiffusion.forward / MDM.forward (:602-625, :315-364) and,

@@ -1,0 +1,12 @@
+# Round 6: the torch glue of a chained step cut from ~9 to ~2 launches (cached constant timesteps and their respacing; mask_cond's Bernoulli
+# mask applied inside the text projection, mst_set_text_dropped; MST_GLUE_CACHE=0 = as before): boundary / training-loop tests, then the
+# fine-tune line off / on, three alternating rounds
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout -k 10 900 python -m pytest tests/test_gpu_boundary.py tests/test_gpu_training_loop.py tests/test_gpu_train_fullsize.py tests/test_gpu_train.py -x -q -m gpu > gpurun_out/r6_glue_tests.log 2>&1; rc=$?
+tail -2 gpurun_out/r6_glue_tests.log
+[ $rc = 0 ] || { grep -E "^E |Error|assert" gpurun_out/r6_glue_tests.log | head -30; exit $rc; }
+for r in 1 2 3; do for v in 0 1; do
+  MST_GLUE_CACHE=$v timeout -k 10 300 python bench.py --mode finetune --steps 50 --warmup 5 --no-cpu-baseline > gpurun_out/ftab.log 2>&1 || { tail -5 gpurun_out/ftab.log; exit 1; }
+  tail -1 gpurun_out/ftab.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('MST_GLUE_CACHE=$v', d['ms_per_step'], 'ms/iteration, host enqueue', d['host_enqueue_ms_per_step'])"
+done; done 2>&1 | tee gpurun_out/r6_glue_ab2.txt
