@@ -28,6 +28,9 @@ class FusedStepFn(torch.autograd.Function):
                                      mask_noise=mask_noise, clip_denoised=clip_denoised)
         ctx.schedule, ctx.sampler, ctx.eta = schedule, int(sampler), float(eta)
         ctx.has_blend = mask is not None and motion is not None
+        # an output without a gradient arrives as None, not as a zero tensor: in the chained steps `sample` is cut from the graph (x.detach()),
+        # and autograd would otherwise fill a zero tensor per step in front of k_step_backward (six launches on the chain's backward pass)
+        ctx.set_materialize_grads(False)
         # clip_denoised (the reference signature's default): x0-hat = clamp(blend, -1, 1); its gradient mask is read off the output
         ctx.save_for_backward(t, mask if ctx.has_blend else None, pred if clip_denoised else None)
         return sample, pred
@@ -35,6 +38,8 @@ class FusedStepFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_sample, g_pred):
         t, mask, pred_clipped = ctx.saved_tensors
+        if g_pred is None and g_sample is None:
+            return (None,) * 11
         ref = g_pred if g_pred is not None else g_sample
         gs = None if g_sample is None else _cuda_f32(g_sample.contiguous(), "g_sample")
         gp = None if g_pred is None else _cuda_f32(g_pred.contiguous(), "g_pred")

@@ -354,7 +354,7 @@ class GaussianDiffusion:
         lo = stop_timesteps if stop_timesteps is not None else 0
         indices = list(range(lo, self.num_timesteps - skip_timesteps))[::-1]
         if init_image is not None:
-            my_t = th.ones([shape[0]], device=device, dtype=th.long) * indices[0]
+            my_t = self._const_timesteps(indices[0], shape[0], device)      # (= ones([n]) * indices[0] of the reference, :768 / :1056: a cached constant)
             img = self.q_sample(init_image, my_t, img, model_kwargs=model_kwargs)
         return device, img, indices
 
