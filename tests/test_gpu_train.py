@@ -505,3 +505,60 @@ def test_chained_calls_share_one_backward_pass(monkeypatch):
     t0 = eng.train_tape(n, T + 1, zero=True)
     o_slot, _ = eng.train_model_forward(xs[1], ts[1], 0.0, 0.0, 0, tape=t0, clip0=1, tape_clips=n)
     assert torch.equal(o_own, o_slot)
+
+
+def test_training_call_head_variants_give_the_same_forward(monkeypatch):
+    """Round 6 (docs/LAB_NOTES.md R6.17): the head of a training model call lost three launches -- the timestep MLP (its output for EVERY timestep
+    is a table, MST_TEMB_TABLE), PositionalEncoding's dropout (inside the embedding kernel's epilogue, MST_TRAIN_FUSE_PE_DROP), and mask_cond's
+    elementwise masking (the Bernoulli mask scales the row inside the text projection, mst_set_text_dropped).  Engines built with each switched
+    off (read when the engine is created): the table changes NO bit (same kernels, same rows), the fused dropout only the rounding of the
+    stream's lo halves (it now acts before the hi / lo split), and the dropped-text projection equals the projection of the masked embedding."""
+    from mst_amd.engine import DenoiserEngine
+    F, T, B = 181, 76, 3
+    w = syn.denoiser_state(SEED, F)
+
+    def build(**env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = DenoiserEngine(F, T, 4, device=_dev())
+        for k in env:
+            monkeypatch.delenv(k)
+        e.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, pe=torch.from_numpy(syn.positional_table(5000, 512)))
+        return e
+
+    x = _cu(syn.normal(SEED, "head/x", (B, F, 1, T)))
+    t = torch.tensor([950, 3, 412], device=_dev())
+    txt = _cu(syn.normal(SEED, "head/txt", (B, 512)))
+    drop = torch.tensor([0.0, 1.0, 0.0], device=_dev())
+    seed, p = 20261005, 0.1
+    res = {}
+    for name, env in (("default", {}), ("no table", {"MST_TEMB_TABLE": "0"}), ("dropout launch", {"MST_TRAIN_FUSE_PE_DROP": "0"})):
+        e = build(**env)
+        e.set_text(txt, drop=drop)
+        proj_dropped = e.debug_buffer("textproj", B, 512).clone()
+        e.set_text(txt * (1.0 - drop).view(-1, 1))
+        assert torch.equal(e.debug_buffer("textproj", B, 512), proj_dropped), name
+        e.set_text(txt, drop=drop)
+        out, tape = e.train_model_forward(x, t, p, p, seed)
+        again, _ = e.train_model_forward(x, t, p, p, seed)
+        assert torch.equal(out, again), name
+        res[name] = out
+    assert torch.equal(res["default"], res["no table"]), "the timestep-embedding table changed the forward pass"
+    err = rel_l2(res["default"].cpu().numpy(), res["dropout launch"].cpu().numpy())
+    print("PositionalEncoding dropout inside the embedding epilogue vs its own launch:", err)
+    assert err < 2e-4, err
+    # a reload of the (frozen) timestep MLP rebuilds the table
+    e = build()
+    e.set_text(txt)
+    a, _ = e.train_model_forward(x, t, 0.0, 0.0, 0)
+    w2 = dict(w)
+    key = next(k for k in w if k.endswith("embed_timestep.time_embed.2.bias"))
+    w2[key] = w[key] + 0.5
+    e.load_state_dict({k: torch.from_numpy(v) for k, v in w2.items()}, pe=torch.from_numpy(syn.positional_table(5000, 512)))
+    e.set_text(txt)
+    b, _ = e.train_model_forward(x, t, 0.0, 0.0, 0)
+    ref = build(MST_TEMB_TABLE="0")
+    ref.load_state_dict({k: torch.from_numpy(v) for k, v in w2.items()}, pe=torch.from_numpy(syn.positional_table(5000, 512)))
+    ref.set_text(txt)
+    c, _ = ref.train_model_forward(x, t, 0.0, 0.0, 0)
+    assert not torch.equal(a, b) and torch.equal(b, c), "the table was not rebuilt behind a reload of the timestep MLP"
