@@ -230,6 +230,8 @@ class DenoiserEngine:
         if drop is not None:
             assert keep is None and not cfg
             dr = _f32c(drop.reshape(-1), self.device, "drop")
+            if dr.numel() != te.shape[0]:
+                raise ValueError(f"set_text: a drop mask of {dr.numel()} entries for {te.shape[0]} text embeddings")
             N.check(N.lib().mst_set_text_dropped(self.handle, N.ptr(te), N.ptr(dr), te.shape[0], N.stream_ptr(self.device)))
             self._text_keepalive = (te, dr)
             return

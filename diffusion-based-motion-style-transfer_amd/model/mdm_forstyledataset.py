@@ -227,6 +227,7 @@ class _EngineHost:
         prior = self._prior()
         enc = y['text_embed'] if y.get('text_embed') is not None else prior.encode_text(y['text'])
         force = y.get('uncond', False)
+        self.__dict__.pop("_mst_cond_drop", None)          # (nothing left over from a call that raised before its node consumed it)
         if not force and self.training and self.cond_mask_prob > 0. and _os_environ_get("MST_GLUE_CACHE", "1") != "0":
             # mask_cond (:592-600) with the mask handed to the engine as drawn: cond * (1 - drop) happens inside the text projection's launch
             # (mst_set_text_dropped).  Same draw from the same generator state as `bernoulli(ones(bs) * p)`.
