@@ -152,6 +152,13 @@ struct TrainWS {
     bool layer_done[16] = {false};
     float* part = nullptr;                              // split-K partial products
     float* ln_part = nullptr;                           // k_ln_bwd's per-block [dgamma | dbeta | dbias] partials (dgrad stream)
+    float* ln_part2 = nullptr;                          // ... LayerNorm2's, when both LayerNorms of a layer are finished by one launch (round 6)
+    // round 6: a layer's split-K reduces wait for ONE batched launch at the layer's end (train_stack_backward sets red_defer around its layers;
+    // each weight gradient then gets a region of `part` of its own).  MST_WGRAD_REDUCE_BATCH=0: a reduce behind every weight gradient.
+    RedJobs red_jobs{};
+    int n_red = 0;
+    bool red_defer = false;
+    size_t part_used = 0, part_cap = 0;
     float* cs_part = nullptr;                           // k_colsum_f16's per-row-block bias-gradient partials (wgrad stream)
     float* zeros = nullptr;                             // zero bias
     float* gscale = nullptr;                            // [0] scale applied to the incoming gradient, [1] its inverse
@@ -443,7 +450,7 @@ extern "C" void mst_engine_destroy(mst_engine* e) {
     {
         TrainWS& t = e->tw;
         void* p[] = {t.g0, t.g1, t.dbr2[0], t.dbr2[1], t.dbr1[0], t.dbr1[1], t.dpre[0], t.dpre[1], t.dqkv[0], t.dqkv[1],
-                     t.datt, t.part, t.zeros, t.gscale, t.amax, t.ln_part, t.cs_part, t.hidr[0], t.hidr[1]};
+                     t.datt, t.part, t.zeros, t.gscale, t.amax, t.ln_part, t.cs_part, t.hidr[0], t.hidr[1], t.ln_part2};
         if (t.ev_ready) (void)hipEventDestroy(t.ev_ready);
         for (int i = 0; i < 16; i++) if (t.ev_layer[i]) (void)hipEventDestroy(t.ev_layer[i]);
         for (int i = 0; i < 2; i++) if (t.ev_side[i]) (void)hipEventDestroy(t.ev_side[i]);
@@ -1941,13 +1948,26 @@ static int train_ws(mst_engine* e) {
     HIPCHECK(hipEventCreateWithFlags(&t.ev_ready, hipEventDisableTiming));
     for (int i = 0; i < 16; i++) HIPCHECK(hipEventCreateWithFlags(&t.ev_layer[i], hipEventDisableTiming));
     CHECK(dmalloc(&t.datt, Mp * MST_D));
-    CHECK(dmalloc(&t.part, t.split_cap * (size_t)3 * MST_D * MST_D));
+    t.part_cap = t.split_cap * (size_t)3 * MST_D * MST_D;
+    CHECK(dmalloc(&t.part, t.part_cap));
     CHECK(dmalloc(&t.ln_part, (size_t)512 * 3 * MST_D));
+    CHECK(dmalloc(&t.ln_part2, (size_t)512 * 3 * MST_D));
     CHECK(dmalloc(&t.cs_part, (Mp / 128 + 2) * (size_t)3 * MST_D));
     CHECK(dmalloc(&t.zeros, 3 * MST_D + MST_D));          // zero bias [1536] + a 512-float dump for unwanted reductions
     CHECK(dmalloc(&t.gscale, 2));
     CHECK(dmalloc(&t.amax, 1));
     t.ready = true;
+    return 0;
+}
+
+static int wgrad_flush(mst_engine* e, hipStream_t st) {
+    TrainWS& t = e->tw;
+    if (t.n_red) {
+        hipLaunchKernelGGL(k_splitk_reduce_multi, dim3(768, t.n_red), dim3(256), 0, st, t.red_jobs, t.gscale);
+        HIPCHECK(hipGetLastError());
+    }
+    t.n_red = 0;
+    t.part_used = 0;
     return 0;
 }
 
@@ -1994,7 +2014,10 @@ static int wgrad(mst_engine* e, const f16* dY, int n_out, const f16* X, int k_in
         e->prof_now = prof_keep;
         HIPCHECK(hipGetLastError());
     } else {
-        DEpiF32 epi{nullptr, t.part, k_in, n_out};
+        const bool defer = t.red_defer && t.n_red < 4 && t.part_used + (size_t)nsplit * nelem <= t.part_cap;
+        if (!defer) CHECK(wgrad_flush(e, st));               // (pending regions start at offset 0 as well)
+        float* part = t.part + (defer ? t.part_used : 0);
+        DEpiF32 epi{nullptr, part, k_in, n_out};
         {
             ProfScope ps(e, FAM_WGRAD, st);
             if (xcd) hipLaunchKernelGGL(kern, dim3(tiles * nsplit), dim3(512), WgTile::SMEM, st, dY, n_out, X, k_in, M, kchunk, nelem, epi, tiles);
@@ -2002,8 +2025,13 @@ static int wgrad(mst_engine* e, const f16* dY, int n_out, const f16* X, int k_in
         }
         e->prof_now = prof_keep;
         HIPCHECK(hipGetLastError());
-        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((nelem / 4 + 255) / 256)), dim3(256), 0, st, t.part, nsplit, nelem, t.gscale, dW);
-        HIPCHECK(hipGetLastError());
+        if (defer) {
+            t.red_jobs.j[t.n_red++] = RedJob{part, dW, nelem, nsplit, 0};
+            t.part_used += (size_t)nsplit * nelem;
+        } else {
+            hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((nelem / 4 + 255) / 256)), dim3(256), 0, st, t.part, nsplit, nelem, t.gscale, dW);
+            HIPCHECK(hipGetLastError());
+        }
     }
     if (db) {
         const int rpb = 128, nrb = (M + rpb - 1) / rpb;      // bias gradient: row-block partials, then an ordered sum (no float atomics)
@@ -2076,6 +2104,10 @@ static int train_stack_backward(mst_engine* e, const Tape& t, int rows, int S, f
         CHECK(ensure_dyn_lds((const void*)k_layer_tail_bwd<false, true>, TailBwdCfg::SMEM));
     }
     const bool fused_ln2 = fused_bwd && e->train_fuse_ln2_bwd && !grads;      // (frozen stacks: with gradients dbr2 and LayerNorm2's sums must reach HBM anyway)
+    static const int red_batch = [] { const char* v = getenv("MST_WGRAD_REDUCE_BATCH"); return v ? atoi(v) : 1; }();
+    w_.red_defer = red_batch != 0 && grads != nullptr;
+    w_.n_red = 0;
+    w_.part_used = 0;
     for (int l = nl - 1; l >= 0; l--) {
         const LayerW& w = e->L[l];
         const TapeL& a = t.L[l];
@@ -2089,10 +2121,14 @@ static int train_stack_backward(mst_engine* e, const Tape& t, int rows, int S, f
         for (int i = 0; i < 12; i++) if (!G[i]) return fail("mst_train_backward: null gradient buffer (layer %d, tensor %d)", l, i);
         if (two && side_used[par]) HIPCHECK(hipStreamWaitEvent(st, w_.ev_side[par], 0));
         // LayerNorm2 backward: gB -> dz2 (gA, fp32) and the branch gradient dbr2 (f16); dgamma2, dbeta2, db2
+        // (round 6, MST_LN_FINISH_MERGE: with parameter gradients and the unfused tail, LayerNorm2's partial sums wait in a buffer of their own and
+        // ONE launch behind LayerNorm1's backward finishes both -- a launch less per layer on the dgrad chain, same sums in the same order)
+        static const int merge_on = [] { const char* v = getenv("MST_LN_FINISH_MERGE"); return v ? atoi(v) : 1; }();
+        const bool merge_fin = merge_on && wg && !fused_bwd;
         if (!fused_ln2) {
         hipLaunchKernelGGL(ln_bwd, dim3(ln_blocks), dim3(64 * ln_wpb), 0, st, gB, a.z2h, a.z2l, w.g2, M, make_drop(seed, l, 3, p_drop), w_.gscale,
-                           gA, dbr2, w_.ln_part);
-        if (wg) hipLaunchKernelGGL(k_ln_bwd_finish, dim3(3 * MST_D / kFinOut), dim3(256), 0, st, w_.ln_part, ln_blocks, w_.gscale, G[10], G[11], G[7]);
+                           gA, dbr2, merge_fin ? w_.ln_part2 : w_.ln_part);
+        if (wg && !merge_fin) hipLaunchKernelGGL(k_ln_bwd_finish, dim3(3 * MST_D / kFinOut), dim3(256), 0, st, w_.ln_part, ln_blocks, w_.gscale, G[10], G[11], G[7]);
         HIPCHECK(hipGetLastError());
         }
         // d pre = (dbr2 W2) * mask * gelu'(pre); the same epilogue regenerates hid = dropout(GELU(pre)), dW2's operand, from the pre it reads
@@ -2127,7 +2163,9 @@ static int train_stack_backward(mst_engine* e, const Tape& t, int rows, int S, f
             // g(x1) = dpre W1 + dz2 and LayerNorm1's backward behind it in ONE launch (DEpiLnBwd): dz1 -> gA in place, dbr1, the tiles' sums
             DEpiLnBwd epi{gA, a.z1h, a.z1l, w.g1, M, make_drop(seed, l, 1, p_drop), gA, dbr1, w_.ln_part};
             CHECK((launch_gemm_dma<64, 512, 2, 2, LN_NS, 1, LN_BK>(dim3(ln_tiles, 1), RowsDirect{dpre, MST_FF}, w.w1T, MST_FF, MST_FF, epi, st)));
-            if (wg) hipLaunchKernelGGL(k_ln_bwd_finish, dim3(3 * MST_D / kFinOut), dim3(256), 0, st, w_.ln_part, ln_tiles, w_.gscale, G[8], G[9], G[3]);
+            if (merge_fin) hipLaunchKernelGGL(k_ln_bwd_finish2, dim3(3 * MST_D / kFinOut, 2), dim3(256), 0, st, LnFinJob{w_.ln_part2, ln_blocks, G[10], G[11], G[7]},
+                                              LnFinJob{w_.ln_part, ln_tiles, G[8], G[9], G[3]}, w_.gscale);
+            else if (wg) hipLaunchKernelGGL(k_ln_bwd_finish, dim3(3 * MST_D / kFinOut), dim3(256), 0, st, w_.ln_part, ln_tiles, w_.gscale, G[8], G[9], G[3]);
             HIPCHECK(hipGetLastError());
         } else {
         // g(x1) = dpre W1 + dz2  -> gB
@@ -2139,7 +2177,9 @@ static int train_stack_backward(mst_engine* e, const Tape& t, int rows, int S, f
         // LayerNorm1 backward: gB -> dz1 (gA), dbr1 = d(out-proj output); dgamma1, dbeta1, db_out
         hipLaunchKernelGGL(ln_bwd, dim3(ln_blocks), dim3(64 * ln_wpb), 0, st, gB, a.z1h, a.z1l, w.g1, M, make_drop(seed, l, 1, p_drop), w_.gscale,
                            gA, dbr1, w_.ln_part);
-        if (wg) hipLaunchKernelGGL(k_ln_bwd_finish, dim3(3 * MST_D / kFinOut), dim3(256), 0, st, w_.ln_part, ln_blocks, w_.gscale, G[8], G[9], G[3]);
+        if (merge_fin) hipLaunchKernelGGL(k_ln_bwd_finish2, dim3(3 * MST_D / kFinOut, 2), dim3(256), 0, st, LnFinJob{w_.ln_part2, ln_blocks, G[10], G[11], G[7]},
+                                          LnFinJob{w_.ln_part, ln_blocks, G[8], G[9], G[3]}, w_.gscale);
+        else if (wg) hipLaunchKernelGGL(k_ln_bwd_finish, dim3(3 * MST_D / kFinOut), dim3(256), 0, st, w_.ln_part, ln_blocks, w_.gscale, G[8], G[9], G[3]);
         HIPCHECK(hipGetLastError());
         }
         TO_SIDE()
@@ -2155,6 +2195,7 @@ static int train_stack_backward(mst_engine* e, const Tape& t, int rows, int S, f
         CHECK(launch_attn_bwd(a.qkv, a.att, w_.datt, dqkv, S, rows, make_drop(seed, l, 0, p_drop), key_keep, a.lse, small ? 1 : 0, st));
         TO_SIDE()
         if (wg) CHECK(wgrad(e, dqkv, 3 * MST_D, t.sh[l], MST_D, M, G[0], G[1], sw));               // dW_in += dqkv^T x_in, db_in
+        if (wg) CHECK(wgrad_flush(e, sw));                                                         // the layer's split-K reduces, one launch
         if (two && wg) {
             HIPCHECK(hipEventRecord(w_.ev_side[par], sw));
             side_used[par] = true;
@@ -2174,6 +2215,7 @@ static int train_stack_backward(mst_engine* e, const Tape& t, int rows, int S, f
                         : launch_wide(M, MST_D / 256, RowsDirect{dqkv, 3 * MST_D}, w.w_inT, 3 * MST_D, 3 * MST_D, epi, st));
         }
     }
+    w_.red_defer = false;
 #undef TO_SIDE
     if (two)
         for (int i = 0; i < 2; i++)

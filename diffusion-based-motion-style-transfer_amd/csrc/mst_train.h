@@ -212,6 +212,37 @@ __global__ void k_splitk_reduce(const float* __restrict__ part, int nsplit, size
     }
 }
 
+// The split-K reduces of a layer's (up to four) weight gradients in ONE launch (round 6: three launches less per layer on the weight-gradient
+// stream, the tail of the backward pass; every element's adds in the order of k_splitk_reduce).  blockIdx.y = job.
+struct RedJob { const float* part; float* grad; size_t n; int nsplit, pad; };
+struct RedJobs { RedJob j[4]; };
+__global__ void k_splitk_reduce_multi(RedJobs jobs, const float* __restrict__ gscale) {
+    const RedJob jb = jobs.j[blockIdx.y];
+    const float inv = gscale[1];
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < jb.n; i += (size_t)gridDim.x * blockDim.x * 4) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        int z = 0;
+        for (; z + 4 <= jb.nsplit; z += 4) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(jb.part + (size_t)(z + u) * jb.n + i));
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) s[j] += v[u][j];
+        }
+        for (; z < jb.nsplit; z++) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(jb.part + (size_t)z * jb.n + i);
+#pragma unroll
+            for (int j = 0; j < 4; j++) s[j] += v[j];
+        }
+        f32x4 g = *reinterpret_cast<const f32x4*>(jb.grad + i);
+#pragma unroll
+        for (int j = 0; j < 4; j++) g[j] += inv * s[j];
+        *reinterpret_cast<f32x4*>(jb.grad + i) = g;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Training variant of DEpiResidLN: y = LN(z), z = resid + dropout(acc + bias); residual read from (rin),
 // z and y written to their own tape slots (hi/lo pairs).
@@ -761,6 +792,21 @@ __global__ __launch_bounds__(256) void k_ln_bwd_finish(const float* __restrict__
     if (threadIdx.x < kFinOut) {
         const int a = i / MST_D, f = i - a * MST_D;
         float* dst = a == 0 ? dgamma : (a == 1 ? dbeta : dbias);
+        dst[f] += s * gscale[1];
+    }
+}
+
+// Both LayerNorms of a layer in ONE launch (round 6: one launch less per layer on the dgrad chain; the sums and their order are those of two
+// k_ln_bwd_finish launches).  blockIdx.y = 0: job a, 1: job b.
+struct LnFinJob { const float* part; int nblocks; float *dgamma, *dbeta, *dbias; };
+__global__ __launch_bounds__(256) void k_ln_bwd_finish2(LnFinJob ja, LnFinJob jb, const float* __restrict__ gscale) {
+    __shared__ float red[kFinSlices][kFinOut];
+    const LnFinJob j = blockIdx.y ? jb : ja;
+    const int il = threadIdx.x % kFinOut, i = blockIdx.x * kFinOut + il;
+    const float s = ordered_partial_sum(j.part, j.nblocks, 3 * MST_D, il, i, red);
+    if (threadIdx.x < kFinOut) {
+        const int a = i / MST_D, f = i - a * MST_D;
+        float* dst = a == 0 ? j.dgamma : (a == 1 ? j.dbeta : j.dbias);
         dst[f] += s * gscale[1];
     }
 }
